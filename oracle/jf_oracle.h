@@ -1,0 +1,104 @@
+/*
+ * jf_oracle.h -- CPU oracle for the HRTF binaural convolution hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (include/, the
+ * jefferson-2.0_amd package, libjefferson_hip.so) may include, link or call
+ * this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * What it is: a plain-C float32 restatement of the reference's
+ * frequency-domain interpolated path (GPU_FD_COMPLEX / CPU_FD_COMPLEX of
+ * Cindytb/Jefferson-2.0).  Each function cites the reference file:line it
+ * follows (paths relative to the reference's Jefferson/src/).
+ *
+ * PARITY PIN STATUS.  The reference cannot be built in this image (it needs
+ * FFTW3, libsndfile, PortAudio and the CUDA SDK; no stand-ins are written),
+ * and it ships no golden outputs (media/ofile.wav is empty).  What IS pinned
+ * by data the reference itself holds:
+ *   - the ring sizes 56+60+72+72+72+72+72+60+56+45+36+24+12+1 = 710
+ *     (hrtf_signals.cu:10, Universal.cuh:4) -> azimuth_offset[];
+ *   - the 368 compact KEMAR HRIR files (Jefferson/compact), from which the
+ *     710x2 table is rebuilt (tests/golden/kemar_*.npy);
+ *   - the test scenarios and tolerances of precision_test.cu.
+ * The FFT arithmetic lives in un-vendored FFTW3f / cuFFT (CUDA 10.1), so the
+ * float pipeline's numeric outputs are "parity unpinned": they are anchored
+ * to a float64 model of the same formulas (oracle/model64.py) within the
+ * reference's own CPU-vs-GPU tolerance (2e-7 abs, precision_test.cu:2158).
+ *
+ * Variant choices where the reference's CPU and CUDA paths differ
+ * (SURVEY.md App. C): case predicate and (xH, xw, xD) operand order follow
+ * the CUDA path (GPUSoundSource.cu:267-305); the term sum is in the fixed
+ * order ((t0+t1)+t2)+t3 of the CPU path (CPUSoundSource.cpp:244-253).
+ */
+#ifndef JF_ORACLE_H
+#define JF_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JFO_NUM_ELEV 14
+#define JFO_NUM_HRTF 710
+
+typedef struct jfo_engine jfo_engine;
+
+/* hrtf_signals.cu:119-140 -- ring offsets from the float-accumulated loop. */
+void jfo_azimuth_offsets(int off[JFO_NUM_ELEV + 1]);
+/* hrtf_signals.cu:119-124 -- (elevation, (int)round(azi)) of table row j. */
+void jfo_table_positions(int ele[JFO_NUM_HRTF], int azi[JFO_NUM_HRTF]);
+/* hrtf_signals.cu:20-51 */
+int jfo_pick_hrtf(float obj_ele, float obj_azi);
+/* SoundSource.cu:65-105; returns -1 if the elevation ring does not exist
+ * (the reference reads an uninitialised deltaTheta there). */
+int jfo_interp(float ele, float azi, int idx[4], float omegas[6]);
+/* GPUSoundSource.cu:301-316 predicate -> 1..4 */
+int jfo_case(const int idx[4]);
+/* Flatten (idx, omegas) into <=4 (row, weight) terms in accumulation order
+ * (GPUSoundSource.cu:118-292); returns the number of terms. */
+int jfo_terms(const int idx[4], const float omegas[6], int rows[4], float w[4]);
+/* SoundSource.cu:41-54: out = {ele, azi, x, y, z} */
+void jfo_from_spherical(float ele, float azi, float r, float out[5]);
+/* SoundSource.cu:20-36: out = {ele, azi, r}; returns -1 when r == 0 */
+int jfo_from_cartesian(float x, float y, float z, float out[3]);
+/* GPUSoundSource.cu:81-95 + kernels.cu:116-125: D[k] (re,im) k<nc. */
+void jfo_distance_factor(float x, float y, float z, int nc, float *D);
+/* hrtf_signals.cu:107-153: unnormalised r2c of each zero-padded HRIR.
+ * hrir [n][2][taps] -> table [n][2][N/2+1][2]. */
+void jfo_build_table(const float *hrir, int n_hrtf, int taps, int N, float *table);
+
+/* Unnormalised forward r2c / inverse c2r of length N (power of two) with the
+ * oracle's own float32 FFT -- exposed so tests can check it against numpy. */
+void jfo_rfft(const float *x, int N, float *X /* (N/2+1)*2 */);
+void jfo_irfft(const float *X, int N, float *y /* N */);
+
+/* Engine = Data + sources (DataTag.cuh:9-17, SoundSource.cuh, CPUSoundSource.h). */
+jfo_engine *jfo_create(int frames_per_buffer, int hrtf_len, int n_sources,
+                       const float *hrir /* [710][2][taps] */, int taps);
+void jfo_destroy(jfo_engine *e);
+int jfo_pad_len(const jfo_engine *e);
+/* cudaPart.cu:198-199 (buf/length); the engine copies. */
+int jfo_source_set_signal(jfo_engine *e, int s, const float *mono, int n);
+int jfo_source_set_spherical(jfo_engine *e, int s, float ele, float azi, float r);
+int jfo_source_set_cartesian(jfo_engine *e, int s, float x, float y, float z);
+/* precision_test.cu:2097-2107: zero window, count = 0, old = (0,0). */
+void jfo_source_reset(jfo_engine *e, int s);
+/* Audio.cu:94-163 with CPU-path timing (zero latency): out[2*B] overwritten. */
+void jfo_process_block(jfo_engine *e, float *out);
+/* Last per-source stereo block (2*B floats) of source s, for stage tests. */
+const float *jfo_source_last_block(const jfo_engine *e, int s);
+/*
+ * Batch form used for the timed CPU baseline and large parity cases:
+ * n_blocks blocks for every source, positions given per (source, block) as
+ * latched values {ele, azi, x, y, z} (pos[(s*n_blocks + b)*5 ..]); sources are
+ * processed in parallel with OpenMP (n_threads <= 0 -> all), each into its own
+ * partial, then mixed in source order.  out_mix [n_blocks][2*B];
+ * out_partial (may be NULL) [n_sources][n_blocks][2*B].
+ */
+void jfo_process_batch(jfo_engine *e, int n_blocks, const float *pos,
+                       float *out_mix, float *out_partial, int n_threads);
+int jfo_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,299 @@
+"""float64 NumPy model of the reference's HRTF convolution path.
+
+TEST INFRASTRUCTURE ONLY (same rules as oracle/jf_oracle.h): imported only by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+
+It evaluates the reference's formulas in float64 while
+keeping every quantity the reference holds in a float32 variable (weights,
+radius, fsvs, frac, crossfade ramp, HRIR samples, input samples) at its float32
+value, so it is "the reference with an exact FFT and exact pointwise maths".
+It is the truth the float32 paths (C oracle, HIP kernel) are measured against;
+tolerances are stated in the tests.  Parity with the reference binary itself is
+unpinned (no golden outputs exist; see jf_oracle.h).
+
+The index/weight functions are a second, independent restatement of
+SoundSource.cu:65-105 and hrtf_signals.cu:20-51 in float32 NumPy scalars; the
+tests require them to agree bit-for-bit with the C oracle.
+
+Citations are relative to /root/reference/Jefferson/src/.
+"""
+import math
+
+import numpy as np
+
+f32 = np.float32
+PI = 3.14159265358979323846264338327950288  # Universal.cuh:14-16
+
+NUM_ELEV = 14
+NUM_HRTF = 710
+ELEVATION_POS = [-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90]
+AZIMUTH_INC = [f32(v) for v in (6.43, 6.00, 5.00, 5.00, 5.00, 5.00, 5.00, 6.00,
+                                6.43, 8.00, 10.00, 15.00, 30.00, 361.0)]
+
+
+def _c_round(x):
+    """std::round on a float: half away from zero."""
+    x = float(x)
+    return f32(math.copysign(math.floor(abs(x) + 0.5), x))
+
+
+def _c_div(a, b):
+    """C integer division (truncates toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def azimuth_offsets():
+    """hrtf_signals.cu:119-140."""
+    off = [0]
+    j = 0
+    for i in range(NUM_ELEV):
+        azi = f32(0)
+        while azi < 360:
+            j += 1
+            azi = f32(azi + AZIMUTH_INC[i])
+        off.append(j)
+    return off
+
+
+AZIMUTH_OFFSET = azimuth_offsets()
+
+
+def table_positions():
+    """(elevation, (int)round(azi)) for each of the 710 rows (hrtf_signals.cu:121-124)."""
+    out = []
+    for i in range(NUM_ELEV):
+        azi = f32(0)
+        while azi < 360:
+            out.append((ELEVATION_POS[i], int(_c_round(azi))))
+            azi = f32(azi + AZIMUTH_INC[i])
+    return out
+
+
+def pick_hrtf(obj_ele, obj_azi):
+    """hrtf_signals.cu:20-51."""
+    obj_ele = f32(_c_round(f32(obj_ele) / f32(10)) * f32(10))
+    dmin = f32(1e37)
+    ele_idx = 0
+    for i in range(NUM_ELEV):
+        d = f32(obj_ele - f32(ELEVATION_POS[i]))
+        d = d if d > 0 else -d
+        if d < dmin:
+            dmin, ele_idx = d, i
+    obj_azi = _c_round(obj_azi)
+    dmin = f32(1e37)
+    hrtf_idx = 0
+    n = AZIMUTH_OFFSET[ele_idx + 1] - AZIMUTH_OFFSET[ele_idx]
+    for i in range(n):
+        d = f32(obj_azi - f32(f32(i) * AZIMUTH_INC[ele_idx]))
+        d = d if d > 0 else -d
+        if d < dmin:
+            dmin, hrtf_idx = d, AZIMUTH_OFFSET[ele_idx] + i
+    return hrtf_idx
+
+
+def interp(ele, azi):
+    """SoundSource.cu:65-105 -> (idx[4], omegas[6] float32) or None (missing ring)."""
+    ele, azi = f32(ele), f32(azi)
+    phi0 = _c_div(int(ele), 10) * 10
+    phi1 = _c_div(int(f32(ele + f32(9))), 10) * 10
+    omE = f32(f32(ele - f32(phi0)) / f32(10))
+    omF = f32(f32(f32(phi1) - ele) / f32(10))
+    dt1 = dt2 = None
+    for i in range(NUM_ELEV):
+        if phi0 == ELEVATION_POS[i]:
+            dt1 = AZIMUTH_INC[i]
+        if phi1 == ELEVATION_POS[i]:
+            dt2 = AZIMUTH_INC[i]
+            break
+    if dt1 is None or dt2 is None:
+        return None
+
+    def lo(dt):
+        return int(f32(f32(int(f32(azi / dt))) * dt))
+
+    def hi(dt):
+        return int(f32(f32(int(f32(f32(f32(azi + dt) - f32(1)) / dt))) * dt))
+
+    th = [lo(dt1), hi(dt1), lo(dt2), hi(dt2)]
+    omA = f32(f32(azi - f32(th[0])) / dt1)
+    omB = f32(f32(f32(th[1]) - azi) / dt1)
+    omC = f32(f32(azi - f32(th[2])) / dt2)
+    omD = f32(f32(f32(th[3]) - azi) / dt2)
+    idx = [pick_hrtf(phi0, th[0]), pick_hrtf(phi0, th[1]),
+           pick_hrtf(phi1, th[2]), pick_hrtf(phi1, th[3])]
+    return idx, [omA, omB, omC, omD, omE, omF]
+
+
+def case_of(h):
+    """GPUSoundSource.cu:301-316."""
+    if h[0] == h[1] == h[2] == h[3]:
+        return 1
+    if h[0] == h[2] and h[1] == h[3]:
+        return 2
+    if h[0] == h[1] and h[0] != h[2]:
+        return 3
+    return 4
+
+
+def terms(h, om):
+    """(row, weight float32) list in accumulation order (GPUSoundSource.cu:118-292)."""
+    c = case_of(h)
+    if c == 1:
+        return [(h[0], f32(1))]
+    if c == 2:
+        return [(h[0], om[1]), (h[1], om[0])]
+    if c == 3:
+        return [(h[0], om[5]), (h[2], om[4])]
+    return [(h[0], f32(om[5] * om[1])), (h[1], f32(om[5] * om[0])),
+            (h[2], f32(om[4] * om[3])), (h[3], f32(om[4] * om[2]))]
+
+
+def from_spherical(ele, azi, r):
+    """SoundSource.cu:41-54 -> (ele, azi, (x, y, z)) all float32."""
+    ele, azi, r = _c_round(ele), _c_round(azi), f32(r)
+    x = f32(float(r) * math.sin(float(azi) * PI / 180.0))
+    z = f32(float(r) * -math.cos(float(azi) * PI / 180.0))
+    y = f32(float(r) * math.sin(float(ele) * PI / 180.0))
+    return ele, azi, (x, y, z)
+
+
+def from_cartesian(x, y, z):
+    """SoundSource.cu:20-36 -> (ele, azi, r) float32, or None when r == 0."""
+    x, y, z = f32(x), f32(y), f32(z)
+    r = np.sqrt(f32(f32(f32(x * x) + f32(z * z)) + f32(y * y)))
+    hr = np.sqrt(f32(f32(x * x) + f32(z * z)))
+    if r == 0:
+        return None
+    ele = f32(float(f32(np.arctan2(y, hr) * f32(180.0))) / PI)
+    azi = f32(float(f32(np.arctan2(f32(-x / r), f32(-z / r)) * f32(180.0))) / PI)
+    if azi < 0:
+        azi = f32(azi + f32(360))
+    return _c_round(ele), _c_round(azi), f32(r)
+
+
+def distance_params(coords):
+    """GPUSoundSource.cu:81-90: (r' , fsvs, frac) as float32."""
+    x, y, z = (f32(c) for c in coords)
+    r = np.sqrt(f32(f32(f32(x * x) + f32(y * y)) + f32(z * z)))
+    r = f32(r / f32(5))
+    fsvs = f32(44100.0 / 343.0)
+    frac = f32(f32(1) + f32(fsvs * f32(float(r) ** 2)))
+    return r, fsvs, frac
+
+
+def distance_factor(coords, nc):
+    """kernels.cu:116-125 in float64 (complex128[nc])."""
+    r, fsvs, frac = distance_params(coords)
+    i = np.arange(nc, dtype=np.float64)
+    ph = 2 * PI * float(fsvs) * float(r) * i / nc
+    return (np.cos(ph) - 1j * np.sin(ph)) / float(frac)
+
+
+def build_table(hrir, N):
+    """hrtf_signals.cu:107-153: unnormalised r2c of zero-padded HRIRs, float64.
+    hrir float32 [n][2][taps] -> complex128 [n][2][N/2+1]."""
+    return np.fft.rfft(hrir.astype(np.float64), n=N, axis=-1)
+
+
+class Source:
+    def __init__(self, N):
+        self.buf = np.zeros(0, np.float32)
+        self.count = 0
+        self.x = np.zeros(N, np.float64)
+        # SoundSource.cu:3-16
+        self.ele, self.azi, self.r = f32(0), f32(0), f32(0.5)
+        self.coords = (f32(0), f32(0), f32(0.5))
+        self.old_ele, self.old_azi = f32(0), f32(0)
+        self.last = None
+
+
+class Model:
+    """Data + sources + callback_func (Audio.cu:94-163, CPU timing: zero latency)."""
+
+    def __init__(self, frames_per_buffer, hrtf_len, n_sources, hrir):
+        self.B = int(frames_per_buffer)
+        self.N = int(2 ** math.ceil(math.log2(self.B + hrtf_len - 1)))  # Universal.cuh:12
+        self.Nc = self.N // 2 + 1
+        assert hrir.shape[0] == NUM_HRTF and hrir.shape[1] == 2
+        self.table = build_table(np.asarray(hrir, np.float32), self.N)
+        self.src = [Source(self.N) for _ in range(n_sources)]
+        i = np.arange(self.B, dtype=np.float32)
+        fn = (i / f32(self.B - 1.0)).astype(np.float32)  # kernels.cu:134
+        self.fade_new = fn.astype(np.float64)
+        self.fade_old = (f32(1.0) - fn).astype(np.float64)
+
+    def set_signal(self, s, mono):
+        self.src[s].buf = np.asarray(mono, np.float32).copy()
+        self.src[s].count = 0
+
+    def set_spherical(self, s, ele, azi, r):
+        q = self.src[s]
+        q.ele, q.azi, q.coords = from_spherical(ele, azi, r)
+        q.r = f32(r)
+
+    def set_cartesian(self, s, x, y, z):
+        q = self.src[s]
+        q.ele, q.azi, q.r = from_cartesian(x, y, z)
+        q.coords = (f32(x), f32(y), f32(z))
+
+    def reset(self, s):
+        q = self.src[s]
+        q.x[:] = 0
+        q.count = 0
+        q.old_ele, q.old_azi = f32(0), f32(0)
+
+    def _filter(self, X, D, h, om):
+        Y = np.zeros((2, self.Nc), np.complex128)
+        for row, w in terms(h, om):
+            Y += float(w) * (X[None, :] * self.table[row]) * D[None, :]
+        Y[:, 0] = Y[:, 0].real
+        Y[:, -1] = Y[:, -1].real
+        return np.fft.irfft(Y, n=self.N, axis=-1) * self.N  # unnormalised c2r
+
+    def source_block(self, q, ele, azi, coords):
+        N, B = self.N, self.B
+        L = len(q.buf)
+        if L == 0:
+            new = np.zeros(B)
+        else:
+            pos = (q.count + np.arange(B)) % L
+            new = q.buf[pos].astype(np.float64)
+            q.count = int((q.count + B) % L)
+        q.x[N - B:] = new
+        X = np.fft.rfft(q.x) / N
+        cur = interp(ele, azi)
+        xfade = (q.old_azi != azi) or (q.old_ele != ele)
+        old = interp(q.old_ele, q.old_azi) if xfade else None
+        if cur is None or (xfade and old is None):
+            blk = np.zeros((B, 2))
+        else:
+            D = distance_factor(coords, self.Nc)
+            if not xfade:
+                y = self._filter(X, D, *cur)[:, N - B:]
+            else:
+                y1 = self._filter(X, D, *old)[:, N - B:]
+                y2 = self._filter(X, D, *cur)[:, N - B:]
+                y = y1 * self.fade_old[None, :] + y2 * self.fade_new[None, :]
+            blk = y.T.copy()  # [B][2] interleaved
+        q.old_azi, q.old_ele = f32(azi), f32(ele)
+        q.x[:N - B] = q.x[B:].copy()
+        q.last = blk.reshape(-1)
+        return q.last
+
+    def process_block(self):
+        out = np.zeros(2 * self.B)
+        for q in self.src:
+            out += self.source_block(q, q.ele, q.azi, q.coords)
+        return out
+
+    def process_batch(self, pos):
+        """pos float32 [S][K][5] = latched {ele, azi, x, y, z}; -> mix [K][2B], partial [S][K][2B]."""
+        S, K = pos.shape[0], pos.shape[1]
+        partial = np.zeros((S, K, 2 * self.B))
+        for s, q in enumerate(self.src):
+            for b in range(K):
+                p = pos[s, b]
+                q.ele, q.azi, q.coords = f32(p[0]), f32(p[1]), (f32(p[2]), f32(p[3]), f32(p[4]))
+                partial[s, b] = self.source_block(q, q.ele, q.azi, q.coords)
+        return partial.sum(axis=0), partial
