@@ -1,0 +1,214 @@
+/*
+ * jefferson.h -- C ABI of the MI355X-native HRTF binaural convolution engine.
+ *
+ * Drop-in boundary for the audio-callback / SoundSource-update surface of
+ * Cindytb/Jefferson-2.0.  The reference has no FFI layer: its boundary is a
+ * PortAudio C callback plus public C++ members shared through a global
+ * `Data` object (Jefferson/src/main.cu:12-13).  Every entry point below names
+ * the reference interface it replaces (paths relative to Jefferson/src/).
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes.
+ * Nothing here exits the process or throws (the reference prints and
+ * exit(1)s: cufftDefines.cuh:69-77, Audio.cu:16-55).
+ *
+ * Implemented by libjefferson_hip.so (jefferson-2.0_amd/csrc).  There is no
+ * CPU fallback: if no HIP device is usable, jf_engine_create fails with
+ * JF_ERR_DEVICE.
+ */
+#ifndef JEFFERSON_H
+#define JEFFERSON_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JF_NUM_HRTF 710 /* Universal.cuh:4  NUM_HRTF */
+#define JF_HRTF_CHN 2   /* Universal.cuh:11 HRTF_CHN */
+#define JF_POS_FLOATS 5 /* latched position record: ele, azi, x, y, z */
+
+enum {
+    JF_OK = 0,
+    JF_ERR_ARG = -1,     /* bad argument / out-of-range index */
+    JF_ERR_RANGE = -2,   /* position the reference cannot interpolate (ele outside (-50, 90]) or |coords| == 0 */
+    JF_ERR_DEVICE = -3,  /* HIP runtime error; text in jf_last_error */
+    JF_ERR_IO = -4,      /* HRIR / WAV file problem */
+    JF_ERR_STATE = -5,   /* call out of order (e.g. collect without submit) */
+    JF_ERR_NOMEM = -6
+};
+
+typedef struct jf_engine jf_engine;
+
+/*
+ * Replaces the compile-time constants of Universal.cuh:4-13 and the
+ * constructor arguments of `new GPUSoundSource[num_sources]` (main.cu:60-61).
+ */
+typedef struct jf_config {
+    int frames_per_buffer; /* FRAMES_PER_BUFFER (Universal.cuh:10): 128 or 256 (any multiple of 64 up to 256) */
+    int hrtf_len;          /* HRTF_LEN (Universal.cuh:9): 512 -> PAD_LEN 1024 (Universal.cuh:12) */
+    int n_sources;         /* num_sources (main.cu:60) */
+    int device;            /* HIP device ordinal */
+    int max_batch_blocks;  /* capacity of jf_process_batch / jf_batch_run (>= 1) */
+    unsigned flags;        /* reserved, 0 */
+} jf_config;
+
+/* ---- init / teardown ------------------------------------------------- */
+
+/*
+ * Replaces read_hrtf_signals() + transform_hrtfs() (hrtf_signals.cu:107-153,
+ * :248) and the GPUSoundSource constructors (GPUSoundSource.cu:17-71).
+ * hrir: [JF_NUM_HRTF][2][taps] float32, row order of the reference loader
+ * (elevation-major, azimuth ascending; ear 0 = left), taps <= hrtf_len.
+ * The engine builds the unnormalised 513-bin spectra on the GPU and keeps its
+ * own copies; the caller's buffer is not retained.
+ */
+int jf_engine_create(const jf_config *cfg, const float *hrir, int taps, jf_engine **out);
+
+/*
+ * Same, loading the KEMAR set from a directory with libsndfile-compatible
+ * scaling (int16 / 32768): either the reference's "full" layout
+ * (full/elev%d/L%de%03da.wav + R..., hrtf_signals.cu:124,131) or the "compact"
+ * layout shipped in the reference repo (compact/elev%d/H%de%03da.wav, stereo,
+ * mirrored for azimuth > 180: hrtf_signals.cpp:80-126).
+ */
+int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_engine **out);
+
+/* closeEverything() / cleanup_hrtf_buffers() / ~GPUSoundSource (hrtf_signals.cu:100-105, GPUSoundSource.cu:532-548). */
+void jf_engine_destroy(jf_engine *e);
+
+/* Text of the last error on this engine (or of the last failed create when e == NULL). */
+const char *jf_last_error(const jf_engine *e);
+
+int jf_frames_per_buffer(const jf_engine *e); /* FRAMES_PER_BUFFER */
+int jf_pad_len(const jf_engine *e);           /* PAD_LEN */
+int jf_num_sources(const jf_engine *e);       /* Data::num_sources (DataTag.cuh:14) */
+
+/* ---- source signal and position (SoundSource.cuh:9-46) ---------------- */
+
+/*
+ * Replaces `source.buf / source.length / source.count = 0` set by cudaFFT()
+ * (cudaPart.cu:198-199).  mono float32, looped playback as in
+ * copyIncomingBlock (GPUSoundSource.cu:481-513).  The engine copies (host ->
+ * device); n == 0 silences the source.
+ */
+int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n);
+
+/* SoundSource::updateFromCartesian(float3) (SoundSource.cu:20-36); callable from a
+ * different thread than the audio thread; latched at the next block boundary. */
+int jf_source_set_cartesian(jf_engine *e, int src, float x, float y, float z);
+
+/* SoundSource::updateFromSpherical(ele, azi, r) (SoundSource.cu:41-54). */
+int jf_source_set_spherical(jf_engine *e, int src, float ele, float azi, float r);
+
+/* Reads back {ele, azi, r, x, y, z} (the public fields of SoundSource.cuh:24-36). */
+int jf_source_get_position(const jf_engine *e, int src, float out[6]);
+
+/* test() preamble (precision_test.cu:2097-2107): zero the window, count = 0, old_azi = old_ele = 0. */
+int jf_source_reset(jf_engine *e, int src);
+
+/* The same conversions without an engine, producing the latched record
+ * {ele, azi, x, y, z} used by the batch calls. */
+int jf_position_from_spherical(float ele, float azi, float r, float out[JF_POS_FLOATS]);
+int jf_position_from_cartesian(float x, float y, float z, float out[JF_POS_FLOATS]);
+
+/* SoundSource::interpolationCalculations (SoundSource.cu:65-105) + pick_hrtf
+ * (hrtf_signals.cu:20-51), host side, for inspection/tests. */
+int jf_interpolation(float ele, float azi, int hrtf_indices[4], float omegas[6]);
+int jf_pick_hrtf(float ele, float azi);
+
+/* ---- per-block processing (Audio.cu:94-175) --------------------------- */
+
+/*
+ * callback_func(output, p, false) with the CPU path's timing (Audio.cu:118-158):
+ * block k's input produces block k's output.  out: interleaved stereo
+ * float32, 2 * frames_per_buffer values, fully overwritten.  Synchronous.
+ */
+int jf_process_block(jf_engine *e, float *out);
+
+/*
+ * The CUDA path's pipelining (Audio.cu:104-117): jf_submit_block enqueues
+ * block k (chunkProcess, GPUSoundSource.cu:463-471) and returns at once;
+ * jf_collect_block waits (cudaStreamSynchronize, Audio.cu:107) and returns it.
+ */
+int jf_submit_block(jf_engine *e);
+int jf_collect_block(jf_engine *e, float *out);
+
+/*
+ * callback_func for GPU_FD_COMPLEX exactly as the reference orders it: output
+ * the block submitted by the PREVIOUS call (zeros on the first call), then
+ * submit the next -> one block of latency.
+ */
+int jf_callback(jf_engine *e, float *out);
+
+/*
+ * paCallback (Audio.cu:164-175) with PortAudio's PaStreamCallback signature
+ * (opaque pointers so portaudio.h is not needed); userData is the jf_engine*
+ * (the reference passes &data).  Returns 0 (paContinue).
+ */
+int jf_pa_callback(const void *input, void *output, unsigned long frames_per_buffer,
+                   const void *time_info, unsigned long status_flags, void *user_data);
+
+/* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed. */
+int jf_set_pause(jf_engine *e, int paused);
+
+/* ---- batch (offline / throughput) processing -------------------------- */
+
+/*
+ * n_blocks consecutive callbacks in one call.  positions:
+ * [n_blocks][n_sources][JF_POS_FLOATS] latched records, i.e. what the
+ * reference's audio thread would have read from each source at each block
+ * (crossfade state carries across blocks and across calls).
+ * out_mix: [n_blocks][2 * frames_per_buffer] host buffer.
+ */
+int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *out_mix);
+
+/*
+ * Device-resident form: positions are uploaded once, then any window of them
+ * is processed with no host<->device traffic.  jf_batch_run launches on the
+ * engine's stream and returns without waiting; d_out_mix is a DEVICE pointer
+ * to [n_blocks][2*B] floats (NULL -> the engine's own buffer, see
+ * jf_batch_mix_device).  Blocks first_block .. first_block + n_blocks - 1 of
+ * the uploaded trajectory are consumed.
+ */
+int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *positions);
+int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix);
+int jf_synchronize(jf_engine *e);
+/* Device pointers owned by the engine (valid until destroy). */
+float *jf_batch_mix_device(jf_engine *e);     /* [max_batch_blocks][2*B] */
+float *jf_batch_partial_device(jf_engine *e); /* [max_batch_blocks][n_sources][2*B], per-source blocks of the last run */
+/* hipStream_t the engine launches on, as void*. */
+void *jf_engine_stream(jf_engine *e);
+
+/* Timing of the fused kernel inside jf_batch_run with HIP events recorded on
+ * the engine's stream.  enable != 0 arms it; jf_profile_read waits and returns
+ * the accumulated milliseconds and launch count since arming. */
+int jf_profile_enable(jf_engine *e, int enable);
+int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches);
+
+/* ---- debugging / parity taps ------------------------------------------ */
+
+/* Copy of the device HRTF spectrum table in the REFERENCE layout
+ * fft_hrtf[(j*2 + ear)*Nc + k] (hrtf_signals.cu:90-98), complex64 -> 2 floats. */
+int jf_debug_read_table(jf_engine *e, float *out /* 710*2*Nc*2 */);
+/* Runs only the index/weight kernel on n latched (ele, azi) pairs:
+ * rows[n][4], weights[n][4], nterms[n] (<= 0: not interpolable). */
+int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *azi,
+                           int *rows, float *weights, int *nterms);
+/* Forward real FFT of n windows of PAD_LEN samples with the kernel's LDS FFT
+ * (unnormalised, Nc complex bins each). */
+int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spectra);
+
+/* ---- WAV I/O (cudaPart.cu:21-63 readFile; main.cu:77-82 output file) --- */
+
+/* 16/24/32-bit PCM or float32 WAV -> mono float32 with libsndfile scaling;
+ * stereo is mixed L/2 + R/2 (cudaPart.cu:50-52).  *out is malloc'd; free with jf_free. */
+int jf_wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate);
+/* Interleaved stereo float32 -> 24-bit PCM WAV (SF_FORMAT_PCM_24, main.cu:79). */
+int jf_wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate);
+void jf_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JEFFERSON_H */

@@ -1,0 +1,285 @@
+"""jefferson-2.0_amd -- ctypes binding of libjefferson_hip.so (include/jefferson.h).
+
+Plumbing for tests and bench.py; the product is the C ABI.  The directory name is
+not an importable identifier, so load it with `jf_load.py` at the repo root
+(`from jf_load import jf`).  There is no fallback: if the HIP library is missing
+or no GPU is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjefferson_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
+
+JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+NUM_HRTF = 710
+PAD_LEN = 1024
+NC = 513
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+
+
+class JfConfig(C.Structure):
+    _fields_ = [("frames_per_buffer", C.c_int), ("hrtf_len", C.c_int), ("n_sources", C.c_int),
+                ("device", C.c_int), ("max_batch_blocks", C.c_int), ("flags", C.c_uint)]
+
+
+class JfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"jefferson error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_SIGS = {
+    "jf_engine_create": (C.c_int, [C.POINTER(JfConfig), _f, C.c_int, C.POINTER(C.c_void_p)]),
+    "jf_engine_create_from_dir": (C.c_int, [C.POINTER(JfConfig), C.c_char_p, C.POINTER(C.c_void_p)]),
+    "jf_engine_destroy": (None, [C.c_void_p]),
+    "jf_last_error": (C.c_char_p, [C.c_void_p]),
+    "jf_frames_per_buffer": (C.c_int, [C.c_void_p]),
+    "jf_pad_len": (C.c_int, [C.c_void_p]),
+    "jf_num_sources": (C.c_int, [C.c_void_p]),
+    "jf_source_set_signal": (C.c_int, [C.c_void_p, C.c_int, _f, C.c_size_t]),
+    "jf_source_set_cartesian": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "jf_source_set_spherical": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "jf_source_get_position": (C.c_int, [C.c_void_p, C.c_int, _f]),
+    "jf_source_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_position_from_spherical": (C.c_int, [C.c_float, C.c_float, C.c_float, _f]),
+    "jf_position_from_cartesian": (C.c_int, [C.c_float, C.c_float, C.c_float, _f]),
+    "jf_interpolation": (C.c_int, [C.c_float, C.c_float, _i, _f]),
+    "jf_pick_hrtf": (C.c_int, [C.c_float, C.c_float]),
+    "jf_process_block": (C.c_int, [C.c_void_p, _f]),
+    "jf_submit_block": (C.c_int, [C.c_void_p]),
+    "jf_collect_block": (C.c_int, [C.c_void_p, _f]),
+    "jf_callback": (C.c_int, [C.c_void_p, _f]),
+    "jf_pa_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p, C.c_ulong, C.c_void_p]),
+    "jf_set_pause": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_process_batch": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
+    "jf_batch_upload_positions": (C.c_int, [C.c_void_p, C.c_int, _f]),
+    "jf_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "jf_synchronize": (C.c_int, [C.c_void_p]),
+    "jf_batch_mix_device": (C.c_void_p, [C.c_void_p]),
+    "jf_batch_partial_device": (C.c_void_p, [C.c_void_p]),
+    "jf_engine_stream": (C.c_void_p, [C.c_void_p]),
+    "jf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
+    "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
+    "jf_debug_rfft_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
+    "jf_wav_read_mono": (C.c_int, [C.c_char_p, C.POINTER(_f), C.POINTER(C.c_size_t), _i]),
+    "jf_wav_write_stereo24": (C.c_int, [C.c_char_p, _f, C.c_size_t, C.c_int]),
+    "jf_free": (None, [C.c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names every include/jefferson.h entry point must be exported under."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JfError(JF_ERR_DEVICE, f"{LIB_PATH} is not built (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_i)
+
+
+def position_from_spherical(ele, azi, r):
+    o = np.zeros(5, np.float32)
+    rc = lib().jf_position_from_spherical(ele, azi, r, _fp(o))
+    if rc:
+        raise JfError(rc, "position_from_spherical")
+    return o
+
+
+def position_from_cartesian(x, y, z):
+    o = np.zeros(5, np.float32)
+    rc = lib().jf_position_from_cartesian(x, y, z, _fp(o))
+    return None if rc else o
+
+
+def interpolation(ele, azi):
+    idx = np.zeros(4, np.int32)
+    om = np.zeros(6, np.float32)
+    rc = lib().jf_interpolation(ele, azi, _ip(idx), _fp(om))
+    return None if rc else (idx, om)
+
+
+def pick_hrtf(ele, azi):
+    return lib().jf_pick_hrtf(ele, azi)
+
+
+def wav_read_mono(path):
+    p = _f()
+    n = C.c_size_t()
+    fs = C.c_int()
+    rc = lib().jf_wav_read_mono(path.encode(), C.byref(p), C.byref(n), C.byref(fs))
+    if rc:
+        raise JfError(rc, lib().jf_last_error(None).decode())
+    out = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+    lib().jf_free(p)
+    return out, fs.value
+
+
+def wav_write_stereo24(path, interleaved, fs=44100):
+    a = np.ascontiguousarray(interleaved, np.float32).reshape(-1)
+    rc = lib().jf_wav_write_stereo24(path.encode(), _fp(a), len(a) // 2, fs)
+    if rc:
+        raise JfError(rc, lib().jf_last_error(None).decode())
+
+
+class Engine:
+    """Thin object wrapper; method names follow the C ABI."""
+
+    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1):
+        L = lib()
+        cfg = JfConfig(B, hrtf_len, n_sources, device, max_batch_blocks, 0)
+        h = C.c_void_p()
+        if hrir_dir is not None:
+            rc = L.jf_engine_create_from_dir(C.byref(cfg), hrir_dir.encode(), C.byref(h))
+        else:
+            hrir = np.ascontiguousarray(hrir, np.float32)
+            assert hrir.shape[0] == NUM_HRTF and hrir.shape[1] == 2
+            rc = L.jf_engine_create(C.byref(cfg), _fp(hrir), hrir.shape[2], C.byref(h))
+        if rc:
+            raise JfError(rc, L.jf_last_error(None).decode())
+        self.h = h
+        self.B, self.S, self.maxK = B, n_sources, max_batch_blocks
+        self.N = L.jf_pad_len(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().jf_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise JfError(rc, lib().jf_last_error(self.h).decode())
+
+    def set_signal(self, s, mono):
+        mono = np.ascontiguousarray(mono, np.float32)
+        self._chk(lib().jf_source_set_signal(self.h, s, _fp(mono), len(mono)))
+
+    def set_spherical(self, s, ele, azi, r):
+        return lib().jf_source_set_spherical(self.h, s, ele, azi, r)
+
+    def set_cartesian(self, s, x, y, z):
+        return lib().jf_source_set_cartesian(self.h, s, x, y, z)
+
+    def get_position(self, s):
+        o = np.zeros(6, np.float32)
+        self._chk(lib().jf_source_get_position(self.h, s, _fp(o)))
+        return o
+
+    def reset(self, s):
+        self._chk(lib().jf_source_reset(self.h, s))
+
+    def process_block(self):
+        out = np.zeros(2 * self.B, np.float32)
+        self._chk(lib().jf_process_block(self.h, _fp(out)))
+        return out
+
+    def submit_block(self):
+        return lib().jf_submit_block(self.h)
+
+    def collect_block(self):
+        out = np.zeros(2 * self.B, np.float32)
+        rc = lib().jf_collect_block(self.h, _fp(out))
+        return rc, out
+
+    def callback(self):
+        out = np.zeros(2 * self.B, np.float32)
+        self._chk(lib().jf_callback(self.h, _fp(out)))
+        return out
+
+    def set_pause(self, p):
+        self._chk(lib().jf_set_pause(self.h, int(p)))
+
+    def process_batch(self, pos):
+        pos = np.ascontiguousarray(pos, np.float32)
+        K, S = pos.shape[0], pos.shape[1]
+        assert S == self.S and pos.shape[2] == 5
+        mix = np.zeros((K, 2 * self.B), np.float32)
+        self._chk(lib().jf_process_batch(self.h, K, _fp(pos), _fp(mix)))
+        return mix
+
+    def upload_positions(self, pos):
+        pos = np.ascontiguousarray(pos, np.float32)
+        assert pos.shape[1] == self.S and pos.shape[2] == 5
+        self._chk(lib().jf_batch_upload_positions(self.h, pos.shape[0], _fp(pos)))
+
+    def batch_run(self, first, n, d_out=None):
+        self._chk(lib().jf_batch_run(self.h, first, n, d_out))
+
+    def synchronize(self):
+        self._chk(lib().jf_synchronize(self.h))
+
+    def mix_device_ptr(self):
+        return lib().jf_batch_mix_device(self.h)
+
+    def partial_device_ptr(self):
+        return lib().jf_batch_partial_device(self.h)
+
+    def stream_ptr(self):
+        return lib().jf_engine_stream(self.h)
+
+    def profile_enable(self, on):
+        self._chk(lib().jf_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        f, p, m = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_long()
+        self._chk(lib().jf_profile_read(self.h, C.byref(f), C.byref(p), C.byref(m), C.byref(n)))
+        return {"fused_ms": f.value, "prep_ms": p.value, "mix_ms": m.value, "launches": n.value}
+
+    def read_table(self):
+        t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)
+        self._chk(lib().jf_debug_read_table(self.h, _fp(t)))
+        return t.view(np.complex64)[..., 0]
+
+    def interp_device(self, ele, azi):
+        ele = np.ascontiguousarray(ele, np.float32)
+        azi = np.ascontiguousarray(azi, np.float32)
+        n = len(ele)
+        rows = np.zeros((n, 4), np.int32)
+        w = np.zeros((n, 4), np.float32)
+        nt = np.zeros(n, np.int32)
+        self._chk(lib().jf_debug_interp_device(self.h, n, _fp(ele), _fp(azi), _ip(rows), _fp(w), _ip(nt)))
+        return rows, w, nt
+
+    def rfft_device(self, windows):
+        windows = np.ascontiguousarray(windows, np.float32)
+        n = windows.shape[0]
+        assert windows.shape[1] == PAD_LEN
+        sp = np.zeros((n, NC, 2), np.float32)
+        self._chk(lib().jf_debug_rfft_device(self.h, n, _fp(windows), _fp(sp)))
+        return sp.view(np.complex64)[..., 0]

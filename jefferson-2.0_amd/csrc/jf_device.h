@@ -1,0 +1,77 @@
+// jf_device.h -- shared host/device declarations of the HIP engine (gfx950).
+//
+// Data layout in HBM (all engine-owned):
+//   htab   float4[710][512]   HRTF spectra, both ears interleaved per bin:
+//                             k >= 1: {L.re, L.im, R.re, R.im};
+//                             k == 0: {L[0].re, L[512].re, R[0].re, R[512].re}
+//                             (bins 0 and 512 of a real HRIR are real), so one
+//                             16-byte load per lane fetches both ears and a row
+//                             is exactly 8 KiB.  Same numbers as the reference's
+//                             fft_hrtf[(j*2+ear)*513+k] (hrtf_signals.cu:90-98).
+//   tw     float2[1024]       exp(+2*pi*i*j/1024), from double.
+//   sig    float[len_s]       one device buffer per source (looped playback).
+//   hist   float[2][S][1024]  each source's last window (ping-pong per call).
+//   state  SrcState[2][S]     count / old_ele / old_azi (ping-pong per call).
+//   pos    float[K][S][5]     latched positions {ele, azi, x, y, z} per block.
+//   desc   ItemDesc[K][S]     per (block, source) rows/weights/distance terms.
+//   partial float[K][S][2B]   per-source stereo blocks (reference: intermediate).
+//   mix    float[K][2B]       sum over sources in source order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jf {
+
+constexpr int kN = 1024;       // PAD_LEN (Universal.cuh:12)
+constexpr int kNc = 513;       // PAD_LEN / 2 + 1
+constexpr int kNumHrtf = 710;  // NUM_HRTF (Universal.cuh:4)
+constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
+constexpr int kWavesPerWg = 8; // waves (work items) per workgroup of the fused kernel
+
+struct ItemDesc {
+    int rows_new[4];
+    float w_new[4];
+    int rows_old[4];
+    float w_old[4];
+    double a;        // fsvs * r'  (turns per bin * 513)
+    float inv_frac;  // 1 / (1 + fsvs r'^2)
+    int n_new;       // 1, 2 or 4 terms; 0 = position not interpolable -> silence
+    int n_old;       // 0 = no crossfade
+    int pad;
+};
+static_assert(sizeof(ItemDesc) == 88, "ItemDesc layout");
+
+struct SrcState {
+    int count;      // SoundSource::count
+    float old_ele;  // SoundSource::old_ele
+    float old_azi;  // SoundSource::old_azi
+    int pad;
+};
+
+struct SrcSignal {
+    const float *ptr;  // SoundSource::buf, device copy
+    int length;        // SoundSource::length (0 = silent)
+    int pad;
+};
+
+// hrtf_signals.cu:7-12 tables, filled on the host by the reference's own loop.
+struct RingTable {
+    int offset[kNumElev + 1];
+    float inc[kNumElev];
+};
+
+struct FusedParams {
+    const float4 *htab;
+    const float2 *tw;
+    const ItemDesc *desc;   // [K][S]
+    const SrcSignal *sigs;  // [S]
+    const SrcState *st_in;  // [S]
+    SrcState *st_out;       // [S]
+    const float *hist_in;   // [S][1024]
+    float *hist_out;        // [S][1024]
+    const float *pos;       // [K][S][5] (window of the uploaded trajectory)
+    float *partial;         // [K][S][2B]
+    int S, K, B;
+};
+
+}  // namespace jf

@@ -1,0 +1,608 @@
+// jf_engine.cpp -- implementation of the C ABI (include/jefferson.h) on HIP.
+// One engine = one GPU (one process per GPU in multi-GPU runs).  No CPU
+// fallback: every processing entry point runs the HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/jefferson.h"
+#include "jf_device.h"
+#include "jf_host.h"
+
+namespace jf {
+hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
+hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
+hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
+                               float *d_w, int *d_nt, int n, hipStream_t st);
+hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc, int S,
+                       int K, hipStream_t st);
+hipError_t launch_fused(const FusedParams &P, hipStream_t st);
+hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
+}  // namespace jf
+
+using namespace jf;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct HostPos {  // public fields of SoundSource (SoundSource.cuh:24-36)
+    float ele, azi, r, x, y, z;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+}  // namespace
+
+struct jf_engine {
+    jf_config cfg{};
+    int B = 0, S = 0, maxK = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    float4 *d_htab = nullptr;
+    float2 *d_tw = nullptr;
+    SrcSignal *d_sigs = nullptr;
+    SrcState *d_state[2] = {nullptr, nullptr};
+    float *d_hist[2] = {nullptr, nullptr};
+    ItemDesc *d_desc = nullptr;
+    float *d_partial = nullptr;
+    float *d_mix = nullptr;
+    float *d_pos_rt = nullptr;  // [S][5]
+    float *d_traj = nullptr;    // [total][S][5]
+    int traj_blocks = 0;
+    int cur = 0;  // parity of the valid state/history
+
+    std::vector<float *> d_signal;  // per source
+    std::vector<SrcSignal> h_sigs;
+
+    std::mutex pos_mu;  // setters may come from another thread (graphics.cu:378)
+    std::vector<HostPos> pos;
+    bool paused = false;
+
+    float *h_pos_pinned = nullptr;  // [S][5]
+    float *h_out_pinned = nullptr;  // [2B]
+    bool in_flight = false;         // a submitted block not yet collected
+    bool have_prev = false;         // jf_callback: a block is pending from the previous call
+
+    bool profiling = false;
+    std::vector<EventPair> ev_prep, ev_fused, ev_mix;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(jf_engine *e, int code, const std::string &msg) {
+    if (e)
+        e->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define JF_HIP(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _s = (call);                                                                \
+        if (_s != hipSuccess)                                                                  \
+            return fail((e), JF_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(_s)); \
+    } while (0)
+
+bool valid_src(const jf_engine *e, int s) { return e && s >= 0 && s < e->S; }
+
+EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
+    if (pool.size() <= e->ev_used) {
+        EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        pool.push_back(p);
+    }
+    return &pool[e->ev_used];
+}
+
+// prep -> fused -> mix on the engine stream, K blocks starting at d_pos.
+int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
+    const int p = e->cur;
+    EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
+    if (e->profiling) {
+        ep = next_events(e, e->ev_prep);
+        ef = next_events(e, e->ev_fused);
+        em = next_events(e, e->ev_mix);
+        if (!ep || !ef || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
+    }
+    if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
+    JF_HIP(e, launch_prep(ring_table(), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
+    if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
+    FusedParams P;
+    P.htab = e->d_htab;
+    P.tw = e->d_tw;
+    P.desc = e->d_desc;
+    P.sigs = e->d_sigs;
+    P.st_in = e->d_state[p];
+    P.st_out = e->d_state[p ^ 1];
+    P.hist_in = e->d_hist[p];
+    P.hist_out = e->d_hist[p ^ 1];
+    P.pos = d_pos;
+    P.partial = e->d_partial;
+    P.S = e->S;
+    P.K = K;
+    P.B = e->B;
+    if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
+    JF_HIP(e, launch_fused(P, e->stream));
+    if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
+    if (em) JF_HIP(e, hipEventRecord(em->a, e->stream));
+    JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S, K, e->B, e->stream));
+    if (em) JF_HIP(e, hipEventRecord(em->b, e->stream));
+    if (e->profiling) e->ev_used++;
+    e->cur = p ^ 1;
+    return JF_OK;
+}
+
+void snapshot_positions(jf_engine *e, float *dst /* [S][5] */) {
+    std::lock_guard<std::mutex> lk(e->pos_mu);
+    for (int s = 0; s < e->S; s++) {
+        const HostPos &q = e->pos[s];
+        float *d = dst + 5 * s;
+        d[0] = q.ele;
+        d[1] = q.azi;
+        d[2] = q.x;
+        d[3] = q.y;
+        d[4] = q.z;
+    }
+}
+
+void destroy_engine(jf_engine *e) {
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (float *p : e->d_signal)
+        if (p) (void)hipFree(p);
+    (void)hipFree(e->d_htab);
+    (void)hipFree(e->d_tw);
+    (void)hipFree(e->d_sigs);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(e->d_state[i]);
+        (void)hipFree(e->d_hist[i]);
+    }
+    (void)hipFree(e->d_desc);
+    (void)hipFree(e->d_partial);
+    (void)hipFree(e->d_mix);
+    (void)hipFree(e->d_pos_rt);
+    (void)hipFree(e->d_traj);
+    if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
+    if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
+    for (auto *pool : {&e->ev_prep, &e->ev_fused, &e->ev_mix})
+        for (auto &p : *pool) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine **out) {
+    if (!cfg || !hrir || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
+    *out = nullptr;
+    const int B = cfg->frames_per_buffer;
+    if (B < 64 || B > 256 || B % 64) return fail(nullptr, JF_ERR_ARG, "frames_per_buffer must be 64, 128, 192 or 256");
+    if (cfg->hrtf_len <= 0 || taps <= 0 || taps > cfg->hrtf_len)
+        return fail(nullptr, JF_ERR_ARG, "need 0 < taps <= hrtf_len");
+    // PAD_LEN = 2^ceil(log2(B + L - 1)) (Universal.cuh:12); the kernels are built for 1024
+    const int pad = (int)pow(2, ceil(log2((double)(B + cfg->hrtf_len - 1))));
+    if (pad != kN) return fail(nullptr, JF_ERR_ARG, "frames_per_buffer + hrtf_len - 1 must pad to 1024");
+    if (cfg->n_sources <= 0) return fail(nullptr, JF_ERR_ARG, "n_sources must be positive");
+    if (cfg->max_batch_blocks <= 0) return fail(nullptr, JF_ERR_ARG, "max_batch_blocks must be positive");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, JF_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, JF_ERR_ARG, "device ordinal out of range");
+
+    jf_engine *e = new jf_engine();
+    e->cfg = *cfg;
+    e->B = B;
+    e->S = cfg->n_sources;
+    e->maxK = cfg->max_batch_blocks;
+    const size_t S = (size_t)e->S, K = (size_t)e->maxK;
+    int rc = JF_OK;
+    auto body = [&]() -> int {
+        JF_HIP(e, hipSetDevice(cfg->device));
+        JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
+        JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
+        JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
+        for (int i = 0; i < 2; i++) {
+            JF_HIP(e, hipMalloc(&e->d_state[i], sizeof(SrcState) * S));
+            JF_HIP(e, hipMalloc(&e->d_hist[i], sizeof(float) * S * kN));
+            JF_HIP(e, hipMemset(e->d_state[i], 0, sizeof(SrcState) * S));
+            JF_HIP(e, hipMemset(e->d_hist[i], 0, sizeof(float) * S * kN));
+        }
+        JF_HIP(e, hipMalloc(&e->d_desc, sizeof(ItemDesc) * S * K));
+        JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
+        JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
+        JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
+        JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5));
+        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B));
+        e->d_signal.assign(S, nullptr);
+        e->h_sigs.assign(S, SrcSignal{nullptr, 0, 0});
+        JF_HIP(e, hipMemset(e->d_sigs, 0, sizeof(SrcSignal) * S));
+        // SoundSource::SoundSource() defaults (SoundSource.cu:3-16)
+        e->pos.assign(S, HostPos{0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.5f});
+
+        // twiddles exp(+2 pi i j / 1024) from double
+        std::vector<float2> tw(1024);
+        for (int j = 0; j < 1024; j++) {
+            const double a = 2.0 * 3.14159265358979323846264338327950288 * j / 1024.0;
+            tw[j] = make_float2((float)cos(a), (float)sin(a));
+        }
+        JF_HIP(e, hipMemcpy(e->d_tw, tw.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
+
+        // HRTF spectra on the GPU (read_hrtf_signals + transform_hrtfs)
+        float *d_hrir = nullptr;
+        const size_t hb = sizeof(float) * kNumHrtf * 2 * (size_t)taps;
+        JF_HIP(e, hipMalloc(&d_hrir, hb));
+        hipError_t s1 = hipMemcpy(d_hrir, hrir, hb, hipMemcpyHostToDevice);
+        hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_tw, e->d_htab, e->stream) : s1;
+        hipError_t s3 = s2 == hipSuccess ? hipStreamSynchronize(e->stream) : s2;
+        (void)hipFree(d_hrir);
+        JF_HIP(e, s3);
+        return JF_OK;
+    };
+    rc = body();
+    if (rc != JF_OK) {
+        g_create_error = e->err;
+        destroy_engine(e);
+        return rc;
+    }
+    *out = e;
+    return JF_OK;
+}
+
+}  // namespace
+
+// =============================================================== C ABI ====
+extern "C" {
+
+int jf_engine_create(const jf_config *cfg, const float *hrir, int taps, jf_engine **out) {
+    return create_engine(cfg, hrir, taps, out);
+}
+
+int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_engine **out) {
+    if (!cfg || !hrir_dir || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
+    std::vector<float> hrir;
+    int taps = 0;
+    std::string err;
+    int rc = load_hrir_dir(hrir_dir, &hrir, &taps, &err);
+    if (rc) return fail(nullptr, rc, err);
+    return create_engine(cfg, hrir.data(), taps, out);
+}
+
+void jf_engine_destroy(jf_engine *e) { destroy_engine(e); }
+
+const char *jf_last_error(const jf_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int jf_frames_per_buffer(const jf_engine *e) { return e ? e->B : JF_ERR_ARG; }
+int jf_pad_len(const jf_engine *e) { return e ? kN : JF_ERR_ARG; }
+int jf_num_sources(const jf_engine *e) { return e ? e->S : JF_ERR_ARG; }
+
+int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
+    if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    float *d_new = nullptr;
+    if (n) {
+        JF_HIP(e, hipMalloc(&d_new, sizeof(float) * n));
+        hipError_t st = hipMemcpy(d_new, mono, sizeof(float) * n, hipMemcpyHostToDevice);
+        if (st != hipSuccess) {
+            (void)hipFree(d_new);
+            JF_HIP(e, st);
+        }
+    }
+    if (e->d_signal[src]) (void)hipFree(e->d_signal[src]);
+    e->d_signal[src] = d_new;
+    e->h_sigs[src] = SrcSignal{d_new, (int)n, 0};
+    JF_HIP(e, hipMemcpy(e->d_sigs + src, &e->h_sigs[src], sizeof(SrcSignal), hipMemcpyHostToDevice));
+    const int zero = 0;  // count = 0 (cudaPart.cu:198-199 run with a fresh source)
+    JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return JF_OK;
+}
+
+int jf_source_set_cartesian(jf_engine *e, int src, float x, float y, float z) {
+    if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
+    float rec[5], r;
+    int rc = host_from_cartesian(x, y, z, rec, &r);
+    if (rc) return fail(e, rc, "zero or non-finite coordinates");
+    if (!(rec[0] > -50.0f && rec[0] <= 90.0f)) return fail(e, JF_ERR_RANGE, "elevation outside (-50, 90]");
+    std::lock_guard<std::mutex> lk(e->pos_mu);
+    e->pos[src] = HostPos{rec[0], rec[1], r, x, y, z};
+    return JF_OK;
+}
+
+int jf_source_set_spherical(jf_engine *e, int src, float ele, float azi, float r) {
+    if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
+    float rec[5];
+    host_from_spherical(ele, azi, r, rec);
+    if (!(rec[0] > -50.0f && rec[0] <= 90.0f)) return fail(e, JF_ERR_RANGE, "elevation outside (-50, 90]");
+    if (!(fabsf(rec[1]) < 1.0e6f) || !(fabsf(r) < 3.0e38f)) return fail(e, JF_ERR_RANGE, "non-finite azimuth or radius");
+    std::lock_guard<std::mutex> lk(e->pos_mu);
+    e->pos[src] = HostPos{rec[0], rec[1], r, rec[2], rec[3], rec[4]};
+    return JF_OK;
+}
+
+int jf_source_get_position(const jf_engine *e, int src, float out[6]) {
+    if (!valid_src(e, src) || !out) return JF_ERR_ARG;
+    jf_engine *m = const_cast<jf_engine *>(e);
+    std::lock_guard<std::mutex> lk(m->pos_mu);
+    const HostPos &q = e->pos[src];
+    out[0] = q.ele;
+    out[1] = q.azi;
+    out[2] = q.r;
+    out[3] = q.x;
+    out[4] = q.y;
+    out[5] = q.z;
+    return JF_OK;
+}
+
+int jf_source_reset(jf_engine *e, int src) {
+    if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    JF_HIP(e, hipMemset(e->d_hist[e->cur] + (size_t)src * kN, 0, sizeof(float) * kN));
+    JF_HIP(e, hipMemset(e->d_state[e->cur] + src, 0, sizeof(SrcState)));
+    return JF_OK;
+}
+
+int jf_position_from_spherical(float ele, float azi, float r, float out[JF_POS_FLOATS]) {
+    if (!out) return JF_ERR_ARG;
+    host_from_spherical(ele, azi, r, out);
+    return JF_OK;
+}
+
+int jf_position_from_cartesian(float x, float y, float z, float out[JF_POS_FLOATS]) {
+    if (!out) return JF_ERR_ARG;
+    return host_from_cartesian(x, y, z, out, nullptr);
+}
+
+int jf_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
+    if (!idx || !omegas) return JF_ERR_ARG;
+    return host_interpolation(ele, azi, idx, omegas);
+}
+
+int jf_pick_hrtf(float ele, float azi) { return host_pick_hrtf(ele, azi); }
+
+// ---- per-block -----------------------------------------------------------
+int jf_submit_block(jf_engine *e) {
+    if (!e) return JF_ERR_ARG;
+    if (e->in_flight) return fail(e, JF_ERR_STATE, "a block is already in flight");
+    if (e->paused) {  // Audio.cu:101: nothing is consumed, output is silence
+        JF_HIP(e, hipMemsetAsync(e->d_mix, 0, sizeof(float) * 2 * e->B, e->stream));
+    } else {
+        snapshot_positions(e, e->h_pos_pinned);
+        JF_HIP(e, hipMemcpyAsync(e->d_pos_rt, e->h_pos_pinned, sizeof(float) * 5 * e->S, hipMemcpyHostToDevice,
+                                 e->stream));
+        int rc = run_blocks(e, e->d_pos_rt, 1, e->d_mix);
+        if (rc) return rc;
+    }
+    JF_HIP(e, hipMemcpyAsync(e->h_out_pinned, e->d_mix, sizeof(float) * 2 * e->B, hipMemcpyDeviceToHost, e->stream));
+    e->in_flight = true;
+    return JF_OK;
+}
+
+int jf_collect_block(jf_engine *e, float *out) {
+    if (!e || !out) return JF_ERR_ARG;
+    if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_out_pinned, sizeof(float) * 2 * e->B);
+    e->in_flight = false;
+    return JF_OK;
+}
+
+int jf_process_block(jf_engine *e, float *out) {
+    int rc = jf_submit_block(e);
+    if (rc) return rc;
+    return jf_collect_block(e, out);
+}
+
+int jf_callback(jf_engine *e, float *out) {
+    if (!e || !out) return JF_ERR_ARG;
+    int rc;
+    if (e->have_prev) {
+        rc = jf_collect_block(e, out);
+        if (rc) return rc;
+    } else {
+        memset(out, 0, sizeof(float) * 2 * e->B);  // intermediate[] before the first block
+    }
+    rc = jf_submit_block(e);
+    if (rc) return rc;
+    e->have_prev = true;
+    return JF_OK;
+}
+
+int jf_pa_callback(const void *, void *output, unsigned long frames, const void *, unsigned long, void *user) {
+    jf_engine *e = (jf_engine *)user;
+    if (e && output && frames == (unsigned long)e->B) jf_callback(e, (float *)output);
+    return 0;
+}
+
+int jf_set_pause(jf_engine *e, int paused) {
+    if (!e) return JF_ERR_ARG;
+    e->paused = paused != 0;
+    return JF_OK;
+}
+
+// ---- batch -----------------------------------------------------------------
+int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *positions) {
+    if (!e || total_blocks <= 0 || !positions) return fail(e, JF_ERR_ARG, "bad trajectory");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    const size_t bytes = sizeof(float) * 5 * (size_t)e->S * (size_t)total_blocks;
+    if (total_blocks > e->traj_blocks) {
+        (void)hipFree(e->d_traj);
+        e->d_traj = nullptr;
+        e->traj_blocks = 0;
+        JF_HIP(e, hipMalloc(&e->d_traj, bytes));
+    }
+    e->traj_blocks = total_blocks;
+    JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
+    return JF_OK;
+}
+
+int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) {
+    if (!e) return JF_ERR_ARG;
+    if (n_blocks <= 0 || n_blocks > e->maxK) return fail(e, JF_ERR_ARG, "n_blocks exceeds max_batch_blocks");
+    if (first_block < 0 || first_block + n_blocks > e->traj_blocks)
+        return fail(e, JF_ERR_ARG, "window outside the uploaded trajectory");
+    if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
+    return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix);
+}
+
+int jf_synchronize(jf_engine *e) {
+    if (!e) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    return JF_OK;
+}
+
+int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *out_mix) {
+    if (!e || !positions || !out_mix || n_blocks <= 0) return fail(e, JF_ERR_ARG, "bad batch arguments");
+    int rc = jf_batch_upload_positions(e, n_blocks, positions);
+    if (rc) return rc;
+    const size_t blk = (size_t)2 * e->B;
+    for (int b0 = 0; b0 < n_blocks; b0 += e->maxK) {
+        const int k = n_blocks - b0 < e->maxK ? n_blocks - b0 : e->maxK;
+        rc = jf_batch_run(e, b0, k, nullptr);
+        if (rc) return rc;
+        JF_HIP(e, hipMemcpyAsync(out_mix + (size_t)b0 * blk, e->d_mix, sizeof(float) * blk * k, hipMemcpyDeviceToHost,
+                                 e->stream));
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return JF_OK;
+}
+
+float *jf_batch_mix_device(jf_engine *e) { return e ? e->d_mix : nullptr; }
+float *jf_batch_partial_device(jf_engine *e) { return e ? e->d_partial : nullptr; }
+void *jf_engine_stream(jf_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int jf_profile_enable(jf_engine *e, int enable) {
+    if (!e) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    e->profiling = enable != 0;
+    e->ev_used = 0;
+    return JF_OK;
+}
+
+int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches) {
+    if (!e) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    double f = 0, p = 0, m = 0;
+    for (size_t i = 0; i < e->ev_used; i++) {
+        float ms = 0;
+        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_fused[i].a, e->ev_fused[i].b));
+        f += ms;
+        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_prep[i].a, e->ev_prep[i].b));
+        p += ms;
+        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_mix[i].a, e->ev_mix[i].b));
+        m += ms;
+    }
+    if (fused_ms) *fused_ms = f;
+    if (prep_ms) *prep_ms = p;
+    if (mix_ms) *mix_ms = m;
+    if (launches) *launches = (long)e->ev_used;
+    return JF_OK;
+}
+
+// ---- debugging taps -----------------------------------------------------------
+int jf_debug_read_table(jf_engine *e, float *out) {
+    if (!e || !out) return JF_ERR_ARG;
+    std::vector<float4> h((size_t)kNumHrtf * 512);
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    JF_HIP(e, hipMemcpy(h.data(), e->d_htab, sizeof(float4) * h.size(), hipMemcpyDeviceToHost));
+    for (int j = 0; j < kNumHrtf; j++) {
+        float *L = out + ((size_t)j * 2 + 0) * kNc * 2;
+        float *R = out + ((size_t)j * 2 + 1) * kNc * 2;
+        const float4 *row = h.data() + (size_t)j * 512;
+        L[0] = row[0].x;
+        L[1] = 0.0f;
+        L[1024] = row[0].y;
+        L[1025] = 0.0f;
+        R[0] = row[0].z;
+        R[1] = 0.0f;
+        R[1024] = row[0].w;
+        R[1025] = 0.0f;
+        for (int k = 1; k < 512; k++) {
+            L[2 * k] = row[k].x;
+            L[2 * k + 1] = row[k].y;
+            R[2 * k] = row[k].z;
+            R[2 * k + 1] = row[k].w;
+        }
+    }
+    return JF_OK;
+}
+
+int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *azi, int *rows, float *weights,
+                           int *nterms) {
+    if (!e || n <= 0 || !ele || !azi || !rows || !weights || !nterms) return JF_ERR_ARG;
+    float *d_e = nullptr, *d_a = nullptr, *d_w = nullptr;
+    int *d_r = nullptr, *d_n = nullptr;
+    auto body = [&]() -> int {
+        JF_HIP(e, hipMalloc(&d_e, sizeof(float) * n));
+        JF_HIP(e, hipMalloc(&d_a, sizeof(float) * n));
+        JF_HIP(e, hipMalloc(&d_w, sizeof(float) * 4 * n));
+        JF_HIP(e, hipMalloc(&d_r, sizeof(int) * 4 * n));
+        JF_HIP(e, hipMalloc(&d_n, sizeof(int) * n));
+        JF_HIP(e, hipMemcpy(d_e, ele, sizeof(float) * n, hipMemcpyHostToDevice));
+        JF_HIP(e, hipMemcpy(d_a, azi, sizeof(float) * n, hipMemcpyHostToDevice));
+        JF_HIP(e, launch_interp_debug(ring_table(), d_e, d_a, d_r, d_w, d_n, n, e->stream));
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+        JF_HIP(e, hipMemcpy(rows, d_r, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
+        JF_HIP(e, hipMemcpy(weights, d_w, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+        JF_HIP(e, hipMemcpy(nterms, d_n, sizeof(int) * n, hipMemcpyDeviceToHost));
+        return JF_OK;
+    };
+    int rc = body();
+    (void)hipFree(d_e);
+    (void)hipFree(d_a);
+    (void)hipFree(d_w);
+    (void)hipFree(d_r);
+    (void)hipFree(d_n);
+    return rc;
+}
+
+int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spectra) {
+    if (!e || n <= 0 || !windows || !spectra) return JF_ERR_ARG;
+    float *d_w = nullptr;
+    float2 *d_s = nullptr;
+    auto body = [&]() -> int {
+        JF_HIP(e, hipMalloc(&d_w, sizeof(float) * (size_t)n * kN));
+        JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * kNc));
+        JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
+        JF_HIP(e, launch_rfft_debug(d_w, n, e->d_tw, d_s, e->stream));
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+        JF_HIP(e, hipMemcpy(spectra, d_s, sizeof(float2) * (size_t)n * kNc, hipMemcpyDeviceToHost));
+        return JF_OK;
+    };
+    int rc = body();
+    (void)hipFree(d_w);
+    (void)hipFree(d_s);
+    return rc;
+}
+
+// ---- WAV -----------------------------------------------------------------------
+int jf_wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate) {
+    if (!path || !out || !n_frames) return JF_ERR_ARG;
+    std::string err;
+    int rc = wav_read_mono(path, out, n_frames, sample_rate, &err);
+    if (rc) g_create_error = err;
+    return rc;
+}
+
+int jf_wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate) {
+    if (!path || (!interleaved && n_frames)) return JF_ERR_ARG;
+    std::string err;
+    int rc = wav_write_stereo24(path, interleaved, n_frames, sample_rate, &err);
+    if (rc) g_create_error = err;
+    return rc;
+}
+
+void jf_free(void *p) { free(p); }
+
+}  // extern "C"

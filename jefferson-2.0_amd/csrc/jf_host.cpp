@@ -1,0 +1,357 @@
+// jf_host.cpp -- geometry / index rules / file I/O of the engine (host, no GPU).
+// Float32 arithmetic is kept operation-for-operation as the reference performs
+// it, because azimuth/elevation rounding and the interpolation weights are part
+// of the audible result.  Compile with -ffp-contract=off.
+#include "jf_host.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/jefferson.h"
+
+namespace jf {
+
+namespace {
+constexpr double kPi = 3.14159265358979323846264338327950288;  // Universal.cuh:14-16
+const int kElevPos[kNumElev] = {-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90};
+const float kAziInc[kNumElev] = {6.43f, 6.00f, 5.00f, 5.00f, 5.00f, 5.00f, 5.00f,
+                                 6.00f, 6.43f, 8.00f, 10.00f, 15.00f, 30.00f, 361.0f};
+
+struct Rings {
+    RingTable rt;
+    int pos_ele[kNumHrtf];
+    int pos_azi[kNumHrtf];
+    Rings() {
+        int j = 0;
+        rt.offset[0] = 0;
+        for (int e = 0; e < kNumElev; e++) {
+            rt.inc[e] = kAziInc[e];
+            // the reference steps a float azimuth; ring sizes follow from that
+            for (float azi = 0; azi < 360; azi += kAziInc[e]) {
+                if (j < kNumHrtf) {
+                    pos_ele[j] = kElevPos[e];
+                    pos_azi[j] = (int)round(azi);
+                }
+                j++;
+            }
+            rt.offset[e + 1] = j;
+        }
+    }
+};
+const Rings &rings() {
+    static const Rings r;
+    return r;
+}
+}  // namespace
+
+const RingTable &ring_table() { return rings().rt; }
+
+void table_position(int j, int *ele, int *azi) {
+    *ele = rings().pos_ele[j];
+    *azi = rings().pos_azi[j];
+}
+
+int host_pick_hrtf(float obj_ele, float obj_azi) {
+    const RingTable &rt = ring_table();
+    obj_ele = roundf(obj_ele / 10) * 10;
+    int ring = 0;
+    float best = 1e37f;
+    for (int e = 0; e < kNumElev; e++) {
+        float d = obj_ele - kElevPos[e];
+        if (d < 0) d = -d;
+        if (d < best) {
+            best = d;
+            ring = e;
+        }
+    }
+    obj_azi = roundf(obj_azi);
+    best = 1e37f;
+    int pick = 0;
+    const int n = rt.offset[ring + 1] - rt.offset[ring];
+    for (int i = 0; i < n; i++) {
+        float d = obj_azi - i * rt.inc[ring];
+        if (d < 0) d = -d;
+        if (d < best) {
+            best = d;
+            pick = rt.offset[ring] + i;
+        }
+    }
+    return pick;
+}
+
+int host_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
+    if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
+    const int phi0 = (int)ele / 10 * 10;
+    const int phi1 = (int)(ele + 9) / 10 * 10;
+    int r0 = -1, r1 = -1;
+    for (int e = 0; e < kNumElev; e++) {
+        if (kElevPos[e] == phi0) r0 = e;
+        if (kElevPos[e] == phi1) r1 = e;
+    }
+    if (r0 < 0 || r1 < 0) return JF_ERR_RANGE;
+    const float dt1 = kAziInc[r0], dt2 = kAziInc[r1];
+    const int th0 = (int)((int)(azi / dt1) * dt1);
+    const int th1 = (int)((int)((azi + dt1 - 1) / dt1) * dt1);
+    const int th2 = (int)((int)(azi / dt2) * dt2);
+    const int th3 = (int)((int)((azi + dt2 - 1) / dt2) * dt2);
+    omegas[0] = (azi - th0) / dt1;
+    omegas[1] = (th1 - azi) / dt1;
+    omegas[2] = (azi - th2) / dt2;
+    omegas[3] = (th3 - azi) / dt2;
+    omegas[4] = (ele - phi0) / 10.0f;
+    omegas[5] = (phi1 - ele) / 10.0f;
+    idx[0] = host_pick_hrtf((float)phi0, (float)th0);
+    idx[1] = host_pick_hrtf((float)phi0, (float)th1);
+    idx[2] = host_pick_hrtf((float)phi1, (float)th2);
+    idx[3] = host_pick_hrtf((float)phi1, (float)th3);
+    return JF_OK;
+}
+
+void host_from_spherical(float ele, float azi, float r, float out[5]) {
+    ele = roundf(ele);
+    azi = roundf(azi);
+    out[0] = ele;
+    out[1] = azi;
+    out[2] = (float)(r * sin(azi * kPi / 180.0f));
+    out[3] = (float)(r * sin(ele * kPi / 180.0f));
+    out[4] = (float)(r * -cos(azi * kPi / 180.0f));
+}
+
+int host_from_cartesian(float x, float y, float z, float out[5], float *r_out) {
+    const float r = sqrtf(x * x + z * z + y * y);
+    const float horiz = sqrtf(x * x + z * z);
+    if (!(r > 0.0f) || !(r < 3.0e38f)) return JF_ERR_RANGE;
+    float ele = (float)(atan2f(y, horiz) * 180.0f / kPi);
+    float azi = (float)(atan2f(-x / r, -z / r) * 180.0f / kPi);
+    if (azi < 0.0f) azi += 360;
+    out[0] = roundf(ele);
+    out[1] = roundf(azi);
+    out[2] = x;
+    out[3] = y;
+    out[4] = z;
+    if (r_out) *r_out = r;
+    return JF_OK;
+}
+
+// ------------------------------------------------------------------ WAV ---
+namespace {
+struct WavInfo {
+    int format = 0;  // 1 PCM, 3 float
+    int channels = 0;
+    int rate = 0;
+    int bits = 0;
+    long data_off = 0;
+    size_t data_bytes = 0;
+};
+
+uint32_t rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+int wav_open(const char *path, FILE **fp, WavInfo *wi, std::string *err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        *err = std::string("cannot open ") + path;
+        return JF_ERR_IO;
+    }
+    unsigned char hd[12];
+    if (fread(hd, 1, 12, f) != 12 || memcmp(hd, "RIFF", 4) || memcmp(hd + 8, "WAVE", 4)) {
+        fclose(f);
+        *err = std::string("not a RIFF/WAVE file: ") + path;
+        return JF_ERR_IO;
+    }
+    bool have_fmt = false;
+    for (;;) {
+        unsigned char ch[8];
+        if (fread(ch, 1, 8, f) != 8) break;
+        const uint32_t sz = rd32(ch + 4);
+        if (!memcmp(ch, "fmt ", 4)) {
+            unsigned char fm[40] = {0};
+            const size_t n = sz < sizeof(fm) ? sz : sizeof(fm);
+            if (fread(fm, 1, n, f) != n) break;
+            wi->format = rd16(fm);
+            wi->channels = rd16(fm + 2);
+            wi->rate = (int)rd32(fm + 4);
+            wi->bits = rd16(fm + 14);
+            if (wi->format == 0xFFFE && n >= 26) wi->format = rd16(fm + 24);  // WAVE_FORMAT_EXTENSIBLE
+            if (sz > n) fseek(f, (long)(sz - n), SEEK_CUR);
+            if (sz & 1) fseek(f, 1, SEEK_CUR);
+            have_fmt = true;
+        } else if (!memcmp(ch, "data", 4)) {
+            wi->data_off = ftell(f);
+            wi->data_bytes = sz;
+            if (!have_fmt) break;
+            *fp = f;
+            return JF_OK;
+        } else {
+            fseek(f, (long)(sz + (sz & 1)), SEEK_CUR);
+        }
+    }
+    fclose(f);
+    *err = std::string("malformed WAV: ") + path;
+    return JF_ERR_IO;
+}
+
+// libsndfile's sf_read_float scaling: integer PCM / 2^(bits-1); 8-bit is unsigned.
+int wav_read_all(const char *path, std::vector<float> *samples, WavInfo *wi, std::string *err) {
+    FILE *f = nullptr;
+    int rc = wav_open(path, &f, wi, err);
+    if (rc) return rc;
+    const int bps = wi->bits / 8;
+    if (wi->channels < 1 || bps < 1 || bps > 4 || !((wi->format == 1) || (wi->format == 3 && bps == 4))) {
+        fclose(f);
+        *err = std::string("unsupported WAV encoding: ") + path;
+        return JF_ERR_IO;
+    }
+    // a truncated file (header claims more than is there) yields what is present
+    std::vector<unsigned char> raw(wi->data_bytes);
+    const size_t got = fread(raw.data(), 1, raw.size(), f);
+    fclose(f);
+    const size_t n = got / (size_t)bps;
+    samples->resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const unsigned char *p = raw.data() + i * bps;
+        float v;
+        if (wi->format == 3) {
+            memcpy(&v, p, 4);
+        } else if (bps == 1) {
+            v = ((int)p[0] - 128) / 128.0f;
+        } else if (bps == 2) {
+            v = (int16_t)rd16(p) / 32768.0f;
+        } else if (bps == 3) {
+            int32_t x = p[0] | (p[1] << 8) | (p[2] << 16);
+            if (x & 0x800000) x -= 0x1000000;
+            v = x / 8388608.0f;
+        } else {
+            v = (int32_t)rd32(p) / 2147483648.0f;
+        }
+        (*samples)[i] = v;
+    }
+    return JF_OK;
+}
+}  // namespace
+
+int wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate, std::string *err) {
+    std::vector<float> s;
+    WavInfo wi;
+    int rc = wav_read_all(path, &s, &wi, err);
+    if (rc) return rc;
+    if (wi.channels > 2) {  // cudaPart.cu:57-60
+        *err = std::string(path) + ": only mono or stereo accepted";
+        return JF_ERR_IO;
+    }
+    const size_t frames = s.size() / (size_t)wi.channels;
+    float *buf = (float *)malloc(sizeof(float) * (frames ? frames : 1));
+    if (!buf) return JF_ERR_NOMEM;
+    if (wi.channels == 1) {
+        memcpy(buf, s.data(), sizeof(float) * frames);
+    } else {
+        // cudaPart.cu:50-52: L/2 + R/2 (double arithmetic, stored to float)
+        for (size_t i = 0; i < frames; i++) buf[i] = (float)(s[2 * i] / 2.0 + s[2 * i + 1] / 2.0);
+    }
+    *out = buf;
+    *n_frames = frames;
+    if (sample_rate) *sample_rate = wi.rate;
+    return JF_OK;
+}
+
+int wav_write_stereo24(const char *path, const float *il, size_t n_frames, int rate, std::string *err) {
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        *err = std::string("cannot create ") + path;
+        return JF_ERR_IO;
+    }
+    const uint32_t data = (uint32_t)(n_frames * 2 * 3);
+    unsigned char h[44];
+    auto w32 = [](unsigned char *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; };
+    auto w16 = [](unsigned char *p, uint16_t v) { p[0] = (unsigned char)v; p[1] = (unsigned char)(v >> 8); };
+    memcpy(h, "RIFF", 4);
+    w32(h + 4, 36 + data);
+    memcpy(h + 8, "WAVEfmt ", 8);
+    w32(h + 16, 16);
+    w16(h + 20, 1);
+    w16(h + 22, 2);
+    w32(h + 24, (uint32_t)rate);
+    w32(h + 28, (uint32_t)rate * 6);
+    w16(h + 32, 6);
+    w16(h + 34, 24);
+    memcpy(h + 36, "data", 4);
+    w32(h + 40, data);
+    fwrite(h, 1, 44, f);
+    std::vector<unsigned char> buf(n_frames * 6);
+    for (size_t i = 0; i < n_frames * 2; i++) {
+        // libsndfile float -> PCM_24: scale by 0x7FFFFF and round; clipped here
+        // (libsndfile wraps unless SFC_SET_CLIPPING is on)
+        float v = il[i] * 8388607.0f;
+        if (v > 8388607.0f) v = 8388607.0f;
+        if (v < -8388608.0f) v = -8388608.0f;
+        const int32_t x = (int32_t)lrintf(v);
+        buf[3 * i] = (unsigned char)x;
+        buf[3 * i + 1] = (unsigned char)(x >> 8);
+        buf[3 * i + 2] = (unsigned char)(x >> 16);
+    }
+    const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    if (!ok) {
+        *err = std::string("short write: ") + path;
+        return JF_ERR_IO;
+    }
+    return JF_OK;
+}
+
+// ------------------------------------------------------- KEMAR directory ---
+int load_hrir_dir(const char *dir, std::vector<float> *hrir, int *taps_out, std::string *err) {
+    char path[1024];
+    snprintf(path, sizeof(path), "%s/elev0/H0e000a.wav", dir);
+    FILE *probe = fopen(path, "rb");
+    const bool compact = probe != nullptr;
+    if (probe) fclose(probe);
+    int taps = 0;
+    for (int j = 0; j < kNumHrtf; j++) {
+        int ele, azi;
+        table_position(j, &ele, &azi);
+        for (int ear = 0; ear < 2; ear++) {
+            std::vector<float> s;
+            WavInfo wi;
+            int want_ch, take_ch;
+            if (compact) {
+                // right half-sphere measured; left half = mirror with ears exchanged
+                const int a = azi <= 180 ? azi : 360 - azi;
+                snprintf(path, sizeof(path), "%s/elev%d/H%de%03da.wav", dir, ele, ele, a);
+                want_ch = 2;
+                take_ch = azi <= 180 ? ear : 1 - ear;
+            } else {
+                snprintf(path, sizeof(path), "%s/elev%d/%c%de%03da.wav", dir, ele, ear ? 'R' : 'L', ele, azi);
+                want_ch = 1;  // hrtf_signals.cu:68-71
+                take_ch = 0;
+            }
+            int rc = wav_read_all(path, &s, &wi, err);
+            if (rc) return rc;
+            if (wi.channels != want_ch) {
+                *err = std::string("incorrect number of channels in HRTF ") + path;
+                return JF_ERR_IO;
+            }
+            if (wi.rate != 44100) {  // hrtf_signals.cu:72-75
+                *err = std::string("incorrect sampling rate in ") + path;
+                return JF_ERR_IO;
+            }
+            const int frames = (int)(s.size() / (size_t)want_ch);
+            if (taps == 0) {
+                taps = frames;
+                hrir->assign((size_t)kNumHrtf * 2 * taps, 0.0f);
+            }
+            if (frames != taps || taps <= 0) {
+                *err = std::string("HRIR length differs in ") + path;
+                return JF_ERR_IO;
+            }
+            float *dst = hrir->data() + ((size_t)j * 2 + ear) * taps;
+            for (int n = 0; n < taps; n++) dst[n] = s[(size_t)n * want_ch + take_ch];
+        }
+    }
+    *taps_out = taps;
+    return JF_OK;
+}
+
+}  // namespace jf

@@ -1,0 +1,704 @@
+// jf_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the HRTF binaural
+// convolution hot path.  No rocFFT/hipFFT, no Thrust, no MFMA (the path is FFT +
+// pointwise).
+//
+// One 64-lane wavefront owns one work item = (block b, source s) and carries it
+// through the whole per-block pipeline of the reference
+// (GPUSoundSource.cu:320-385 interpolateConvolve + :463-513 window handling):
+//
+//   window gather (signal ring / previous window)            a5
+//   real FFT 1024 = complex FFT 512 (radix 8x8x8 Stockham, two LDS exchanges)
+//     + split post-pass with a cross-lane mirror (ds_bpermute)        a6
+//   distance factor D[k] (double phase reduction, float sincos)        a7
+//   sum_i w_i H_i[k] from the interleaved table, * X[k] D[k], both ears  a8
+//   inverse: Z = Y_L + j Y_R, built in registers (mirror by ds_bpermute),
+//     1024-point inverse as 4 decimated 256-point transforms
+//     (radix 16x16, ONE LDS exchange) + a pruned last radix-4 done as a
+//     DPP quad reduction -- only the last B samples are ever formed     a9
+//   crossfade old/new filter sets in registers                          a10
+//   store the B stereo frames of this source                            a11
+//
+// A second tiny kernel sums the per-source blocks in source order (a12), a
+// third computes indices/weights (a2, a3) for every item.
+#include <hip/hip_runtime.h>
+
+#include "jf_device.h"
+
+namespace jf {
+
+// --------------------------------------------------------------- helpers --
+#define JF_DEV __device__ __forceinline__
+
+// LDS traffic below is private to one wavefront; LDS ops of a wave execute in
+// issue order, so all that is needed is to stop the compiler from moving a
+// lane's reads above other lanes' writes.
+#define JF_WAVE_LDS_SYNC()                                      \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+JF_DEV float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+JF_DEV float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+JF_DEV float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+JF_DEV float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+JF_DEV float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// twiddle from the e^{+i} table: forward transforms use the conjugate
+template <int DIR>
+JF_DEV float2 ctw(float2 v, float2 w) {
+    return DIR > 0 ? cmul(v, w) : cmulc(v, w);
+}
+
+// v * (c + i*DIR*s)
+template <int DIR>
+JF_DEV float2 cmulk(float2 v, float c, float s) {
+    const float d = DIR > 0 ? s : -s;
+    return make_float2(v.x * c - v.y * d, v.x * d + v.y * c);
+}
+
+// v * (DIR * i)
+template <int DIR>
+JF_DEV float2 cmuli(float2 v) {
+    return DIR > 0 ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x);
+}
+
+template <int DIR>
+JF_DEV void fft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    const float2 t2 = cadd(a1, a3), t3 = cmuli<DIR>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// in-register 8-point DFT, natural order in and out
+template <int DIR>
+JF_DEV void fft8(float2 (&v)[8]) {
+    constexpr float h = 0.70710678118654752440f;
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4<DIR>(e0, e1, e2, e3);
+    fft4<DIR>(o0, o1, o2, o3);
+    o1 = cmulk<DIR>(o1, h, h);
+    o2 = cmuli<DIR>(o2);
+    o3 = cmulk<DIR>(o3, -h, h);
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
+JF_DEV void cswap(float2 &a, float2 &b) {
+    const float2 t = a;
+    a = b;
+    b = t;
+}
+
+// in-register 16-point DFT, natural order in and out
+template <int DIR>
+JF_DEV void fft16(float2 (&v)[16]) {
+    constexpr float h = 0.70710678118654752440f;
+    constexpr float c1 = 0.92387953251128675613f;  // cos(pi/8)
+    constexpr float s1 = 0.38268343236508977173f;  // sin(pi/8)
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) fft4<DIR>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    // v[n1 + 4*k2] *= W16^(n1*k2)
+    v[5] = cmulk<DIR>(v[5], c1, s1);     // 1
+    v[9] = cmulk<DIR>(v[9], h, h);       // 2
+    v[13] = cmulk<DIR>(v[13], s1, c1);   // 3
+    v[6] = cmulk<DIR>(v[6], h, h);       // 2
+    v[10] = cmuli<DIR>(v[10]);           // 4
+    v[14] = cmulk<DIR>(v[14], -h, h);    // 6
+    v[7] = cmulk<DIR>(v[7], s1, c1);     // 3
+    v[11] = cmulk<DIR>(v[11], -h, h);    // 6
+    v[15] = cmulk<DIR>(v[15], -c1, -s1); // 9
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) fft4<DIR>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+    // v[k1 + 4*k2] holds X[k2 + 4*k1]: transpose the 4x4
+    cswap(v[1], v[4]);
+    cswap(v[2], v[8]);
+    cswap(v[3], v[12]);
+    cswap(v[6], v[9]);
+    cswap(v[7], v[13]);
+    cswap(v[11], v[14]);
+}
+
+JF_DEV float bperm(int src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+JF_DEV float2 bperm2(int src_lane, float2 v) {
+    return make_float2(bperm(src_lane, v.x), bperm(src_lane, v.y));
+}
+
+// sum over the 4 lanes of a quad, result in all 4 (DPP quad_perm)
+JF_DEV float quad_sum(float v) {
+    // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+// ------------------------------------------------------------ forward FFT --
+// Real FFT of 1024 samples through a 512-point complex FFT.
+// In : z[r] = (x[2(lane+64r)], x[2(lane+64r)+1]), r = 0..7
+// Out: X[q] = bin (lane + 64 q), q = 0..7, UNNORMALISED; on lane 0, X[0] is
+//      packed as (X[0].re, X[512].re) (both bins are real).
+// buf: >= 576 float2 of this wave's LDS; tw: exp(+2 pi i j/1024) in LDS.
+JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const float2 *tw, int lane) {
+    // pass A (sub-length 1): no twiddles; store 8 contiguous, row padded 8 -> 9
+    fft8<-1>(z);
+#pragma unroll
+    for (int r = 0; r < 8; r++) buf[9 * lane + r] = z[r];
+    JF_WAVE_LDS_SYNC();
+    // pass B (sub-length 8)
+    float2 u[8];
+    {
+        const int base = lane + (lane >> 3);
+#pragma unroll
+        for (int r = 0; r < 8; r++) u[r] = buf[base + 72 * r];
+        const int k = lane & 7;
+#pragma unroll
+        for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[(16 * r * k) & 1023]);
+        fft8<-1>(u);
+        JF_WAVE_LDS_SYNC();
+        const int wbase = 72 * (lane >> 3) + k;
+#pragma unroll
+        for (int r = 0; r < 8; r++) buf[wbase + 8 * r] = u[r];
+    }
+    JF_WAVE_LDS_SYNC();
+    // pass C (sub-length 64): Z[lane + 64 r']
+#pragma unroll
+    for (int r = 0; r < 8; r++) u[r] = buf[lane + 72 * r];
+#pragma unroll
+    for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[(2 * r * lane) & 1023]);
+    fft8<-1>(u);
+    JF_WAVE_LDS_SYNC();
+    // split: X[k] = E + (-i) W^k O, E = (Z[k] + conj Z[512-k])/2, O = (Z[k] - conj Z[512-k])/2
+    const int src = (64 - lane) & 63;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        float2 zm = bperm2(src, u[7 - q]);       // lanes >= 1: Z[512 - k]
+        const float2 own = u[(8 - q) & 7];       // lane 0: Z[(512 - 64 q) mod 512]
+        if (lane == 0) zm = own;
+        const float2 zk = u[q];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        // (-i) * conj(tw[k]) * o
+        const float2 wo = cmulc(o, tw[lane + 64 * q]);
+        X[q] = make_float2(e.x + wo.y, e.y - wo.x);
+    }
+    // lane 0: bins 0 and 512 are real: Re(Z0) +/- Im(Z0)
+    X[0] = lane == 0 ? make_float2(u[0].x + u[0].y, u[0].x - u[0].y) : X[0];
+}
+
+// ------------------------------------------------------------ inverse FFT --
+// Last quarter of the unnormalised inverse 1024-point complex transform.
+// In : Zin[r] = Z[lane + 64 r], r = 0..15.
+// Out: v[t] (t = 0..15) = y[768 + (lane>>2) + 16 t], identical in the 4 lanes
+//      of a quad.  buf: >= 1088 float2 of this wave's LDS.
+JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, int lane) {
+    const int a = lane & 3, i = lane >> 2;
+    // lane (i, a) holds S_a[i + 16 r] = Z[4 (i + 16 r) + a]: 16-point inverse over r
+    fft16<+1>(v);
+#pragma unroll
+    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tw[(4 * i * m) & 1023]);
+    // exchange inside each group a: write rows m (padded 64 -> 68), read columns
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[68 * m + lane] = v[m];
+    JF_WAVE_LDS_SYNC();
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = buf[68 * i + 4 * j + a];
+    JF_WAVE_LDS_SYNC();
+    fft16<+1>(v);  // s_a[i + 16 t]
+    // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const float2 w = tw[(a * (i + 16 * t) + 768 * a) & 1023];
+        const float2 p = cmul(v[t], w);
+        v[t] = make_float2(quad_sum(p.x), quad_sum(p.y));
+    }
+}
+
+// ------------------------------------------------------- distance factor --
+// D[k] = exp(-2 pi i * a * k / 513) * inv_frac (kernels.cu:116-125): the phase is
+// reduced in double (turns), the quadrant remainder evaluated in float.
+JF_DEV float2 distance_factor(double a, float inv_frac, int k) {
+    const double t = a * (double)k * (1.0 / 513.0);
+    const double u4 = (t - floor(t)) * 4.0;
+    const double n = rint(u4);
+    const float f = (float)(u4 - n);  // quarter turns in [-0.5, 0.5]
+    float s, c;
+    sincospif(0.5f * f, &s, &c);
+    const int qd = ((int)n) & 3;
+    const float cs = (qd == 0) ? c : (qd == 1) ? -s : (qd == 2) ? -c : s;
+    const float sn = (qd == 0) ? s : (qd == 1) ? c : (qd == 2) ? -s : -c;
+    return make_float2(cs * inv_frac, -sn * inv_frac);
+}
+
+// ------------------------------------------------------ filter + inverse --
+// he[q] = sum_t w[t] * H[rows[t]][lane + 64 q] (both ears in one float4).
+template <int NT>
+JF_DEV void weighted_rows(const float4 *__restrict__ htab, const int *rows, const float *w,
+                          float4 (&he)[8], int lane) {
+    const float4 *hp[NT];
+    float wt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        hp[t] = htab + (size_t)rows[t] * 512 + lane;
+        wt[t] = w[t];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        float4 h[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) h[t] = hp[t][64 * q];
+        float4 acc = make_float4(wt[0] * h[0].x, wt[0] * h[0].y, wt[0] * h[0].z, wt[0] * h[0].w);
+#pragma unroll
+        for (int t = 1; t < NT; t++) {
+            acc.x += wt[t] * h[t].x;
+            acc.y += wt[t] * h[t].y;
+            acc.z += wt[t] * h[t].z;
+            acc.w += wt[t] * h[t].w;
+        }
+        he[q] = acc;
+    }
+}
+
+// One filter set for this lane's bins, then the inverse transform.
+// xd[q] = X[k] D[k] for k = lane + 64 q; on lane 0, xd[0] = (X0*D0.re, X512*D512.re).
+JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows, const float *w,
+                       const float2 (&xd)[8], float2 (&v)[16], float2 *buf, const float2 *tw,
+                       int lane) {
+    float4 he[8];
+    if (nt == 4)
+        weighted_rows<4>(htab, rows, w, he, lane);
+    else if (nt == 2)
+        weighted_rows<2>(htab, rows, w, he, lane);
+    else
+        weighted_rows<1>(htab, rows, w, he, lane);
+    float2 mir[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float2 yl = cmul(xd[q], make_float2(he[q].x, he[q].y));
+        const float2 yr = cmul(xd[q], make_float2(he[q].z, he[q].w));
+        v[q] = make_float2(yl.x - yr.y, yl.y + yr.x);    // Z[k]   = YL + j YR
+        mir[q] = make_float2(yl.x + yr.y, yr.x - yl.y);  // Z[N-k] = conj YL + j conj YR
+    }
+    {
+        // lane 0: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
+        const float2 z0 = make_float2(xd[0].x * he[0].x, xd[0].x * he[0].z);    // Z[0]
+        const float2 z512 = make_float2(xd[0].y * he[0].y, xd[0].y * he[0].w);  // Z[512]
+        v[0] = lane == 0 ? z0 : v[0];
+        mir[0] = lane == 0 ? z512 : mir[0];
+    }
+    // upper half: Z[lane + 64 r], r = 8..15, lives mirrored on lane 64 - lane
+    const int src = (64 - lane) & 63;
+#pragma unroll
+    for (int r = 8; r < 16; r++) {
+        float2 z = bperm2(src, mir[15 - r]);
+        const float2 own = mir[(16 - r) & 7];  // lane 0: r = 8 -> Z[512], else Z[N - 64 (16 - r)]
+        if (lane == 0) z = own;
+        v[r] = z;
+    }
+    ifft1024_lastq_wave(v, buf, tw, lane);
+}
+
+// ------------------------------------------------------------ fused kernel --
+constexpr int kWaveLds = 1088;  // float2 per wave (8704 B): inverse exchange; forward uses 576
+
+template <int NOUT>  // B / 64
+__global__ __launch_bounds__(64 * kWavesPerWg) void fused_block_kernel(const FusedParams P) {
+    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_buf[kWavesPerWg * kWaveLds];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < 1024; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x * kWavesPerWg + wave;
+    const int n_items = P.K * P.S;
+    if (item >= n_items) return;
+    float2 *buf = s_buf + wave * kWaveLds;
+    constexpr int B = 64 * NOUT;
+    const int b = item / P.S;
+    const int s = item - b * P.S;
+
+    // ---- descriptor (wave-uniform -> scalar loads)
+    const ItemDesc *dp = P.desc + item;
+    const int n_new = dp->n_new;
+    const int n_old = dp->n_old;
+    const double da = dp->a;
+    const float inv_frac = dp->inv_frac;
+
+    // ---- window gather (Audio.cu:121-139, GPUSoundSource.cu:472-513)
+    const SrcSignal sg = P.sigs[s];
+    const int count0 = P.st_in[s].count;
+    const float *hist = P.hist_in + (size_t)s * kN;
+    const float *sigp = sg.ptr;
+    // first NEW sample of this call has q = 0; window sample n has q = b*B + n - (N - B)
+    const int q0 = b * B - (kN - B);
+    int pos0 = 0;  // signal index of q = max(q0, 0)
+    if (sg.length > 0) pos0 = (int)(((long long)count0 + (q0 > 0 ? q0 : 0)) % sg.length);
+    float2 z[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        float xv[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int n = 2 * (lane + 64 * r) + c;
+            const int q = q0 + n;
+            float val;
+            if (q < 0) {
+                val = hist[kN + q];
+            } else if (sg.length > 0) {
+                int idx = pos0 + (q0 > 0 ? n : q);
+                if (sg.length >= kN) {
+                    if (idx >= sg.length) idx -= sg.length;
+                } else {
+                    idx %= sg.length;
+                }
+                val = sigp[idx];
+            } else {
+                val = 0.0f;
+            }
+            xv[c] = val;
+        }
+        z[r] = make_float2(xv[0], xv[1]);
+    }
+    if (b == P.K - 1) {
+        // last block of the call: leave the window and the counters for the next call
+        float *ho = P.hist_out + (size_t)s * kN;
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<float2 *>(ho + 2 * (lane + 64 * r)) = z[r];
+        if (lane == 0) {
+            SrcState st;
+            st.count = sg.length > 0 ? (int)(((long long)count0 + (long long)P.K * B) % sg.length) : 0;
+            const float *pp = P.pos + (size_t)item * 5;
+            st.old_ele = pp[0];
+            st.old_azi = pp[1];
+            st.pad = 0;
+            P.st_out[s] = st;
+        }
+    }
+
+    float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)item * B;
+    const int a = lane & 3, i = lane >> 2;
+    if (n_new <= 0) {  // not interpolable: silence (the reference has no defined output here)
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j) - 0] = make_float2(0.f, 0.f);
+        return;
+    }
+
+    // ---- forward FFT, 1/N scale (GPUSoundSource.cu:344-346), times D[k]
+    float2 xd[8];
+    {
+        float2 X[8];
+        rfft1024_wave(z, X, buf, s_tw, lane);
+        constexpr float scale = 1.0f / 1024.0f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float2 d = distance_factor(da, inv_frac, lane + 64 * q);
+            xd[q] = cmul(make_float2(X[q].x * scale, X[q].y * scale), d);
+        }
+        {
+            const float2 d512 = distance_factor(da, inv_frac, 512);
+            const float2 x0 = make_float2(X[0].x * scale * inv_frac, X[0].y * scale * d512.x);
+            xd[0] = lane == 0 ? x0 : xd[0];
+        }
+    }
+
+    // ---- filter set(s) + inverse + crossfade (GPUSoundSource.cu:351-381)
+    float2 res[NOUT];
+    constexpr int T0 = 16 - 4 * NOUT;  // first t with 16 t + i >= 256 - B
+#pragma unroll 1
+    for (int set = (n_old > 0 ? 0 : 1); set < 2; set++) {
+        const int *rows = set ? dp->rows_new : dp->rows_old;
+        const float *w = set ? dp->w_new : dp->w_old;
+        float2 v[16];
+        filter_set(set ? n_new : n_old, P.htab, rows, w, xd, v, buf, s_tw, lane);
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) {
+            const float2 c0 = v[T0 + j], c1 = v[T0 + NOUT + j];
+            const float2 c2 = v[T0 + 2 * NOUT + j], c3 = v[T0 + 3 * NOUT + j];
+            float2 r1 = (a == 0) ? c0 : (a == 1) ? c1 : (a == 2) ? c2 : c3;
+            if (set == 0) {
+                res[j] = r1;
+            } else {
+                const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
+                if (n_old > 0) {
+                    // kernels.cu:132-137
+                    const float fn = (float)n_out / ((float)B - 1.0f);
+                    r1 = make_float2(res[j].x * (1.0f - fn) + r1.x * fn,
+                                     res[j].y * (1.0f - fn) + r1.y * fn);
+                }
+                out[n_out] = r1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- mixing --
+// Audio.cu:109-110: out[i] += source->intermediate[i], sources in index order.
+__global__ void mix_kernel(const float *__restrict__ partial, float *__restrict__ mix, int S, int K,
+                           int blk /* 2B */) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= K * blk) return;
+    const int b = g / blk, n = g - b * blk;
+    const float *p = partial + (size_t)b * S * blk + n;
+    float acc = 0.0f;
+    for (int s = 0; s < S; s++) acc += p[(size_t)s * blk];
+    mix[g] = acc;
+}
+
+// ----------------------------------------------- indices and weights (a2,a3)
+// SoundSource.cu:65-105 and hrtf_signals.cu:20-51, float32 exactly as written
+// (no contraction), the nearest-azimuth search done locally instead of over the
+// whole ring.
+#pragma clang fp contract(off)
+__device__ static const int d_elev_pos[kNumElev] = {-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90};
+
+JF_DEV int dev_pick_azi(const RingTable &rt, int ring, float obj_azi) {
+    const float inc = rt.inc[ring];
+    const int n = rt.offset[ring + 1] - rt.offset[ring];
+    obj_azi = roundf(obj_azi);
+    int i0 = (int)floorf(obj_azi / inc) - 1;
+    if (i0 > n - 4) i0 = n - 4;
+    if (i0 < 0) i0 = 0;
+    float dmin = 1e37f;
+    int best = 0;
+    for (int i = i0; i < i0 + 4 && i < n; i++) {
+        float d = obj_azi - i * inc;
+        d = d > 0 ? d : -d;
+        if (d < dmin) {
+            dmin = d;
+            best = i;
+        }
+    }
+    return rt.offset[ring] + best;
+}
+
+// returns number of terms (1, 2, 4) or 0 when the elevation ring does not exist
+JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[4], float w[4]) {
+    if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return 0;
+    const int phi0 = (int)(ele) / 10 * 10;
+    const int phi1 = (int)(ele + 9) / 10 * 10;
+    const float omegaE = (ele - phi0) / 10.0f;
+    const float omegaF = (phi1 - ele) / 10.0f;
+    int r0 = -1, r1 = -1;
+    for (int e = 0; e < kNumElev; e++) {
+        if (phi0 == d_elev_pos[e]) r0 = e;
+        if (phi1 == d_elev_pos[e]) r1 = e;
+    }
+    if (r0 < 0 || r1 < 0) return 0;
+    const float dt1 = rt.inc[r0], dt2 = rt.inc[r1];
+    const int th0 = (int)((int)(azi / dt1) * dt1);
+    const int th1 = (int)((int)((azi + dt1 - 1) / dt1) * dt1);
+    const int th2 = (int)((int)(azi / dt2) * dt2);
+    const int th3 = (int)((int)((azi + dt2 - 1) / dt2) * dt2);
+    const float omegaA = (azi - th0) / dt1;
+    const float omegaB = (th1 - azi) / dt1;
+    const float omegaC = (azi - th2) / dt2;
+    const float omegaD = (th3 - azi) / dt2;
+    const int h0 = dev_pick_azi(rt, r0, (float)th0);
+    const int h1 = dev_pick_azi(rt, r0, (float)th1);
+    const int h2 = dev_pick_azi(rt, r1, (float)th2);
+    const int h3 = dev_pick_azi(rt, r1, (float)th3);
+    // GPUSoundSource.cu:301-316
+    if (h0 == h1 && h1 == h2 && h2 == h3) {
+        rows[0] = h0; w[0] = 1.0f;
+        rows[1] = rows[2] = rows[3] = h0;
+        w[1] = w[2] = w[3] = 0.0f;
+        return 1;
+    }
+    if (h0 == h2 && h1 == h3) {
+        rows[0] = h0; w[0] = omegaB;
+        rows[1] = h1; w[1] = omegaA;
+        rows[2] = rows[3] = h0;
+        w[2] = w[3] = 0.0f;
+        return 2;
+    }
+    if (h0 == h1 && h0 != h2) {
+        rows[0] = h0; w[0] = omegaF;
+        rows[1] = h2; w[1] = omegaE;
+        rows[2] = rows[3] = h0;
+        w[2] = w[3] = 0.0f;
+        return 2;
+    }
+    rows[0] = h0; w[0] = omegaF * omegaB;
+    rows[1] = h1; w[1] = omegaF * omegaA;
+    rows[2] = h2; w[2] = omegaE * omegaD;
+    rows[3] = h3; w[3] = omegaE * omegaC;
+    return 4;
+}
+
+__global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, const SrcState *__restrict__ st,
+                            ItemDesc *__restrict__ desc, int S, int K) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= S * K) return;
+    const int b = item / S, s = item - b * S;
+    const float *p = pos + (size_t)item * 5;
+    const float ele = p[0], azi = p[1];
+    float old_ele, old_azi;
+    if (b == 0) {
+        old_ele = st[s].old_ele;
+        old_azi = st[s].old_azi;
+    } else {
+        old_ele = p[-5 * S];
+        old_azi = p[-5 * S + 1];
+    }
+    ItemDesc d;
+    d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new);
+    d.n_old = 0;
+    // GPUSoundSource.cu:331-335
+    if (old_azi != azi || old_ele != ele) {
+        d.n_old = dev_interp_terms(rt, old_ele, old_azi, d.rows_old, d.w_old);
+        if (d.n_old == 0) d.n_new = 0;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            d.rows_old[t] = 0;
+            d.w_old[t] = 0.0f;
+        }
+    }
+    // GPUSoundSource.cu:81-90
+    const float x = p[2], y = p[3], z = p[4];
+    float r = sqrtf(x * x + y * y + z * z);
+    r /= 5;
+    const float fsvs = (float)(44100.0 / 343.0);
+    const float frac = 1 + fsvs * (float)((double)r * (double)r);
+    d.a = (double)fsvs * (double)r;
+    d.inv_frac = 1.0f / frac;
+    if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
+    d.pad = 0;
+    desc[item] = d;
+}
+
+__global__ void interp_debug_kernel(const RingTable rt, const float *ele, const float *azi, int *rows,
+                                    float *w, int *nt, int n) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    int r4[4] = {0, 0, 0, 0};
+    float w4[4] = {0, 0, 0, 0};
+    nt[g] = dev_interp_terms(rt, ele[g], azi[g], r4, w4);
+    for (int t = 0; t < 4; t++) {
+        rows[4 * g + t] = r4[t];
+        w[4 * g + t] = w4[t];
+    }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------ table build and FFT tap --
+// hrtf_signals.cu:107-153: unnormalised r2c of every zero-padded HRIR, written
+// in the interleaved device layout.  One wave per table row (both ears).
+__global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict__ hrir, int taps,
+                                                        const float2 *__restrict__ twg,
+                                                        float4 *__restrict__ htab) {
+    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_buf[576];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < 1024; j += 64) s_tw[j] = twg[j];
+    __syncthreads();
+    const int row = blockIdx.x;
+    float2 Xe[2][8];
+#pragma unroll
+    for (int ear = 0; ear < 2; ear++) {
+        const float *h = hrir + ((size_t)row * 2 + ear) * taps;
+        float2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n = 2 * (lane + 64 * r);
+            z[r] = make_float2(n < taps ? h[n] : 0.0f, n + 1 < taps ? h[n + 1] : 0.0f);
+        }
+        rfft1024_wave(z, Xe[ear], s_buf, s_tw, lane);
+        JF_WAVE_LDS_SYNC();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        htab[(size_t)row * 512 + lane + 64 * q] = make_float4(Xe[0][q].x, Xe[0][q].y, Xe[1][q].x, Xe[1][q].y);
+}
+
+// parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
+__global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict__ win,
+                                                       const float2 *__restrict__ twg,
+                                                       float2 *__restrict__ spec) {
+    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_buf[576];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < 1024; j += 64) s_tw[j] = twg[j];
+    __syncthreads();
+    const float *x = win + (size_t)blockIdx.x * kN;
+    float2 z[8], X[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) z[r] = *reinterpret_cast<const float2 *>(x + 2 * (lane + 64 * r));
+    rfft1024_wave(z, X, s_buf, s_tw, lane);
+    float2 *o = spec + (size_t)blockIdx.x * kNc;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (lane == 0 && q == 0) {
+            o[0] = make_float2(X[0].x, 0.0f);
+            o[512] = make_float2(X[0].y, 0.0f);
+        } else {
+            o[lane + 64 * q] = X[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launchers --
+hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
+    return hipGetLastError();
+}
+
+hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(rfft_debug_kernel, dim3(n), dim3(64), 0, st, d_win, d_tw, d_spec);
+    return hipGetLastError();
+}
+
+hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
+                               float *d_w, int *d_nt, int n, hipStream_t st) {
+    hipLaunchKernelGGL(interp_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, d_ele, d_azi,
+                       d_rows, d_w, d_nt, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
+                       int S, int K, hipStream_t st) {
+    const int n = S * K;
+    hipLaunchKernelGGL(prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, d_pos, d_st, d_desc, S, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
+    const int n_items = P.K * P.S;
+    const dim3 grid((n_items + kWavesPerWg - 1) / kWavesPerWg), block(64 * kWavesPerWg);
+    switch (P.B / 64) {
+    case 1: hipLaunchKernelGGL(fused_block_kernel<1>, grid, block, 0, st, P); break;
+    case 2: hipLaunchKernelGGL(fused_block_kernel<2>, grid, block, 0, st, P); break;
+    case 3: hipLaunchKernelGGL(fused_block_kernel<3>, grid, block, 0, st, P); break;
+    case 4: hipLaunchKernelGGL(fused_block_kernel<4>, grid, block, 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st) {
+    const int n = K * 2 * B;
+    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_partial, d_mix, S, K, 2 * B);
+    return hipGetLastError();
+}
+
+}  // namespace jf

@@ -618,7 +618,7 @@ void jfo_process_batch(jfo_engine *e, int n_blocks, const float *pos, float *out
         for (int s = 0; s < S; s++) {
             jfo_source *q = &e->src[s];
             for (int b = 0; b < n_blocks; b++) {
-                const float *p = pos + ((size_t)s * n_blocks + b) * 5;
+                const float *p = pos + ((size_t)b * S + s) * 5;
                 q->ele = p[0];
                 q->azi = p[1];
                 q->coords[0] = p[2];

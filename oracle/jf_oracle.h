@@ -89,7 +89,7 @@ const float *jfo_source_last_block(const jfo_engine *e, int s);
 /*
  * Batch form used for the timed CPU baseline and large parity cases:
  * n_blocks blocks for every source, positions given per (source, block) as
- * latched values {ele, azi, x, y, z} (pos[(s*n_blocks + b)*5 ..]); sources are
+ * latched values {ele, azi, x, y, z} (pos[(b*n_sources + s)*5 ..]); sources are
  * processed in parallel with OpenMP (n_threads <= 0 -> all), each into its own
  * partial, then mixed in source order.  out_mix [n_blocks][2*B];
  * out_partial (may be NULL) [n_sources][n_blocks][2*B].

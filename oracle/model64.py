@@ -288,12 +288,12 @@ class Model:
         return out
 
     def process_batch(self, pos):
-        """pos float32 [S][K][5] = latched {ele, azi, x, y, z}; -> mix [K][2B], partial [S][K][2B]."""
-        S, K = pos.shape[0], pos.shape[1]
+        """pos float32 [K][S][5] = latched {ele, azi, x, y, z}; -> mix [K][2B], partial [S][K][2B]."""
+        K, S = pos.shape[0], pos.shape[1]
         partial = np.zeros((S, K, 2 * self.B))
         for s, q in enumerate(self.src):
             for b in range(K):
-                p = pos[s, b]
+                p = pos[b, s]
                 q.ele, q.azi, q.coords = f32(p[0]), f32(p[1]), (f32(p[2]), f32(p[3]), f32(p[4]))
                 partial[s, b] = self.source_block(q, q.ele, q.azi, q.coords)
         return partial.sum(axis=0), partial

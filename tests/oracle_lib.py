@@ -196,7 +196,7 @@ class Engine:
 
     def process_batch(self, pos, want_partial=False, n_threads=0):
         pos = np.ascontiguousarray(pos, np.float32)
-        S, K = pos.shape[0], pos.shape[1]
+        K, S = pos.shape[0], pos.shape[1]
         assert S == self.S and pos.shape[2] == 5
         mix = np.zeros((K, 2 * self.B), np.float32)
         part = np.zeros((S, K, 2 * self.B), np.float32) if want_partial else None
