@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused HRTF convolution hot path on MI355X.
+
+Workload (BASELINE.json configs[2], "1024 concurrent moving sources batched,
+256-sample blocks, 1xMI355X"): every GPU holds 1024 looped noise sources whose azimuth
+advances 1 degree per block (a crossfade of two 4-point interpolations nearly every
+block).  One STEP = one call of jf_batch_run over BLOCKS_PER_STEP consecutive audio
+blocks of all the rank's sources (prep -> fused FFT/multiply/IFFT/crossfade -> mix),
+plus, for N > 1, the RCCL sum of the stereo mixes to rank 0.  Signals, HRTF table and
+trajectories are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+prints ONE JSON line (rank 0).  metric = source-frames per second (sources x frames/s),
+whole job.  `roofline` prices the fused kernel against HBM peak with ALGORITHMIC bytes
+(SURVEY.md 8d); `cpu_baseline` is the float32 C oracle (oracle/, kind "port") timed on
+this node's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B = 256
+SOURCES_PER_GPU = 1024
+BLOCKS_PER_STEP = 64
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
+    """The oracle (CPU restatement of the reference's path) on the first n_blocks blocks of
+    the first n_sources sources of the same workload, all host threads, parallel over sources."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    ora = oracle_lib.Engine(B, 512, n_sources, hrir)
+    for s in range(n_sources):
+        ora.set_signal(s, wl.source_signal_and_start(s)[0])
+    pos = wl.trajectories(jf, np.arange(n_sources), n_blocks)
+    threads = oracle_lib.lib().jfo_num_threads()
+    ora.process_batch(pos[:2], n_threads=threads)  # warm the thread pool
+    for s in range(n_sources):
+        ora.reset(s)
+    t0 = time.perf_counter()
+    ora.process_batch(pos, n_threads=threads)
+    dt = time.perf_counter() - t0
+    ora.close()
+    return {"value": n_sources * n_blocks * B / dt, "unit": "source-frames/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{n_sources} sources x {n_blocks} blocks of the same moving-source workload, "
+                      f"{dt:.2f} s wall on {threads} threads (float32 C oracle, OpenMP over sources)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=256)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from jf_load import jf
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "jf_workload", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+
+    gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
+    hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
+
+    S = SOURCES_PER_GPU
+    K, W, KB = args.steps, args.warmup, BLOCKS_PER_STEP
+    total_blocks = (K + W) * KB
+    src_lo = rank * S  # weak scaling: every rank brings its own 1024 sources
+    src_ids = np.arange(src_lo, src_lo + S)
+
+    eng = jf.Engine(B, 512, S, hrir=hrir, device=local_rank, max_batch_blocks=KB)
+    for s, sid in enumerate(src_ids):
+        eng.set_signal(s, wl.source_signal_and_start(sid)[0])
+    pos = wl.trajectories(jf, src_ids, total_blocks, moving=not args.stationary)
+    eng.upload_positions(pos)
+
+    # the mix lands in a torch tensor so that RCCL can reduce it in place
+    mix = torch.zeros((KB, 2 * B), dtype=torch.float32, device="cuda")
+    ext = torch.cuda.ExternalStream(eng.stream_ptr())
+
+    def step(i):
+        eng.batch_run(i * KB, KB, mix.data_ptr())
+        if world > 1:
+            with torch.cuda.stream(ext):
+                dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    fence()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        frames = world * S * KB * K * B
+        value = frames / dt
+        # algorithmic bytes of the timed windows of THIS rank (every rank has the same mix of cases)
+        first_old = pos[W * KB - 1, :, :2].astype(np.int64) if W > 0 else None
+        abytes, rows, items = wl.algorithmic_bytes(jf, pos[W * KB:], B, first_old=first_old)
+        fused_s = prof["fused_ms"] * 1e-3
+        achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "source-frames/s (sources x frames/sec) at 256-sample blocks",
+            "value": value, "unit": "source-frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
+                                   "N=1024 overlap-save, KEMAR 710x2 table"
+                                   + (" (stationary variant)" if args.stationary else ""),
+                       "sources_per_gpu": S, "block": B, "blocks_per_step": KB,
+                       "parallelism": f"sources sharded x{world}, RCCL reduce of the stereo mix"
+                       if world > 1 else "1 GPU"},
+            "real_time_factor": (KB * K * B / 44100.0) / dt,
+            "us_per_source_block": dt / (S * KB * K) * 1e6,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "fused_block_kernel<4>",
+                         "algorithmic_bytes_per_launch": abytes / prof["launches"] if prof["launches"] else None,
+                         "avg_launch_ms": prof["fused_ms"] / prof["launches"] if prof["launches"] else None,
+                         "table_rows_per_source_block": rows / items,
+                         "prep_ms_per_launch": prof["prep_ms"] / max(prof["launches"], 1),
+                         "mix_ms_per_launch": prof["mix_ms"] / max(prof["launches"], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(jf, wl, hrir, S, args.cpu_sample_blocks)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,8 @@ int jf_source_reset(jf_engine *e, int src);
  * {ele, azi, x, y, z} used by the batch calls. */
 int jf_position_from_spherical(float ele, float azi, float r, float out[JF_POS_FLOATS]);
 int jf_position_from_cartesian(float x, float y, float z, float out[JF_POS_FLOATS]);
+/* n records at once: out[n][JF_POS_FLOATS] (trajectory construction for the batch calls). */
+int jf_positions_from_spherical(size_t n, const float *ele, const float *azi, const float *r, float *out);
 
 /* SoundSource::interpolationCalculations (SoundSource.cu:65-105) + pick_hrtf
  * (hrtf_signals.cu:20-51), host side, for inspection/tests. */

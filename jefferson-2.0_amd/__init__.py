@@ -51,6 +51,7 @@ _SIGS = {
     "jf_source_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_position_from_spherical": (C.c_int, [C.c_float, C.c_float, C.c_float, _f]),
     "jf_position_from_cartesian": (C.c_int, [C.c_float, C.c_float, C.c_float, _f]),
+    "jf_positions_from_spherical": (C.c_int, [C.c_size_t, _f, _f, _f, _f]),
     "jf_interpolation": (C.c_int, [C.c_float, C.c_float, _i, _f]),
     "jf_pick_hrtf": (C.c_int, [C.c_float, C.c_float]),
     "jf_process_block": (C.c_int, [C.c_void_p, _f]),
@@ -113,6 +114,18 @@ def position_from_spherical(ele, azi, r):
     if rc:
         raise JfError(rc, "position_from_spherical")
     return o
+
+
+def positions_from_spherical(ele, azi, r):
+    """Vectorised: arrays of equal shape -> float32 [..., 5] latched records."""
+    ele = np.ascontiguousarray(ele, np.float32)
+    azi = np.ascontiguousarray(np.broadcast_to(azi, ele.shape), np.float32)
+    r = np.ascontiguousarray(np.broadcast_to(r, ele.shape), np.float32)
+    out = np.zeros(ele.shape + (5,), np.float32)
+    rc = lib().jf_positions_from_spherical(ele.size, _fp(ele), _fp(azi), _fp(r), _fp(out))
+    if rc:
+        raise JfError(rc, "positions_from_spherical")
+    return out
 
 
 def position_from_cartesian(x, y, z):

@@ -364,6 +364,12 @@ int jf_position_from_cartesian(float x, float y, float z, float out[JF_POS_FLOAT
     return host_from_cartesian(x, y, z, out, nullptr);
 }
 
+int jf_positions_from_spherical(size_t n, const float *ele, const float *azi, const float *r, float *out) {
+    if (n && (!ele || !azi || !r || !out)) return JF_ERR_ARG;
+    for (size_t i = 0; i < n; i++) host_from_spherical(ele[i], azi[i], r[i], out + 5 * i);
+    return JF_OK;
+}
+
 int jf_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
     if (!idx || !omegas) return JF_ERR_ARG;
     return host_interpolation(ele, azi, idx, omegas);

@@ -451,15 +451,30 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void fused_block_kernel(const Fus
 
 // ---------------------------------------------------------------- mixing --
 // Audio.cu:109-110: out[i] += source->intermediate[i], sources in index order.
-__global__ void mix_kernel(const float *__restrict__ partial, float *__restrict__ mix, int S, int K,
-                           int blk /* 2B */) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= K * blk) return;
-    const int b = g / blk, n = g - b * blk;
+// Deterministic: 16 groups of consecutive sources are each summed in source order by
+// their own wave, then the 16 group sums are added in group order.  One workgroup
+// = 64 consecutive output floats of one block x 16 source groups.
+constexpr int kMixGroups = 16;
+__global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ mix, int S, int K,
+                                                              int blk /* 2B */) {
+    __shared__ float red[kMixGroups][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int chunks = blk / 64;
+    const int b = blockIdx.x / chunks, n = (blockIdx.x - b * chunks) * 64 + lane;
+    const int per = (S + kMixGroups - 1) / kMixGroups;
+    const int s0 = grp * per, s1 = min(S, s0 + per);
     const float *p = partial + (size_t)b * S * blk + n;
     float acc = 0.0f;
-    for (int s = 0; s < S; s++) acc += p[(size_t)s * blk];
-    mix[g] = acc;
+    for (int s = s0; s < s1; s++) acc += p[(size_t)s * blk];
+    red[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int g = 1; g < kMixGroups; g++) t += red[g][lane];
+        mix[(size_t)b * blk + n] = t;
+    }
 }
 
 // ----------------------------------------------- indices and weights (a2,a3)
@@ -696,8 +711,9 @@ hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
 }
 
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st) {
-    const int n = K * 2 * B;
-    hipLaunchKernelGGL(mix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_partial, d_mix, S, K, 2 * B);
+    const int blk = 2 * B;  // multiple of 64 because B is
+    hipLaunchKernelGGL(mix_kernel, dim3(K * (blk / 64)), dim3(64 * kMixGroups), 0, st, d_partial, d_mix, S, K,
+                       blk);
     return hipGetLastError();
 }
 

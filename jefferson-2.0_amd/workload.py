@@ -1,0 +1,81 @@
+"""Synthetic multi-source workloads of SURVEY.md 8(d) (BASELINE.json configs 3/4) and
+the source sharding used for multi-GPU runs.  Pure NumPy + the C ABI's position helper;
+no GPU needed to build a workload.
+
+config 3: per source `src` (GLOBAL id, so shards of a multi-GPU job are disjoint pieces of
+one job): 1 s of uniform white noise in [-0.5, 0.5), seed 1234 + src, looped; start azimuth
+(src*37) mod 360, elevation -40 + (src*7) mod 121, radius uniform in [0.5, 3.5] from the same
+generator; "moving" = azimuth + 1 degree every block (a crossfade every block).
+"""
+import numpy as np
+
+FS = 44100
+TABLE_ROW_BYTES = 2 * 513 * 8   # one HRTF row pair in the reference layout
+WINDOW_BYTES = 1024 * 4
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous source range of `rank`: sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def source_signal_and_start(src, n_samples=FS):
+    rng = np.random.default_rng(1234 + int(src))
+    r = np.float32(rng.uniform(0.5, 3.5))  # drawn first, so it does not depend on n_samples
+    sig = rng.uniform(-0.5, 0.5, n_samples).astype(np.float32)
+    azi = (int(src) * 37) % 360
+    ele = -40 + (int(src) * 7) % 121
+    return sig, ele, azi, r
+
+
+def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0):
+    """Latched position records [n_blocks][len(src_ids)][5] for blocks first_block.."""
+    src_ids = np.asarray(src_ids)
+    ele = np.array([-40 + (int(s) * 7) % 121 for s in src_ids], np.float32)
+    azi0 = np.array([(int(s) * 37) % 360 for s in src_ids], np.int64)
+    r = np.array([source_signal_and_start(s, 1)[3] for s in src_ids], np.float32)
+    b = np.arange(first_block, first_block + n_blocks, dtype=np.int64)[:, None]
+    azi = (azi0[None, :] + (b if moving else 0 * b)) % 360
+    ele2 = np.broadcast_to(ele[None, :], azi.shape)
+    r2 = np.broadcast_to(r[None, :], azi.shape)
+    return jf.positions_from_spherical(ele2, azi.astype(np.float32), r2)
+
+
+def n_terms_table(jf):
+    """terms[ele + 49][azi] = number of table rows read for that latched (ele, azi), azi 0..360."""
+    t = np.zeros((140, 361), np.int32)
+    for e in range(-49, 91):
+        for a in range(361):
+            idx, _ = jf.interpolation(float(e), float(a))
+            if idx[0] == idx[1] == idx[2] == idx[3]:
+                n = 1
+            elif (idx[0] == idx[2] and idx[1] == idx[3]) or (idx[0] == idx[1] and idx[0] != idx[2]):
+                n = 2
+            else:
+                n = 4
+            t[e + 49, a] = n
+    return t
+
+
+def algorithmic_bytes(jf, pos, B, first_old=None, terms=None):
+    """Algorithmic bytes of a [K][S][5] trajectory window, SURVEY.md 8(d): per source-block
+    (rows_old + rows_new) * 8208 B of table + 4096 B window + 2*B*4 B stereo block out.
+    first_old: (ele, azi) [S][2] latched before the window (None -> (0, 0), a fresh engine)."""
+    if terms is None:
+        terms = n_terms_table(jf)
+    ele = pos[..., 0].astype(np.int64)
+    azi = pos[..., 1].astype(np.int64)
+    K, S = ele.shape
+    prev_e = np.zeros((K, S), np.int64)
+    prev_a = np.zeros((K, S), np.int64)
+    if first_old is not None:
+        prev_e[0], prev_a[0] = first_old[:, 0], first_old[:, 1]
+    prev_e[1:], prev_a[1:] = ele[:-1], azi[:-1]
+    n_new = terms[ele + 49, azi]
+    moved = (prev_e != ele) | (prev_a != azi)
+    n_old = np.where(moved, terms[prev_e + 49, prev_a], 0)
+    rows = int(n_new.sum() + n_old.sum())
+    items = K * S
+    return rows * TABLE_ROW_BYTES + items * (WINDOW_BYTES + 2 * B * 4), rows, items
