@@ -1,0 +1,199 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/jefferson.h
+declares, its host-side logic (geometry, index rules, WAV/HRIR readers) agrees with the
+oracle, and it fails loudly -- never falls back -- when no GPU is present."""
+import ctypes
+import os
+import re
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+import model64
+import oracle_lib
+from conftest import GOLD, ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "jefferson.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(jf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(jf):
+    names = _header_functions()
+    assert len(names) >= 35
+    L = ctypes.CDLL(jf.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the binding covers the whole header
+    assert sorted(jf.exported_symbols()) == names
+
+
+def test_header_cites_reference_interfaces():
+    src = open(os.path.join(ROOT, "include", "jefferson.h")).read()
+    for cite in ("Audio.cu:94", "Audio.cu:164-175", "SoundSource.cu:20-36", "SoundSource.cu:41-54",
+                 "hrtf_signals.cu:107-153", "GPUSoundSource.cu:463-471", "cudaPart.cu:21-63"):
+        assert cite in src, cite
+
+
+def test_no_gpu_means_loud_failure(jf, hrir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(jf.JfError) as ei:
+        jf.Engine(256, 512, 1, hrir=hrir)
+    assert ei.value.code == jf.JF_ERR_DEVICE
+
+
+def test_create_argument_checks(jf, hrir):
+    cfg_bad = [(100, 512, 1, 1), (256, 512, 0, 1), (256, 100, 1, 1), (256, 512, 1, 0), (512, 512, 1, 1)]
+    for B, L, S, K in cfg_bad:
+        with pytest.raises(jf.JfError) as ei:
+            jf.Engine(B, L, S, hrir=hrir, max_batch_blocks=K)
+        assert ei.value.code == jf.JF_ERR_ARG, (B, L, S, K)
+    with pytest.raises(jf.JfError) as ei:
+        jf.Engine(256, 512, 1, hrir_dir="/nonexistent/kemar")
+    assert ei.value.code == jf.JF_ERR_IO
+
+
+def test_product_code_does_not_touch_the_oracle():
+    """The shipped library and package must not link, import or call oracle/."""
+    pkg = os.path.join(ROOT, "jefferson-2.0_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "jf_oracle" not in text and "model64" not in text and "jfo_" not in text, f
+    out = os.popen(f"ldd '{os.path.join(pkg, 'libjefferson_hip.so')}'").read()
+    assert "jf_oracle" not in out
+
+
+def test_host_interpolation_matches_oracle(jf):
+    for ele in range(-52, 94):
+        for azi in list(range(-3, 364, 5)) + [359, 360, 361]:
+            a, b = jf.interpolation(float(ele), float(azi)), oracle_lib.interp(float(ele), float(azi))
+            assert (a is None) == (b is None), (ele, azi)
+            if a is not None:
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (ele, azi)
+    for ele in (-40, 0, 37, 90):
+        for azi in range(0, 361):
+            assert jf.pick_hrtf(ele, azi) == oracle_lib.pick_hrtf(ele, azi)
+
+
+def test_host_positions_match_oracle(jf):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        ele, azi, r = rng.uniform(-49, 90), rng.uniform(0, 360), rng.uniform(0.1, 5)
+        assert np.array_equal(jf.position_from_spherical(ele, azi, r), oracle_lib.from_spherical(ele, azi, r))
+        x, y, z = rng.uniform(-3, 3, 3)
+        p, o = jf.position_from_cartesian(x, y, z), oracle_lib.from_cartesian(x, y, z)
+        assert np.array_equal(p[:2], o[:2]) and np.array_equal(p[2:], np.float32([x, y, z]))
+    assert jf.position_from_cartesian(0, 0, 0) is None
+    ele = rng.integers(-40, 90, (7, 5)).astype(np.float32)
+    azi = rng.integers(0, 360, (7, 5)).astype(np.float32)
+    v = jf.positions_from_spherical(ele, azi, np.float32(1.5))
+    assert v.shape == (7, 5, 5)
+    assert np.array_equal(v[3, 2], jf.position_from_spherical(ele[3, 2], azi[3, 2], 1.5))
+
+
+def _write_wav(path, data, sampwidth, nch=1, fs=44100):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(nch)
+        w.setsampwidth(sampwidth)
+        w.setframerate(fs)
+        w.writeframes(data)
+
+
+def test_wav_reader_scaling_and_stereo_downmix(jf, tmp_path):
+    """cudaPart.cu:21-63 readFile with libsndfile's float scaling."""
+    ints = np.array([0, 1, -1, 32767, -32768, 12345], np.int16)
+    p = str(tmp_path / "m16.wav")
+    _write_wav(p, ints.tobytes(), 2)
+    x, fs = jf.wav_read_mono(p)
+    assert fs == 44100 and np.array_equal(x, ints.astype(np.float32) / np.float32(32768))
+
+    v24 = np.array([0, 1, -1, 8388607, -8388608, 1234567], np.int32)
+    raw = b"".join(struct.pack("<i", int(v))[:3] for v in v24)
+    p = str(tmp_path / "m24.wav")
+    _write_wav(p, raw, 3)
+    x, _ = jf.wav_read_mono(p)
+    assert np.array_equal(x, (v24 / 8388608.0).astype(np.float32))
+
+    st = np.array([[1000, 3000], [-2000, 2000], [32767, 32767]], np.int16)
+    p = str(tmp_path / "s16.wav")
+    _write_wav(p, st.tobytes(), 2, nch=2)
+    x, _ = jf.wav_read_mono(p)
+    f = st.astype(np.float32) / np.float32(32768)
+    assert np.array_equal(x, (f[:, 0] / 2.0 + f[:, 1] / 2.0).astype(np.float32))
+
+    with pytest.raises(jf.JfError):
+        jf.wav_read_mono(str(tmp_path / "missing.wav"))
+    (tmp_path / "junk.wav").write_bytes(b"not a wav file at all")
+    with pytest.raises(jf.JfError):
+        jf.wav_read_mono(str(tmp_path / "junk.wav"))
+
+
+def test_wav_reader_on_the_castanets_fixture(jf, castanets, tmp_path):
+    ex = np.load(os.path.join(GOLD, "castanets_441_excerpt_i24.npy"))
+    raw = b"".join(struct.pack("<i", int(v))[:3] for v in ex[:5000])
+    p = str(tmp_path / "c.wav")
+    _write_wav(p, raw, 3)
+    x, _ = jf.wav_read_mono(p)
+    assert np.array_equal(x, castanets[:5000])
+
+
+def test_wav_writer_pcm24_roundtrip(jf, tmp_path):
+    rng = np.random.default_rng(2)
+    y = rng.uniform(-1, 1, (300, 2)).astype(np.float32)
+    y[0] = (1.5, -1.5)  # clipped
+    p = str(tmp_path / "o.wav")
+    jf.wav_write_stereo24(p, y)
+    with wave.open(p) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (2, 3, 44100, 300)
+        raw = np.frombuffer(w.readframes(300), np.uint8).reshape(-1, 3).astype(np.int32)
+    v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+    v = np.where(v >= 1 << 23, v - (1 << 24), v).reshape(300, 2)
+    assert v[0, 0] == 8388607 and v[0, 1] == -8388608
+    # float32 scaling (as libsndfile) then rounding: within one 24-bit step
+    assert np.abs(v[1:] / 8388607.0 - y[1:]).max() <= 1.0 / 8388607
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Jefferson/compact"),
+                    reason="the reference's compact KEMAR directory only exists in the build container")
+def test_compact_directory_loader_reproduces_the_fixture(jf, hrir):
+    """jf_engine_create_from_dir reads the reference's own data files: up to the point where a
+    GPU is needed, i.e. a complete, valid directory yields JF_ERR_DEVICE (not JF_ERR_IO)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("checked on the GPU by test_gpu_engine.py")
+    with pytest.raises(jf.JfError) as ei:
+        jf.Engine(256, 512, 1, hrir_dir="/root/reference/Jefferson/compact")
+    assert ei.value.code == jf.JF_ERR_DEVICE
+
+
+def test_workload_helpers(jf):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+    assert [wl.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert wl.shard_range(8192, 8, 7) == (7168, 8192)
+    sig, ele, azi, r = wl.source_signal_and_start(5)
+    assert len(sig) == 44100 and abs(sig).max() <= 0.5 and (ele, azi) == (-5, 185) and 0.5 <= r <= 3.5
+    assert wl.source_signal_and_start(5, 10)[3] == r
+    pos = wl.trajectories(jf, [0, 5, 1029], 4)
+    assert pos.shape == (4, 3, 5)
+    assert pos[:, 1, 1].tolist() == [185, 186, 187, 188] and set(pos[:, 1, 0]) == {-5.0}
+    # shards of a multi-GPU job are slices of the single-GPU job
+    assert np.array_equal(wl.trajectories(jf, [1029], 4)[:, 0], pos[:, 2])
+    terms = wl.n_terms_table(jf)
+    assert terms[0 + 49, 0] == 1 and terms[0 + 49, 3] == 2 and terms[5 + 49, 0] == 2 and terms[5 + 49, 3] == 4
+    # stationary case-4 source: 4 rows + window + output = 38 976 B
+    one = np.tile(jf.position_from_spherical(5, 3, 1.0), (3, 1, 1))
+    b, rows, items = wl.algorithmic_bytes(jf, one, 256, first_old=np.array([[5, 3]]), terms=terms)
+    assert (b, rows, items) == (3 * 38976, 12, 3)
+    mov = wl.trajectories(jf, [2], 3, first_block=2)  # ele -26, azi 76, 77, 78: both ends case 4 -> 71 808 B
+    b, rows, items = wl.algorithmic_bytes(jf, mov[1:], 256, first_old=mov[0, :, :2].astype(np.int64), terms=terms)
+    assert b == 2 * 71808
