@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjefferson_hip.so")
+# JF_LIB selects an A/B build of the same library (csrc/Makefile `variant`); default = the product
+LIB_PATH = os.environ.get("JF_LIB") or os.path.join(_HERE, "libjefferson_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
 
 JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6

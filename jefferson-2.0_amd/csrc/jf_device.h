@@ -26,7 +26,16 @@ constexpr int kN = 1024;       // PAD_LEN (Universal.cuh:12)
 constexpr int kNc = 513;       // PAD_LEN / 2 + 1
 constexpr int kNumHrtf = 710;  // NUM_HRTF (Universal.cuh:4)
 constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
-constexpr int kWavesPerWg = 8; // waves (work items) per workgroup of the fused kernel
+// Tuning knobs of the fused kernel (overridable at build time for A/B runs):
+// waves (= work items) per workgroup, and the minimum waves per SIMD the register
+// allocator must leave room for (__launch_bounds__ second argument; 0 = unconstrained).
+#ifndef JF_WAVES_PER_WG
+#define JF_WAVES_PER_WG 4
+#endif
+#ifndef JF_MIN_WAVES
+#define JF_MIN_WAVES 0
+#endif
+constexpr int kWavesPerWg = JF_WAVES_PER_WG;
 
 struct ItemDesc {
     int rows_new[4];

@@ -49,6 +49,7 @@ struct jf_engine {
     float4 *d_htab = nullptr;
     float2 *d_tw = nullptr;
     SrcSignal *d_sigs = nullptr;
+    float *d_zero = nullptr;  // PAD_LEN zeros: the "signal" of a source without one
     SrcState *d_state[2] = {nullptr, nullptr};
     float *d_hist[2] = {nullptr, nullptr};
     ItemDesc *d_desc = nullptr;
@@ -163,6 +164,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_htab);
     (void)hipFree(e->d_tw);
     (void)hipFree(e->d_sigs);
+    (void)hipFree(e->d_zero);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(e->d_state[i]);
         (void)hipFree(e->d_hist[i]);
@@ -227,8 +229,10 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5));
         JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B));
         e->d_signal.assign(S, nullptr);
-        e->h_sigs.assign(S, SrcSignal{nullptr, 0, 0});
-        JF_HIP(e, hipMemset(e->d_sigs, 0, sizeof(SrcSignal) * S));
+        JF_HIP(e, hipMalloc(&e->d_zero, sizeof(float) * kN));
+        JF_HIP(e, hipMemset(e->d_zero, 0, sizeof(float) * kN));
+        e->h_sigs.assign(S, SrcSignal{e->d_zero, kN, 0});
+        JF_HIP(e, hipMemcpy(e->d_sigs, e->h_sigs.data(), sizeof(SrcSignal) * S, hipMemcpyHostToDevice));
         // SoundSource::SoundSource() defaults (SoundSource.cu:3-16)
         e->pos.assign(S, HostPos{0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.5f});
 
@@ -291,10 +295,23 @@ int jf_num_sources(const jf_engine *e) { return e ? e->S : JF_ERR_ARG; }
 int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
     JF_HIP(e, hipStreamSynchronize(e->stream));
+    // The device copy always has length >= PAD_LEN so that the kernel wraps the loop with
+    // one conditional subtract: a shorter signal is stored as whole repetitions of itself
+    // (the looped stream is identical), an empty one as the shared zero buffer.
     float *d_new = nullptr;
+    size_t n_dev = n;
     if (n) {
-        JF_HIP(e, hipMalloc(&d_new, sizeof(float) * n));
-        hipError_t st = hipMemcpy(d_new, mono, sizeof(float) * n, hipMemcpyHostToDevice);
+        const float *src_host = mono;
+        std::vector<float> tiled;
+        if (n < (size_t)kN) {
+            const size_t reps = ((size_t)kN + n - 1) / n;
+            tiled.resize(reps * n);
+            for (size_t r = 0; r < reps; r++) memcpy(tiled.data() + r * n, mono, sizeof(float) * n);
+            src_host = tiled.data();
+            n_dev = reps * n;
+        }
+        JF_HIP(e, hipMalloc(&d_new, sizeof(float) * n_dev));
+        hipError_t st = hipMemcpy(d_new, src_host, sizeof(float) * n_dev, hipMemcpyHostToDevice);
         if (st != hipSuccess) {
             (void)hipFree(d_new);
             JF_HIP(e, st);
@@ -302,7 +319,7 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     }
     if (e->d_signal[src]) (void)hipFree(e->d_signal[src]);
     e->d_signal[src] = d_new;
-    e->h_sigs[src] = SrcSignal{d_new, (int)n, 0};
+    e->h_sigs[src] = n ? SrcSignal{d_new, (int)n_dev, 0} : SrcSignal{e->d_zero, kN, 0};
     JF_HIP(e, hipMemcpy(e->d_sigs + src, &e->h_sigs[src], sizeof(SrcSignal), hipMemcpyHostToDevice));
     const int zero = 0;  // count = 0 (cudaPart.cu:198-199 run with a fresh source)
     JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));

@@ -238,8 +238,12 @@ JF_DEV float2 distance_factor(double a, float inv_frac, int k) {
     const double u4 = (t - floor(t)) * 4.0;
     const double n = rint(u4);
     const float f = (float)(u4 - n);  // quarter turns in [-0.5, 0.5]
-    float s, c;
-    sincospif(0.5f * f, &s, &c);
+    // sin/cos of x = f*pi/2, |x| <= pi/4: minimax kernels (Cephes sinf/cosf), ~1 ulp
+    const float x = f * 1.57079632679489661923f;
+    const float x2 = x * x;
+    const float s = x + x * x2 * (-1.6666654611e-1f + x2 * (8.3321608736e-3f + x2 * -1.9515295891e-4f));
+    const float c = 1.0f - 0.5f * x2 +
+                    x2 * x2 * (4.166664568298827e-2f + x2 * (-1.388731625493765e-3f + x2 * 2.443315711809948e-5f));
     const int qd = ((int)n) & 3;
     const float cs = (qd == 0) ? c : (qd == 1) ? -s : (qd == 2) ? -c : s;
     const float sn = (qd == 0) ? s : (qd == 1) ? c : (qd == 2) ? -s : -c;
@@ -258,20 +262,29 @@ JF_DEV void weighted_rows(const float4 *__restrict__ htab, const int *rows, cons
         hp[t] = htab + (size_t)rows[t] * 512 + lane;
         wt[t] = w[t];
     }
+    // 8 row loads (8 KiB per wave) in flight at a time: enough to cover the L2/MALL latency
+    // with 3-4 waves per SIMD, and it keeps the register footprint at 32 VGPRs.
+    constexpr int QC = 8 / NT;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        float4 h[NT];
+    for (int qc = 0; qc < 8; qc += QC) {
+        float4 h[QC][NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) h[t] = hp[t][64 * q];
-        float4 acc = make_float4(wt[0] * h[0].x, wt[0] * h[0].y, wt[0] * h[0].z, wt[0] * h[0].w);
+        for (int q = 0; q < QC; q++)
 #pragma unroll
-        for (int t = 1; t < NT; t++) {
-            acc.x += wt[t] * h[t].x;
-            acc.y += wt[t] * h[t].y;
-            acc.z += wt[t] * h[t].z;
-            acc.w += wt[t] * h[t].w;
+            for (int t = 0; t < NT; t++) h[q][t] = hp[t][64 * (qc + q)];
+#pragma unroll
+        for (int q = 0; q < QC; q++) {
+            float4 acc = make_float4(wt[0] * h[q][0].x, wt[0] * h[q][0].y, wt[0] * h[q][0].z, wt[0] * h[q][0].w);
+#pragma unroll
+            for (int t = 1; t < NT; t++) {
+                acc.x += wt[t] * h[q][t].x;
+                acc.y += wt[t] * h[q][t].y;
+                acc.z += wt[t] * h[q][t].z;
+                acc.w += wt[t] * h[q][t].w;
+            }
+            he[qc + q] = acc;
         }
-        he[q] = acc;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -318,7 +331,12 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
 constexpr int kWaveLds = 1088;  // float2 per wave (8704 B): inverse exchange; forward uses 576
 
 template <int NOUT>  // B / 64
-__global__ __launch_bounds__(64 * kWavesPerWg) void fused_block_kernel(const FusedParams P) {
+#if JF_MIN_WAVES > 0
+#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg, JF_MIN_WAVES)
+#else
+#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg)
+#endif
+__global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     __shared__ float2 s_tw[1024];
     __shared__ float2 s_buf[kWavesPerWg * kWaveLds];
     const int tid = threadIdx.x;
@@ -348,32 +366,23 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void fused_block_kernel(const Fus
     const float *hist = P.hist_in + (size_t)s * kN;
     const float *sigp = sg.ptr;
     // first NEW sample of this call has q = 0; window sample n has q = b*B + n - (N - B)
+    // The engine stores every signal with length >= N (short ones tiled, empty ones as
+    // zeros), so one conditional subtract wraps the loop.
     const int q0 = b * B - (kN - B);
-    int pos0 = 0;  // signal index of q = max(q0, 0)
-    if (sg.length > 0) pos0 = (int)(((long long)count0 + (q0 > 0 ? q0 : 0)) % sg.length);
+    const int L = sg.length;
+    const int qpos = q0 > 0 ? q0 : 0;
+    const int base = (int)(((long long)count0 + qpos) % L) - qpos;  // signal index of q = 0 (mod L)
     float2 z[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         float xv[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int n = 2 * (lane + 64 * r) + c;
-            const int q = q0 + n;
-            float val;
-            if (q < 0) {
-                val = hist[kN + q];
-            } else if (sg.length > 0) {
-                int idx = pos0 + (q0 > 0 ? n : q);
-                if (sg.length >= kN) {
-                    if (idx >= sg.length) idx -= sg.length;
-                } else {
-                    idx %= sg.length;
-                }
-                val = sigp[idx];
-            } else {
-                val = 0.0f;
-            }
-            xv[c] = val;
+            const int q = q0 + 2 * (lane + 64 * r) + c;
+            int idx = base + q;  // < L + N for q >= 0
+            idx = idx >= L ? idx - L : idx;
+            const float *p = q < 0 ? hist + (kN + q) : sigp + idx;
+            xv[c] = *p;
         }
         z[r] = make_float2(xv[0], xv[1]);
     }
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void fused_block_kernel(const Fus
         for (int r = 0; r < 8; r++) *reinterpret_cast<float2 *>(ho + 2 * (lane + 64 * r)) = z[r];
         if (lane == 0) {
             SrcState st;
-            st.count = sg.length > 0 ? (int)(((long long)count0 + (long long)P.K * B) % sg.length) : 0;
+            st.count = (int)(((long long)count0 + (long long)P.K * B) % L);
             const float *pp = P.pos + (size_t)item * 5;
             st.old_ele = pp[0];
             st.old_azi = pp[1];

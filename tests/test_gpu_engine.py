@@ -140,7 +140,9 @@ def test_distance_sweep_gain_and_delay(jf, hrir):
             x.set_spherical(0, 0, 45, r)
         for _ in range(4):
             y, y64 = e.process_block(), m.process_block()
-            assert np.abs(y - y64).max() <= TOL64
+            # the 2e-7 bound is for |y| < 1 (the reference flags > 1.0 as clipping, Audio.cu:111);
+            # at r = 0.05 the gain is ~1 and the noise input drives |y| to ~1.3
+            assert np.abs(y - y64).max() <= TOL64 * max(1.0, np.abs(y64).max())
         e.close()
 
 
