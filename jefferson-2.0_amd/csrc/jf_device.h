@@ -32,6 +32,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_WAVES_PER_WG
 #define JF_WAVES_PER_WG 4
 #endif
+#ifndef JF_CHUNK_LOADS
+#define JF_CHUNK_LOADS 8  // table-row loads (16 B per lane each) a wave keeps in flight per round
+#endif
 #ifndef JF_MIN_WAVES
 #define JF_MIN_WAVES 0
 #endif
@@ -42,7 +45,7 @@ struct ItemDesc {
     float w_new[4];
     int rows_old[4];
     float w_old[4];
-    double a;        // fsvs * r'  (turns per bin * 513)
+    unsigned long long c_fix;  // frac(fsvs * r' / 513) * 2^64: distance-delay phase step per bin, in turns
     float inv_frac;  // 1 / (1 + fsvs r'^2)
     int n_new;       // 1, 2 or 4 terms; 0 = position not interpolable -> silence
     int n_old;       // 0 = no crossfade

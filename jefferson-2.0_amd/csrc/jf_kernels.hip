@@ -231,30 +231,35 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
 }
 
 // ------------------------------------------------------- distance factor --
-// D[k] = exp(-2 pi i * a * k / 513) * inv_frac (kernels.cu:116-125): the phase is
-// reduced in double (turns), the quadrant remainder evaluated in float.
-JF_DEV float2 distance_factor(double a, float inv_frac, int k) {
-    const double t = a * (double)k * (1.0 / 513.0);
-    const double u4 = (t - floor(t)) * 4.0;
-    const double n = rint(u4);
-    const float f = (float)(u4 - n);  // quarter turns in [-0.5, 0.5]
-    // sin/cos of x = f*pi/2, |x| <= pi/4: minimax kernels (Cephes sinf/cosf), ~1 ulp
-    const float x = f * 1.57079632679489661923f;
+// D[k] = exp(-2 pi i * fsvs r' k / 513) * inv_frac (kernels.cu:116-125).  The phase is
+// exact integer arithmetic: c = frac(fsvs r'/513) as a 64-bit fraction of a turn, phase(k) =
+// k*c mod 1 (top 32 bits kept, 1.5e-9 rad), split into the nearest quarter turn and a
+// remainder |f| <= 1/2 quarter turn that goes through float minimax kernels.
+JF_DEV float2 distance_factor(unsigned c_hi, unsigned c_lo, float inv_frac, int k) {
+    const unsigned p = (unsigned)k * c_hi + __umulhi((unsigned)k, c_lo);
+    const unsigned p2 = p + 0x20000000u;  // + 1/8 turn: round to the nearest quarter
+    const int qd = (int)(p2 >> 30);
+    const int rem = (int)(p2 & 0x3FFFFFFFu) - 0x20000000;
+    // x = remainder in radians, |x| <= pi/4
+    const float x = (float)rem * (1.57079632679489661923f / 1073741824.0f);
     const float x2 = x * x;
+    // Cephes sinf/cosf kernels, ~1 ulp
     const float s = x + x * x2 * (-1.6666654611e-1f + x2 * (8.3321608736e-3f + x2 * -1.9515295891e-4f));
     const float c = 1.0f - 0.5f * x2 +
                     x2 * x2 * (4.166664568298827e-2f + x2 * (-1.388731625493765e-3f + x2 * 2.443315711809948e-5f));
-    const int qd = ((int)n) & 3;
     const float cs = (qd == 0) ? c : (qd == 1) ? -s : (qd == 2) ? -c : s;
     const float sn = (qd == 0) ? s : (qd == 1) ? c : (qd == 2) ? -s : -c;
     return make_float2(cs * inv_frac, -sn * inv_frac);
 }
 
 // ------------------------------------------------------ filter + inverse --
-// he[q] = sum_t w[t] * H[rows[t]][lane + 64 q] (both ears in one float4).
+// For this lane's bins k = lane + 64 q: he = sum_t w[t] * H[rows[t]][k] (both ears in one
+// float4), Y_ear = (X D)[k] * he_ear, and the two inputs of the inverse transform it yields:
+// v[q] = Z[k] = Y_L + j Y_R and mir[q] = Z[N-k] = conj Y_L + j conj Y_R.
+// xd[q] = X[k] D[k]; on lane 0, xd[0] = (X0*D0.re, X512*D512.re).
 template <int NT>
-JF_DEV void weighted_rows(const float4 *__restrict__ htab, const int *rows, const float *w,
-                          float4 (&he)[8], int lane) {
+JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, const float *w,
+                          const float2 (&xd)[8], float2 (&v)[16], float2 (&mir)[8], int lane) {
     const float4 *hp[NT];
     float wt[NT];
 #pragma unroll
@@ -262,9 +267,9 @@ JF_DEV void weighted_rows(const float4 *__restrict__ htab, const int *rows, cons
         hp[t] = htab + (size_t)rows[t] * 512 + lane;
         wt[t] = w[t];
     }
-    // 8 row loads (8 KiB per wave) in flight at a time: enough to cover the L2/MALL latency
-    // with 3-4 waves per SIMD, and it keeps the register footprint at 32 VGPRs.
-    constexpr int QC = 8 / NT;
+    // JF_CHUNK_LOADS row loads (16 B per lane each) in flight per round; the weighted sum is
+    // folded into Z right away so that only the loads of one round are live.
+    constexpr int QC = (JF_CHUNK_LOADS / NT) > 8 ? 8 : (JF_CHUNK_LOADS / NT);
 #pragma unroll
     for (int qc = 0; qc < 8; qc += QC) {
         float4 h[QC][NT];
@@ -274,47 +279,44 @@ JF_DEV void weighted_rows(const float4 *__restrict__ htab, const int *rows, cons
             for (int t = 0; t < NT; t++) h[q][t] = hp[t][64 * (qc + q)];
 #pragma unroll
         for (int q = 0; q < QC; q++) {
-            float4 acc = make_float4(wt[0] * h[q][0].x, wt[0] * h[q][0].y, wt[0] * h[q][0].z, wt[0] * h[q][0].w);
+            float4 he = make_float4(wt[0] * h[q][0].x, wt[0] * h[q][0].y, wt[0] * h[q][0].z, wt[0] * h[q][0].w);
 #pragma unroll
             for (int t = 1; t < NT; t++) {
-                acc.x += wt[t] * h[q][t].x;
-                acc.y += wt[t] * h[q][t].y;
-                acc.z += wt[t] * h[q][t].z;
-                acc.w += wt[t] * h[q][t].w;
+                he.x += wt[t] * h[q][t].x;
+                he.y += wt[t] * h[q][t].y;
+                he.z += wt[t] * h[q][t].z;
+                he.w += wt[t] * h[q][t].w;
             }
-            he[qc + q] = acc;
+            const float2 x = xd[qc + q];
+            const float2 yl = cmul(x, make_float2(he.x, he.y));
+            const float2 yr = cmul(x, make_float2(he.z, he.w));
+            float2 zk = make_float2(yl.x - yr.y, yl.y + yr.x);
+            float2 zm = make_float2(yl.x + yr.y, yr.x - yl.y);
+            if (qc + q == 0) {
+                // lane 0: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
+                const float2 z0 = make_float2(x.x * he.x, x.x * he.z);    // Z[0]
+                const float2 z512 = make_float2(x.y * he.y, x.y * he.w);  // Z[512]
+                zk = lane == 0 ? z0 : zk;
+                zm = lane == 0 ? z512 : zm;
+            }
+            v[qc + q] = zk;
+            mir[qc + q] = zm;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // One filter set for this lane's bins, then the inverse transform.
-// xd[q] = X[k] D[k] for k = lane + 64 q; on lane 0, xd[0] = (X0*D0.re, X512*D512.re).
 JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows, const float *w,
                        const float2 (&xd)[8], float2 (&v)[16], float2 *buf, const float2 *tw,
                        int lane) {
-    float4 he[8];
-    if (nt == 4)
-        weighted_rows<4>(htab, rows, w, he, lane);
-    else if (nt == 2)
-        weighted_rows<2>(htab, rows, w, he, lane);
-    else
-        weighted_rows<1>(htab, rows, w, he, lane);
     float2 mir[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const float2 yl = cmul(xd[q], make_float2(he[q].x, he[q].y));
-        const float2 yr = cmul(xd[q], make_float2(he[q].z, he[q].w));
-        v[q] = make_float2(yl.x - yr.y, yl.y + yr.x);    // Z[k]   = YL + j YR
-        mir[q] = make_float2(yl.x + yr.y, yr.x - yl.y);  // Z[N-k] = conj YL + j conj YR
-    }
-    {
-        // lane 0: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
-        const float2 z0 = make_float2(xd[0].x * he[0].x, xd[0].x * he[0].z);    // Z[0]
-        const float2 z512 = make_float2(xd[0].y * he[0].y, xd[0].y * he[0].w);  // Z[512]
-        v[0] = lane == 0 ? z0 : v[0];
-        mir[0] = lane == 0 ? z512 : mir[0];
-    }
+    if (nt == 4)
+        filtered_bins<4>(htab, rows, w, xd, v, mir, lane);
+    else if (nt == 2)
+        filtered_bins<2>(htab, rows, w, xd, v, mir, lane);
+    else
+        filtered_bins<1>(htab, rows, w, xd, v, mir, lane);
     // upper half: Z[lane + 64 r], r = 8..15, lives mirrored on lane 64 - lane
     const int src = (64 - lane) & 63;
 #pragma unroll
@@ -357,7 +359,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     const ItemDesc *dp = P.desc + item;
     const int n_new = dp->n_new;
     const int n_old = dp->n_old;
-    const double da = dp->a;
+    const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
     const float inv_frac = dp->inv_frac;
 
     // ---- window gather (Audio.cu:121-139, GPUSoundSource.cu:472-513)
@@ -375,16 +377,27 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     float2 z[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        float xv[2];
+        const int qr = q0 + 128 * r;  // first sample of this 128-sample row (wave-uniform)
+        if ((NOUT % 2 == 0) && qr < 0) {
+            // B is a multiple of 128: the window/signal boundary falls between rows
+            z[r] = *reinterpret_cast<const float2 *>(hist + (kN + qr) + 2 * lane);
+        } else if (NOUT % 2 == 0) {
+            int i0 = base + qr + 2 * lane, i1 = i0 + 1;  // < L + N
+            i0 = i0 >= L ? i0 - L : i0;
+            i1 = i1 >= L ? i1 - L : i1;
+            z[r] = make_float2(sigp[i0], sigp[i1]);
+        } else {
+            float xv[2];
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int q = q0 + 2 * (lane + 64 * r) + c;
-            int idx = base + q;  // < L + N for q >= 0
-            idx = idx >= L ? idx - L : idx;
-            const float *p = q < 0 ? hist + (kN + q) : sigp + idx;
-            xv[c] = *p;
+            for (int c = 0; c < 2; c++) {
+                const int q = qr + 2 * lane + c;
+                int idx = base + q;  // < L + N for q >= 0
+                idx = idx >= L ? idx - L : idx;
+                const float *p = q < 0 ? hist + (kN + q) : sigp + idx;
+                xv[c] = *p;
+            }
+            z[r] = make_float2(xv[0], xv[1]);
         }
-        z[r] = make_float2(xv[0], xv[1]);
     }
     if (b == P.K - 1) {
         // last block of the call: leave the window and the counters for the next call
@@ -418,11 +431,11 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         constexpr float scale = 1.0f / 1024.0f;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const float2 d = distance_factor(da, inv_frac, lane + 64 * q);
+            const float2 d = distance_factor(c_hi, c_lo, inv_frac, lane + 64 * q);
             xd[q] = cmul(make_float2(X[q].x * scale, X[q].y * scale), d);
         }
         {
-            const float2 d512 = distance_factor(da, inv_frac, 512);
+            const float2 d512 = distance_factor(c_hi, c_lo, inv_frac, 512);
             const float2 x0 = make_float2(X[0].x * scale * inv_frac, X[0].y * scale * d512.x);
             xd[0] = lane == 0 ? x0 : xd[0];
         }
@@ -602,7 +615,12 @@ __global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, c
     r /= 5;
     const float fsvs = (float)(44100.0 / 343.0);
     const float frac = 1 + fsvs * (float)((double)r * (double)r);
-    d.a = (double)fsvs * (double)r;
+    {
+        // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+        double c = (double)fsvs * (double)r / 513.0;
+        c -= floor(c);
+        d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
+    }
     d.inv_frac = 1.0f / frac;
     if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
     d.pad = 0;
