@@ -230,3 +230,61 @@ def test_full_size_moving_workload_properties(jf, hrir):
     half = e2.process_batch(pos)
     e2.close()
     assert np.array_equal(half, (0.5 * mix).astype(np.float32))
+
+
+def _write_compact_dir(root, hrir):
+    """Re-create the reference's compact KEMAR layout (compact/elev%d/H%de%03da.wav, stereo int16)
+    from the committed table fixture, so the directory loader can be exercised off the build box."""
+    import wave
+    for j, (e, a) in enumerate(model64.table_positions()):
+        if a > 180:
+            continue
+        d = os.path.join(root, f"elev{e}")
+        os.makedirs(d, exist_ok=True)
+        pcm = np.round(hrir[j].T * 32768.0).astype(np.int16)  # [128][2], ch0 = left
+        with wave.open(os.path.join(d, f"H{e}e{a:03d}a.wav"), "wb") as w:
+            w.setnchannels(2)
+            w.setsampwidth(2)
+            w.setframerate(44100)
+            w.writeframes(pcm.tobytes())
+
+
+def test_directory_loader_and_offline_driver(jf, hrir, castanets, tmp_path):
+    """jf_engine_create_from_dir on a compact-layout directory, and the plain-C offline driver
+    (jf_render: WAV in -> stereo 24-bit WAV out, benchmarkTesting trajectory) against the oracle."""
+    import struct
+    import subprocess
+    import wave
+    from conftest import ROOT, scenario_positions
+    kemar = str(tmp_path / "compact")
+    _write_compact_dir(kemar, hrir)
+    eng = jf.Engine(256, 512, 1, hrir_dir=kemar)
+    assert np.array_equal(eng.read_table(), jf.Engine(256, 512, 1, hrir=hrir).read_table())
+    eng.close()
+
+    ex = np.load(os.path.join(ROOT, "tests", "golden", "castanets_441_excerpt_i24.npy"))[:30000]
+    inp = str(tmp_path / "in.wav")
+    with wave.open(inp, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(44100)
+        w.writeframes(b"".join(struct.pack("<i", int(v))[:3] for v in ex))
+    outp = str(tmp_path / "out.wav")
+    exe = os.path.join(ROOT, "jefferson-2.0_amd", "jf_render")
+    r = subprocess.run([exe, kemar, inp, outp, "--block", "256", "--azi", "3", "--ele", "5",
+                        "--dwell", "4", "--rounds", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with wave.open(outp) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getnframes()) == (2, 3, 256 * 4 * 6)
+        raw = np.frombuffer(w.readframes(w.getnframes()), np.uint8).reshape(-1, 3).astype(np.int32)
+    v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+    got = (np.where(v >= 1 << 23, v - (1 << 24), v) / 8388607.0).reshape(-1, 512)
+
+    ora = oracle_lib.Engine(256, 512, 1, hrir)
+    ora.set_signal(0, castanets[:30000])
+    ora.reset(0)
+    want = []
+    for (ele, azi, rr) in scenario_positions(3, 5, 4, 5):
+        ora.set_spherical(0, ele, azi, rr)
+        want.append(ora.process_block())
+    assert np.abs(got - np.array(want)).max() <= 1.0 / 8388607 + TOL32
