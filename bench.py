@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
+    ap.add_argument("--reverb", action="store_true",
+                    help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
+                         "(partitioned FDL convolution ahead of the spatialiser); not the default bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=256)
     args = ap.parse_args()
@@ -92,8 +95,15 @@ def main():
     gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
     hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
 
+    global B
     S = SOURCES_PER_GPU
     K, W, KB = args.steps, args.warmup, BLOCKS_PER_STEP
+    ir = None
+    if args.reverb:
+        B, S, KB = 128, 256, 32
+        rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
+        ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
+        ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
     total_blocks = (K + W) * KB
     src_lo = rank * S  # weak scaling: every rank brings its own 1024 sources
     src_ids = np.arange(src_lo, src_lo + S)
@@ -101,6 +111,8 @@ def main():
     eng = jf.Engine(B, 512, S, hrir=hrir, device=local_rank, max_batch_blocks=KB)
     for s, sid in enumerate(src_ids):
         eng.set_signal(s, wl.source_signal_and_start(sid)[0])
+    if ir is not None:
+        eng.set_reverb(ir, 0.5)
     pos = wl.trajectories(jf, src_ids, total_blocks, moving=not args.stationary)
     eng.upload_positions(pos)
 
@@ -131,6 +143,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
+    reverb_ms = eng.profile_read_reverb() if ir is not None else 0.0
     eng.profile_enable(False)
 
     if world > 1:
@@ -175,7 +188,20 @@ def main():
                          "prep_ms_per_launch": prof["prep_ms"] / max(prof["launches"], 1),
                          "mix_ms_per_launch": prof["mix_ms"] / max(prof["launches"], 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if ir is not None:
+            # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
+            # 690*129*8 B of IR spectra once per block (shared by all sources)
+            P = -(-len(ir) // B)
+            rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
+            t = reverb_ms / max(prof["launches"], 1) * 1e-3
+            out["config"]["workload"] = ("configs[4]: 256 sources + 2 s convolution-reverb IR, partitioned "
+                                         "overlap-save (690 partitions of 128), 128-sample blocks")
+            out["reverb_roofline"] = {"bound": "hbm", "achieved": rb / t / 1e9 if t > 0 else 0.0,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None,
+                                      "kernel": "reverb_fft_kernel + reverb_mac_kernel",
+                                      "algorithmic_bytes_per_launch": rb, "avg_launch_ms": t * 1e3}
+        if world == 1 and not args.no_cpu_baseline and ir is None:
             out["cpu_baseline"] = cpu_baseline(jf, wl, hrir, S, args.cpu_sample_blocks)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

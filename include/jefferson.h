@@ -154,6 +154,24 @@ int jf_pa_callback(const void *input, void *output, unsigned long frames_per_buf
 /* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed. */
 int jf_set_pause(jf_engine *e, int paused);
 
+/* ---- convolution reverb -------------------------------- */
+
+/*
+ * Replaces the offline whole-signal reverb of cudaFFT() (cudaPart.cu:65-205: mono input (*) mono
+ * impulse response, then a gain that matches the output RMS to the input RMS, :118,161-165)
+ * by real-time uniformly partitioned convolution ahead of the spatialiser: every source's
+ * signal is convolved with `ir` (n_ir taps, mono; partitions of frames_per_buffer taps,
+ * frames_per_buffer must be 64, 128 or 256) and scaled by `gain`.  n_ir == 0 turns the
+ * stage off.  Call before processing starts or between blocks; it resets every source's
+ * window and play position (like jf_source_reset).
+ */
+int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain);
+
+/* The reference's gain rule (cudaPart.cu:118,161-165): rms(x) / rms(x (*) ir) over the whole
+ * signal (x zero-padded by ceil(n_ir/2), circular convolution of that length: cudaPart.cu:170-186),
+ * evaluated on the host in double.  Returns 1 for degenerate inputs. */
+float jf_reverb_rms_gain(const float *signal, size_t n, const float *ir, size_t n_ir);
+
 /* ---- batch (offline / throughput) processing -------------------------- */
 
 /*
@@ -187,6 +205,7 @@ void *jf_engine_stream(jf_engine *e);
  * the accumulated milliseconds and launch count since arming. */
 int jf_profile_enable(jf_engine *e, int enable);
 int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches);
+int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb kernels, same launches */
 
 /* ---- debugging / parity taps ------------------------------------------ */
 

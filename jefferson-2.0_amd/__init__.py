@@ -71,6 +71,9 @@ _SIGS = {
     "jf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "jf_reverb_set_ir": (C.c_int, [C.c_void_p, _f, C.c_size_t, C.c_float]),
+    "jf_reverb_rms_gain": (C.c_float, [_f, C.c_size_t, _f, C.c_size_t]),
+    "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
     "jf_debug_rfft_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
@@ -144,6 +147,12 @@ def interpolation(ele, azi):
 
 def pick_hrtf(ele, azi):
     return lib().jf_pick_hrtf(ele, azi)
+
+
+def reverb_rms_gain(signal, ir):
+    signal = np.ascontiguousarray(signal, np.float32)
+    ir = np.ascontiguousarray(ir, np.float32)
+    return float(lib().jf_reverb_rms_gain(_fp(signal), len(signal), _fp(ir), len(ir)))
 
 
 def wav_read_mono(path):
@@ -274,6 +283,15 @@ class Engine:
         n = C.c_long()
         self._chk(lib().jf_profile_read(self.h, C.byref(f), C.byref(p), C.byref(m), C.byref(n)))
         return {"fused_ms": f.value, "prep_ms": p.value, "mix_ms": m.value, "launches": n.value}
+
+    def set_reverb(self, ir, gain=1.0):
+        ir = np.ascontiguousarray(ir, np.float32)
+        self._chk(lib().jf_reverb_set_ir(self.h, _fp(ir) if len(ir) else None, len(ir), gain))
+
+    def profile_read_reverb(self):
+        r = C.c_double()
+        self._chk(lib().jf_profile_read_reverb(self.h, C.byref(r)))
+        return r.value
 
     def read_table(self):
         t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)

@@ -86,4 +86,25 @@ struct FusedParams {
     int S, K, B;
 };
 
+// Convolution reverb stage (jf_reverb.hip): uniformly partitioned overlap-save with a
+// frequency-domain delay line.  Spectra are packed: B complex per partition, bin 0 =
+// (X[0].re, X[B].re).
+//   fdl    float2[S][Rg][B]   last Rg input spectra of every source (ring, slot = block index mod Rg)
+//   hspec  float2[P][B]       IR partition spectra, pre-scaled by gain / B
+//   wet    float[S][Wr]       reverberated mono signal, read by the spatialiser as the source signal
+//   prev   float[2][S][B]     last dry block (ping-pong per call), dry_count int[2][S]
+struct ReverbParams {
+    const float2 *tw;
+    const SrcSignal *dry;     // [S]
+    const int *dry_count_in;  // [S]
+    int *dry_count_out;       // [S]
+    const float *prev_in;     // [S][B]
+    float *prev_out;          // [S][B]
+    float2 *fdl;
+    const float2 *hspec;
+    float *wet;
+    const SrcState *st_in;    // count = wet-ring position of the first new sample of this call
+    int S, K, B, P, Rg, Wr, head;
+};
+
 }  // namespace jf

@@ -24,6 +24,9 @@ hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *
                        int K, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
+hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
+                            float2 *d_hspec, hipStream_t st);
+hipError_t launch_reverb(const ReverbParams &P, hipStream_t st);
 }  // namespace jf
 
 using namespace jf;
@@ -73,8 +76,17 @@ struct jf_engine {
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
     bool profiling = false;
-    std::vector<EventPair> ev_prep, ev_fused, ev_mix;
+    std::vector<EventPair> ev_prep, ev_fused, ev_mix, ev_reverb;
     size_t ev_used = 0;
+
+    // convolution reverb stage (jf_reverb.hip); off while rv_P == 0
+    int rv_P = 0, rv_Rg = 0, rv_Wr = 0, rv_head = 0;
+    float2 *d_rv_hspec = nullptr;
+    float2 *d_rv_fdl = nullptr;
+    float *d_rv_wet = nullptr;
+    float *d_rv_prev[2] = {nullptr, nullptr};
+    int *d_rv_count[2] = {nullptr, nullptr};
+    SrcSignal *d_sigs_wet = nullptr;  // [S] the wet rings as the spatialiser's signals
 };
 
 namespace {
@@ -118,11 +130,41 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
     JF_HIP(e, launch_prep(ring_table(), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
+    if (e->rv_P > 0) {
+        // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring (this call's K blocks)
+        EventPair *er = nullptr;
+        if (e->profiling) {
+            er = next_events(e, e->ev_reverb);
+            if (!er) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
+            JF_HIP(e, hipEventRecord(er->a, e->stream));
+        }
+        ReverbParams R;
+        R.tw = e->d_tw;
+        R.dry = e->d_sigs;
+        R.dry_count_in = e->d_rv_count[p];
+        R.dry_count_out = e->d_rv_count[p ^ 1];
+        R.prev_in = e->d_rv_prev[p];
+        R.prev_out = e->d_rv_prev[p ^ 1];
+        R.fdl = e->d_rv_fdl;
+        R.hspec = e->d_rv_hspec;
+        R.wet = e->d_rv_wet;
+        R.st_in = e->d_state[p];
+        R.S = e->S;
+        R.K = K;
+        R.B = e->B;
+        R.P = e->rv_P;
+        R.Rg = e->rv_Rg;
+        R.Wr = e->rv_Wr;
+        R.head = e->rv_head;
+        JF_HIP(e, launch_reverb(R, e->stream));
+        if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
+        e->rv_head = (e->rv_head + K) % e->rv_Rg;
+    }
     FusedParams P;
     P.htab = e->d_htab;
     P.tw = e->d_tw;
     P.desc = e->d_desc;
-    P.sigs = e->d_sigs;
+    P.sigs = e->rv_P > 0 ? e->d_sigs_wet : e->d_sigs;
     P.st_in = e->d_state[p];
     P.st_out = e->d_state[p ^ 1];
     P.hist_in = e->d_hist[p];
@@ -156,9 +198,44 @@ void snapshot_positions(jf_engine *e, float *dst /* [S][5] */) {
     }
 }
 
+void free_reverb(jf_engine *e) {
+    (void)hipFree(e->d_rv_hspec);
+    (void)hipFree(e->d_rv_fdl);
+    (void)hipFree(e->d_rv_wet);
+    (void)hipFree(e->d_sigs_wet);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(e->d_rv_prev[i]);
+        (void)hipFree(e->d_rv_count[i]);
+        e->d_rv_prev[i] = nullptr;
+        e->d_rv_count[i] = nullptr;
+    }
+    e->d_rv_hspec = nullptr;
+    e->d_rv_fdl = nullptr;
+    e->d_rv_wet = nullptr;
+    e->d_sigs_wet = nullptr;
+    e->rv_P = e->rv_Rg = e->rv_Wr = e->rv_head = 0;
+}
+
+// zero one source's (or every source's, src < 0) window, counters and reverb state
+int reset_sources(jf_engine *e, int src) {
+    const size_t s0 = src < 0 ? 0 : (size_t)src, ns = src < 0 ? (size_t)e->S : 1;
+    const int p = e->cur;
+    JF_HIP(e, hipMemset(e->d_hist[p] + s0 * kN, 0, sizeof(float) * kN * ns));
+    JF_HIP(e, hipMemset(e->d_state[p] + s0, 0, sizeof(SrcState) * ns));
+    if (e->rv_P > 0) {
+        const size_t B = (size_t)e->B;
+        JF_HIP(e, hipMemset(e->d_rv_fdl + s0 * e->rv_Rg * B, 0, sizeof(float2) * e->rv_Rg * B * ns));
+        JF_HIP(e, hipMemset(e->d_rv_wet + s0 * e->rv_Wr, 0, sizeof(float) * e->rv_Wr * ns));
+        JF_HIP(e, hipMemset(e->d_rv_prev[p] + s0 * B, 0, sizeof(float) * B * ns));
+        JF_HIP(e, hipMemset(e->d_rv_count[p] + s0, 0, sizeof(int) * ns));
+    }
+    return JF_OK;
+}
+
 void destroy_engine(jf_engine *e) {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_reverb(e);
     for (float *p : e->d_signal)
         if (p) (void)hipFree(p);
     (void)hipFree(e->d_htab);
@@ -176,7 +253,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_traj);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
-    for (auto *pool : {&e->ev_prep, &e->ev_fused, &e->ev_mix})
+    for (auto *pool : {&e->ev_prep, &e->ev_fused, &e->ev_mix, &e->ev_reverb})
         for (auto &p : *pool) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
@@ -322,7 +399,10 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     e->h_sigs[src] = n ? SrcSignal{d_new, (int)n_dev, 0} : SrcSignal{e->d_zero, kN, 0};
     JF_HIP(e, hipMemcpy(e->d_sigs + src, &e->h_sigs[src], sizeof(SrcSignal), hipMemcpyHostToDevice));
     const int zero = 0;  // count = 0 (cudaPart.cu:198-199 run with a fresh source)
-    JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));
+    if (e->rv_P > 0)  // the play position of the dry signal lives in the reverb stage
+        JF_HIP(e, hipMemcpy(e->d_rv_count[e->cur] + src, &zero, sizeof(int), hipMemcpyHostToDevice));
+    else
+        JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));
     return JF_OK;
 }
 
@@ -365,9 +445,7 @@ int jf_source_get_position(const jf_engine *e, int src, float out[6]) {
 int jf_source_reset(jf_engine *e, int src) {
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     JF_HIP(e, hipStreamSynchronize(e->stream));
-    JF_HIP(e, hipMemset(e->d_hist[e->cur] + (size_t)src * kN, 0, sizeof(float) * kN));
-    JF_HIP(e, hipMemset(e->d_state[e->cur] + src, 0, sizeof(SrcState)));
-    return JF_OK;
+    return reset_sources(e, src);
 }
 
 int jf_position_from_spherical(float ele, float azi, float r, float out[JF_POS_FLOATS]) {
@@ -451,6 +529,78 @@ int jf_pa_callback(const void *, void *output, unsigned long frames, const void 
 int jf_set_pause(jf_engine *e, int paused) {
     if (!e) return JF_ERR_ARG;
     e->paused = paused != 0;
+    return JF_OK;
+}
+
+// ---- convolution reverb ----------------------------------------------------
+int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
+    if (!e || (n_ir && !ir) || n_ir > (size_t)1 << 26) return fail(e, JF_ERR_ARG, "bad impulse response");
+    if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    const bool was_on = e->rv_P > 0;
+    free_reverb(e);
+    if (n_ir == 0) {
+        if (was_on) return reset_sources(e, -1);
+        return JF_OK;
+    }
+    const int B = e->B;
+    if (B != 64 && B != 128 && B != 256)
+        return fail(e, JF_ERR_ARG, "reverb needs frames_per_buffer of 64, 128 or 256 (FFT of 2 blocks)");
+    const size_t S = (size_t)e->S;
+    const int P = (int)((n_ir + B - 1) / B);
+    const int Rg = P + e->maxK;                          // slots a call may still read + the ones it writes
+    const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
+    float *d_ir = nullptr;
+    auto body = [&]() -> int {
+        JF_HIP(e, hipMalloc(&e->d_rv_hspec, sizeof(float2) * (size_t)P * B));
+        JF_HIP(e, hipMalloc(&e->d_rv_fdl, sizeof(float2) * S * Rg * B));
+        JF_HIP(e, hipMalloc(&e->d_rv_wet, sizeof(float) * S * Wr));
+        JF_HIP(e, hipMalloc(&e->d_sigs_wet, sizeof(SrcSignal) * S));
+        for (int i = 0; i < 2; i++) {
+            JF_HIP(e, hipMalloc(&e->d_rv_prev[i], sizeof(float) * S * B));
+            JF_HIP(e, hipMalloc(&e->d_rv_count[i], sizeof(int) * S));
+            JF_HIP(e, hipMemset(e->d_rv_prev[i], 0, sizeof(float) * S * B));
+            JF_HIP(e, hipMemset(e->d_rv_count[i], 0, sizeof(int) * S));
+        }
+        std::vector<SrcSignal> wet(S);
+        for (size_t s = 0; s < S; s++) wet[s] = SrcSignal{e->d_rv_wet + s * Wr, Wr, 0};
+        JF_HIP(e, hipMemcpy(e->d_sigs_wet, wet.data(), sizeof(SrcSignal) * S, hipMemcpyHostToDevice));
+        JF_HIP(e, hipMalloc(&d_ir, sizeof(float) * n_ir));
+        JF_HIP(e, hipMemcpy(d_ir, ir, sizeof(float) * n_ir, hipMemcpyHostToDevice));
+        // 1/B: normalisation of the B-point inverse used for the 2B-point real transform
+        JF_HIP(e, launch_reverb_ir(d_ir, (int)n_ir, P, B, gain / (float)B, e->d_tw, e->d_rv_hspec, e->stream));
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+        return JF_OK;
+    };
+    int rc = body();
+    (void)hipFree(d_ir);
+    if (rc != JF_OK) {
+        const std::string msg = e->err;
+        free_reverb(e);
+        return fail(e, rc, msg);
+    }
+    e->rv_P = P;
+    e->rv_Rg = Rg;
+    e->rv_Wr = Wr;
+    e->rv_head = 0;
+    return reset_sources(e, -1);
+}
+
+float jf_reverb_rms_gain(const float *signal, size_t n, const float *ir, size_t n_ir) {
+    if (!signal || !ir || n == 0 || n_ir == 0) return 1.0f;
+    return host_reverb_rms_gain(signal, n, ir, n_ir);
+}
+
+int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
+    if (!e || !reverb_ms) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    double r = 0;
+    for (size_t i = 0; i < e->ev_used && i < e->ev_reverb.size(); i++) {
+        float ms = 0;
+        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_reverb[i].a, e->ev_reverb[i].b));
+        r += ms;
+    }
+    *reverb_ms = r;
     return JF_OK;
 }
 

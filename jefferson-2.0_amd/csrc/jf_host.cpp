@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "../../include/jefferson.h"
 
 namespace jf {
@@ -299,6 +301,65 @@ int wav_write_stereo24(const char *path, const float *il, size_t n_frames, int r
         return JF_ERR_IO;
     }
     return JF_OK;
+}
+
+// ------------------------------------------------------------ reverb gain ---
+namespace {
+// in-place radix-2 complex FFT in double (n a power of two), sign = -1 forward / +1 inverse
+void dfft(std::vector<double> &re, std::vector<double> &im, int sign) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = sign * 2.0 * kPi / (double)len;
+        for (size_t base = 0; base < n; base += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
+                const size_t a = base + k, b = a + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+    }
+}
+}  // namespace
+
+float host_reverb_rms_gain(const float *x, size_t n, const float *ir, size_t n_ir) {
+    // cudaPart.cu:170-186 PadData: both padded to new_size = n + (n_ir - n_ir/2); the product of
+    // the two new_size-point spectra is a CIRCULAR convolution of that length (the tail wraps).
+    const size_t new_size = n + (n_ir - n_ir / 2);
+    size_t m = 1;
+    while (m < n + n_ir) m <<= 1;
+    std::vector<double> ar(m, 0.0), ai(m, 0.0), br(m, 0.0), bi(m, 0.0);
+    double e_in = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        ar[i] = x[i];
+        e_in += (double)x[i] * x[i];
+    }
+    for (size_t i = 0; i < n_ir; i++) br[i] = ir[i];
+    dfft(ar, ai, -1);
+    dfft(br, bi, -1);
+    for (size_t i = 0; i < m; i++) {
+        const double r = ar[i] * br[i] - ai[i] * bi[i], q = ar[i] * bi[i] + ai[i] * br[i];
+        ar[i] = r;
+        ai[i] = q;
+    }
+    dfft(ar, ai, +1);
+    std::vector<double> y(new_size, 0.0);
+    for (size_t i = 0; i < n + n_ir - 1; i++) y[i % new_size] += ar[i] / (double)m;  // fold the linear result
+    double e_out = 0.0;
+    for (size_t i = 0; i < new_size; i++) e_out += y[i] * y[i];
+    if (!(e_in > 0.0) || !(e_out > 0.0)) return 1.0f;
+    return (float)sqrt(e_in / e_out);
 }
 
 // ------------------------------------------------------- KEMAR directory ---

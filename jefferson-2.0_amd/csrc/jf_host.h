@@ -24,6 +24,9 @@ int host_from_cartesian(float x, float y, float z, float out[5], float *r);   //
 // KEMAR directory -> [710][2][taps] float32 (int16 / 32768).
 int load_hrir_dir(const char *dir, std::vector<float> *hrir, int *taps, std::string *err);
 
+// rms(x) / rms(x (*) ir) with the padding and circular length of cudaPart.cu:170-186, in double.
+float host_reverb_rms_gain(const float *x, size_t n, const float *ir, size_t n_ir);
+
 int wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate, std::string *err);
 int wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate,
                        std::string *err);

@@ -1,0 +1,281 @@
+// jf_reverb.hip -- convolution reverb ahead of the spatialiser (SURVEY.md 8f-1,
+// BASELINE.json configs[4]): uniformly partitioned overlap-save convolution with a
+// frequency-domain delay line (FDL), one partition = one audio block of B samples.
+//
+// Replaces the reference's offline whole-signal cuFFT convolution (cudaPart.cu:65-205,
+// disabled there by reverbFlag = false and broken by swapped kernel arguments, App. C#12)
+// with the real-time form: per block and source
+//   A  X_k = rfft([x_{k-1}, x_k])                          -> FDL slot (head + k)        1 KB written
+//   B  Y_k = sum_{p<P} X_{k-p} * H_p ; y_k = irfft(Y_k)[B:] -> the source's "wet" ring    P KB read
+// and the spatialiser then reads the wet ring as the source's signal.  Stage B is the
+// HBM-bound part: P x B x 8 bytes of FDL per source-block (690 x 1 KB at B = 128, 2 s IR).
+//
+// Spectra are stored packed: B complex per partition, bin 0 holding (X[0].re, X[B].re).
+#include <hip/hip_runtime.h>
+
+#include "jf_device.h"
+
+namespace jf {
+
+#define JF_DEV __device__ __forceinline__
+
+namespace {
+
+JF_DEV float2 rv_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+JF_DEV float2 rv_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+JF_DEV float2 rv_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+JF_DEV float2 rv_mulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+
+// Wave-private LDS hand-off (see jf_kernels.hip)
+#define JF_RV_SYNC()                                            \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+// In-LDS complex FFT of NPT points by one wavefront: radix-2 Stockham autosort,
+// ping-pong between a and b; returns the buffer holding the result in natural order.
+// DIR = -1 forward, +1 inverse (unnormalised).  tw = exp(+2 pi i j / 1024).
+template <int NPT, int DIR>
+JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, int lane) {
+#pragma unroll 1
+    for (int p = 1; p < NPT; p <<= 1) {
+        const int tstep = 512 / p;  // exp(-+ 2 pi i k / (2p)) = tw[k * 512 / p]
+        for (int j = lane; j < NPT / 2; j += 64) {
+            const int k = j & (p - 1);
+            const float2 u0 = a[j];
+            const float2 w = tw[k * tstep];
+            const float2 u1 = DIR > 0 ? rv_mul(a[j + NPT / 2], w) : rv_mulc(a[j + NPT / 2], w);
+            const int dst = ((j - k) << 1) + k;
+            b[dst] = rv_add(u0, u1);
+            b[dst + p] = rv_sub(u0, u1);
+        }
+        JF_RV_SYNC();
+        float2 *t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- stage A --
+// One wavefront per (block k, source s): spectrum of [x_{k-1}, x_k] into the FDL.
+template <int B>
+__global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
+    __shared__ float2 s_buf[4][2 * B];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= P.K * P.S) return;
+    const int k = g / P.S, s = g - k * P.S;
+    float2 *a = s_buf[wave], *b = s_buf[wave] + B;
+
+    const SrcSignal sg = P.dry[s];
+    const int L = sg.length;  // >= 1024 (tiled / zero buffer)
+    const int dc0 = P.dry_count_in[s];
+    const int cur0 = (int)(((long long)dc0 + (long long)k * B) % L);
+    const int prv0 = (int)(((long long)dc0 + (long long)(k > 0 ? k - 1 : 0) * B) % L);
+    const float *prev_state = P.prev_in + (size_t)s * B;
+    // z[m] = x[2m] + j x[2m+1] over x = [previous block, current block]
+    for (int m = lane; m < B; m += 64) {
+        float xv[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int n = 2 * m + c;
+            float v;
+            if (n < B) {
+                if (k == 0) {
+                    v = prev_state[n];
+                } else {
+                    int idx = prv0 + n;
+                    idx = idx >= L ? idx - L : idx;
+                    v = sg.ptr[idx];
+                }
+            } else {
+                int idx = cur0 + (n - B);
+                idx = idx >= L ? idx - L : idx;
+                v = sg.ptr[idx];
+            }
+            xv[c] = v;
+        }
+        a[m] = make_float2(xv[0], xv[1]);
+    }
+    if (k == P.K - 1) {
+        // state for the next call: the last dry block and the advanced play position
+        float *po = P.prev_out + (size_t)s * B;
+        for (int n = lane; n < B; n += 64) {
+            int idx = cur0 + n;
+            idx = idx >= L ? idx - L : idx;
+            po[n] = sg.ptr[idx];
+        }
+        if (lane == 0) P.dry_count_out[s] = (int)(((long long)dc0 + (long long)P.K * B) % L);
+    }
+    JF_RV_SYNC();
+    const float2 *Z = cfft_small<B, -1>(a, b, P.tw, lane);
+    // real-FFT split: X[k] = E + (-i) W^k O, W = exp(-2 pi i / 2B)
+    float2 *out = P.fdl + ((size_t)s * P.Rg + (size_t)((P.head + k) % P.Rg)) * B;
+    for (int q = lane; q < B; q += 64) {
+        const float2 zk = Z[q];
+        const float2 zm = Z[(B - q) & (B - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 wo = rv_mulc(o, P.tw[q * (512 / B)]);
+        float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+        if (q == 0) x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B]), both real
+        out[q] = x;
+    }
+}
+
+// ---------------------------------------------------------------- stage B --
+// One workgroup (4 waves) per (block k, source s): the 4 waves split the P partitions,
+// each lane owns B/64 consecutive bins; LDS reduce; wave 0 inverts and writes the wet block.
+template <int B>
+__global__ __launch_bounds__(256) void reverb_mac_kernel(const ReverbParams P) {
+    constexpr int NB = B / 64;
+    __shared__ float2 s_red[4][B];
+    __shared__ float2 s_fft[2 * B];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x / P.S, s = blockIdx.x - k * P.S;
+
+    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + lane * NB;
+    const float2 *hs = P.hspec + lane * NB;
+    float2 acc[NB];
+    float2 acc0 = make_float2(0.f, 0.f);  // bin 0 is two packed real bins
+#pragma unroll
+    for (int i = 0; i < NB; i++) acc[i] = make_float2(0.f, 0.f);
+    int slot = (P.head + k - wave) % P.Rg;
+    if (slot < 0) slot += P.Rg;
+#pragma unroll 2
+    for (int p = wave; p < P.P; p += 4) {
+        float2 x[NB], h[NB];
+        const float2 *xp = fdl + (size_t)slot * B;
+        const float2 *hp = hs + (size_t)p * B;
+        if (NB == 2) {
+            const float4 xv = *reinterpret_cast<const float4 *>(xp);
+            const float4 hv = *reinterpret_cast<const float4 *>(hp);
+            x[0] = make_float2(xv.x, xv.y);
+            x[NB - 1] = make_float2(xv.z, xv.w);
+            h[0] = make_float2(hv.x, hv.y);
+            h[NB - 1] = make_float2(hv.z, hv.w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                x[i] = xp[i];
+                h[i] = hp[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            acc[i].x += x[i].x * h[i].x - x[i].y * h[i].y;
+            acc[i].y += x[i].x * h[i].y + x[i].y * h[i].x;
+        }
+        acc0.x += x[0].x * h[0].x;
+        acc0.y += x[0].y * h[0].y;
+        slot -= 4;
+        if (slot < 0) slot += P.Rg;
+    }
+    if (lane == 0) acc[0] = acc0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) s_red[wave][lane * NB + i] = acc[i];
+    __syncthreads();
+    if (wave != 0) return;
+
+    // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
+    float2 *ybuf = s_fft, *zbuf = s_fft + B;
+    for (int q = lane; q < B; q += 64)
+        ybuf[q] = rv_add(rv_add(s_red[0][q], s_red[1][q]), rv_add(s_red[2][q], s_red[3][q]));
+    JF_RV_SYNC();
+    for (int q = lane; q < B; q += 64) {
+        const float2 yk = ybuf[q];
+        const float2 ym = ybuf[(B - q) & (B - 1)];
+        float2 z;
+        if (q == 0) {
+            z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));  // E0 + j O0 from (Y[0], Y[B])
+        } else {
+            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+            const float2 o = rv_mul(d, P.tw[q * (512 / B)]);  // W^-q = exp(+2 pi i q / 2B)
+            z = make_float2(e.x - o.y, e.y + o.x);
+        }
+        zbuf[q] = z;
+    }
+    JF_RV_SYNC();
+    const float2 *zt = cfft_small<B, +1>(zbuf, ybuf, P.tw, lane);
+    // overlap-save: time samples B..2B-1 = z[m], m >= B/2 (even, odd interleaved)
+    const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
+    float *wet = P.wet + (size_t)s * P.Wr;
+    const int w0 = (int)(((long long)c0 + (long long)k * B) % P.Wr);
+    for (int m = B / 2 + lane; m < B; m += 64) {
+        const float2 v = zt[m];
+        const int n = 2 * m - B;  // 0..B-2, even; the ring length is a multiple of B, w0 too
+        *reinterpret_cast<float2 *>(wet + w0 + n) = v;
+    }
+}
+
+// ------------------------------------------------------------- IR spectra --
+// One wavefront per partition p: rfft([h_p (B taps), zeros]) * scale, packed.
+template <int B>
+__global__ __launch_bounds__(64) void reverb_ir_kernel(const float *__restrict__ ir, int n_ir, float scale,
+                                                      const float2 *__restrict__ tw, float2 *__restrict__ hspec) {
+    __shared__ float2 s_buf[2 * B];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    float2 *a = s_buf, *b = s_buf + B;
+    for (int m = lane; m < B; m += 64) {
+        const int n = 2 * m;
+        const int i0 = p * B + n, i1 = i0 + 1;
+        const float x0 = (n < B && i0 < n_ir) ? ir[i0] : 0.0f;
+        const float x1 = (n + 1 < B && i1 < n_ir) ? ir[i1] : 0.0f;
+        a[m] = make_float2(x0, x1);
+    }
+    JF_RV_SYNC();
+    const float2 *Z = cfft_small<B, -1>(a, b, tw, lane);
+    for (int q = lane; q < B; q += 64) {
+        const float2 zk = Z[q];
+        const float2 zm = Z[(B - q) & (B - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 wo = rv_mulc(o, tw[q * (512 / B)]);
+        float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+        if (q == 0) x = make_float2(zk.x + zk.y, zk.x - zk.y);
+        hspec[(size_t)p * B + q] = make_float2(x.x * scale, x.y * scale);
+    }
+}
+
+// ---------------------------------------------------------------- launchers --
+hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
+                            float2 *d_hspec, hipStream_t st) {
+    switch (B) {
+    case 64: hipLaunchKernelGGL(reverb_ir_kernel<64>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
+    case 128: hipLaunchKernelGGL(reverb_ir_kernel<128>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
+    case 256: hipLaunchKernelGGL(reverb_ir_kernel<256>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
+    const dim3 ga((P.K * P.S + 3) / 4), gb(P.K * P.S), blk(256);
+    switch (P.B) {
+    case 64:
+        hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<64>, gb, blk, 0, st, P);
+        break;
+    case 128:
+        hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<128>, gb, blk, 0, st, P);
+        break;
+    case 256:
+        hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<256>, gb, blk, 0, st, P);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace jf

@@ -173,6 +173,21 @@ def test_compact_directory_loader_reproduces_the_fixture(jf, hrir):
     assert ei.value.code == jf.JF_ERR_DEVICE
 
 
+def test_reverb_rms_gain_rule(jf):
+    """cudaPart.cu:118,161-186: rms(x) / rms(circular convolution of length n + ceil(n_ir/2))."""
+    rng = np.random.default_rng(4)
+    for n, n_ir in [(1000, 64), (777, 301), (4096, 1000)]:
+        x = rng.uniform(-.5, .5, n).astype(np.float32)
+        h = (rng.standard_normal(n_ir) * np.exp(-3 * np.arange(n_ir) / n_ir)).astype(np.float32)
+        new_size = n + (n_ir - n_ir // 2)
+        X = np.fft.fft(np.pad(x.astype(np.float64), (0, new_size - n)))
+        H = np.fft.fft(np.pad(h.astype(np.float64), (0, new_size - n_ir)))
+        y = np.fft.ifft(X * H).real
+        want = np.sqrt((x.astype(np.float64) ** 2).sum() / (y ** 2).sum())
+        assert jf.reverb_rms_gain(x, h) == pytest.approx(want, rel=1e-6)
+    assert jf.reverb_rms_gain(np.zeros(10, np.float32), np.ones(3, np.float32)) == 1.0
+
+
 def test_workload_helpers(jf):
     import importlib.util
     spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
