@@ -79,11 +79,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # JF_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the multi-rank path
+    # on a 1-GPU box (RCCL refuses duplicate devices); the measured configuration is always nccl.
+    backend = os.environ.get("JF_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from jf_load import jf
     import importlib.util
@@ -124,7 +132,10 @@ def main():
         eng.batch_run(i * KB, KB, mix.data_ptr())
         if world > 1:
             with torch.cuda.stream(ext):
-                dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)
+                if backend == "nccl":
+                    dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: K * 2 KB per GPU
+                else:
+                    dist.all_reduce(mix, op=dist.ReduceOp.SUM)     # gloo has no GPU reduce
 
     def fence():
         eng.synchronize()
@@ -147,7 +158,7 @@ def main():
     eng.profile_enable(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

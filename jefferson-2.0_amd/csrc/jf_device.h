@@ -8,7 +8,8 @@
 //                             16-byte load per lane fetches both ears and a row
 //                             is exactly 8 KiB.  Same numbers as the reference's
 //                             fft_hrtf[(j*2+ear)*513+k] (hrtf_signals.cu:90-98).
-//   tw     float2[1024]       exp(+2*pi*i*j/1024), from double.
+//   tw     float2[1024]       exp(+2*pi*i*j/1024), from double (reverb kernels).
+//   twpack float2[2368]       the same values re-laid per FFT pass (see kTw* below), staged in LDS.
 //   sig    float[len_s]       one device buffer per source (looped playback).
 //   hist   float[2][S][1024]  each source's last window (ping-pong per call).
 //   state  SrcState[2][S]     count / old_ele / old_azi (ping-pong per call).
@@ -30,7 +31,7 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 // waves (= work items) per workgroup, and the minimum waves per SIMD the register
 // allocator must leave room for (__launch_bounds__ second argument; 0 = unconstrained).
 #ifndef JF_WAVES_PER_WG
-#define JF_WAVES_PER_WG 4
+#define JF_WAVES_PER_WG 16
 #endif
 #ifndef JF_CHUNK_LOADS
 #define JF_CHUNK_LOADS 8  // table-row loads (16 B per lane each) a wave keeps in flight per round
@@ -39,6 +40,16 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #define JF_MIN_WAVES 0
 #endif
 constexpr int kWavesPerWg = JF_WAVES_PER_WG;
+
+// Twiddle pack: every table the FFT passes need, laid out so that a wave reads consecutive
+// float2 entries at compile-time offsets (no index arithmetic, no LDS bank conflicts).
+// w(j) = exp(+2 pi i j / 1024); lane = 4 i + a.
+constexpr int kTwW3 = 0;       // [16][64] last inverse stage  w(a (i + 16 t) + 768 a)   at [t][lane]
+constexpr int kTwU = 1024;     // [8][64]  real-FFT split      w(lane + 64 q)            at [q][lane]
+constexpr int kTwWC = 1536;    // [8][64]  forward pass C      w(2 r lane)               at [r][lane]
+constexpr int kTwW2 = 2048;    // [16][16] inverse inter-stage w(4 i m)                  at [m][i]
+constexpr int kTwWB = 2304;    // [8][8]   forward pass B      w(16 r k)                 at [r][k]
+constexpr int kTwPack = 2368;  // float2 entries (18 944 B)
 
 struct ItemDesc {
     int rows_new[4];

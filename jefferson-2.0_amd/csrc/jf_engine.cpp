@@ -51,6 +51,7 @@ struct jf_engine {
 
     float4 *d_htab = nullptr;
     float2 *d_tw = nullptr;
+    float2 *d_twpack = nullptr;
     SrcSignal *d_sigs = nullptr;
     float *d_zero = nullptr;  // PAD_LEN zeros: the "signal" of a source without one
     SrcState *d_state[2] = {nullptr, nullptr};
@@ -162,7 +163,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     }
     FusedParams P;
     P.htab = e->d_htab;
-    P.tw = e->d_tw;
+    P.tw = e->d_twpack;
     P.desc = e->d_desc;
     P.sigs = e->rv_P > 0 ? e->d_sigs_wet : e->d_sigs;
     P.st_in = e->d_state[p];
@@ -240,6 +241,7 @@ void destroy_engine(jf_engine *e) {
         if (p) (void)hipFree(p);
     (void)hipFree(e->d_htab);
     (void)hipFree(e->d_tw);
+    (void)hipFree(e->d_twpack);
     (void)hipFree(e->d_sigs);
     (void)hipFree(e->d_zero);
     for (int i = 0; i < 2; i++) {
@@ -320,13 +322,27 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             tw[j] = make_float2((float)cos(a), (float)sin(a));
         }
         JF_HIP(e, hipMemcpy(e->d_tw, tw.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
+        // the same values re-laid per FFT pass (jf_device.h kTw*)
+        std::vector<float2> pack(kTwPack);
+        for (int lane = 0; lane < 64; lane++) {
+            const int a = lane & 3, i = lane >> 2;
+            for (int t = 0; t < 16; t++) pack[kTwW3 + 64 * t + lane] = tw[(a * (i + 16 * t) + 768 * a) & 1023];
+            for (int q = 0; q < 8; q++) pack[kTwU + 64 * q + lane] = tw[lane + 64 * q];
+            for (int r = 0; r < 8; r++) pack[kTwWC + 64 * r + lane] = tw[(2 * r * lane) & 1023];
+        }
+        for (int m = 0; m < 16; m++)
+            for (int i = 0; i < 16; i++) pack[kTwW2 + 16 * m + i] = tw[(4 * i * m) & 1023];
+        for (int r = 0; r < 8; r++)
+            for (int k = 0; k < 8; k++) pack[kTwWB + 8 * r + k] = tw[(16 * r * k) & 1023];
+        JF_HIP(e, hipMalloc(&e->d_twpack, sizeof(float2) * kTwPack));
+        JF_HIP(e, hipMemcpy(e->d_twpack, pack.data(), sizeof(float2) * kTwPack, hipMemcpyHostToDevice));
 
         // HRTF spectra on the GPU (read_hrtf_signals + transform_hrtfs)
         float *d_hrir = nullptr;
         const size_t hb = sizeof(float) * kNumHrtf * 2 * (size_t)taps;
         JF_HIP(e, hipMalloc(&d_hrir, hb));
         hipError_t s1 = hipMemcpy(d_hrir, hrir, hb, hipMemcpyHostToDevice);
-        hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_tw, e->d_htab, e->stream) : s1;
+        hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_twpack, e->d_htab, e->stream) : s1;
         hipError_t s3 = s2 == hipSuccess ? hipStreamSynchronize(e->stream) : s2;
         (void)hipFree(d_hrir);
         JF_HIP(e, s3);
@@ -748,7 +764,7 @@ int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spect
         JF_HIP(e, hipMalloc(&d_w, sizeof(float) * (size_t)n * kN));
         JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * kNc));
         JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
-        JF_HIP(e, launch_rfft_debug(d_w, n, e->d_tw, d_s, e->stream));
+        JF_HIP(e, launch_rfft_debug(d_w, n, e->d_twpack, d_s, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(spectra, d_s, sizeof(float2) * (size_t)n * kNc, hipMemcpyDeviceToHost));
         return JF_OK;

@@ -154,7 +154,7 @@ JF_DEV float quad_sum(float v) {
 // In : z[r] = (x[2(lane+64r)], x[2(lane+64r)+1]), r = 0..7
 // Out: X[q] = bin (lane + 64 q), q = 0..7, UNNORMALISED; on lane 0, X[0] is
 //      packed as (X[0].re, X[512].re) (both bins are real).
-// buf: >= 576 float2 of this wave's LDS; tw: exp(+2 pi i j/1024) in LDS.
+// buf: >= 576 float2 of this wave's LDS; tw: the twiddle pack (jf_device.h) in LDS.
 JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const float2 *tw, int lane) {
     // pass A (sub-length 1): no twiddles; store 8 contiguous, row padded 8 -> 9
     fft8<-1>(z);
@@ -169,7 +169,7 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
         for (int r = 0; r < 8; r++) u[r] = buf[base + 72 * r];
         const int k = lane & 7;
 #pragma unroll
-        for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[(16 * r * k) & 1023]);
+        for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[kTwWB + 8 * r + k]);
         fft8<-1>(u);
         JF_WAVE_LDS_SYNC();
         const int wbase = 72 * (lane >> 3) + k;
@@ -181,7 +181,7 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
 #pragma unroll
     for (int r = 0; r < 8; r++) u[r] = buf[lane + 72 * r];
 #pragma unroll
-    for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[(2 * r * lane) & 1023]);
+    for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[kTwWC + 64 * r + lane]);
     fft8<-1>(u);
     JF_WAVE_LDS_SYNC();
     // split: X[k] = E + (-i) W^k O, E = (Z[k] + conj Z[512-k])/2, O = (Z[k] - conj Z[512-k])/2
@@ -194,8 +194,8 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
         const float2 zk = u[q];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-        // (-i) * conj(tw[k]) * o
-        const float2 wo = cmulc(o, tw[lane + 64 * q]);
+        // (-i) * conj(W^k) * o
+        const float2 wo = cmulc(o, tw[kTwU + 64 * q + lane]);
         X[q] = make_float2(e.x + wo.y, e.y - wo.x);
     }
     // lane 0: bins 0 and 512 are real: Re(Z0) +/- Im(Z0)
@@ -212,7 +212,7 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
     // lane (i, a) holds S_a[i + 16 r] = Z[4 (i + 16 r) + a]: 16-point inverse over r
     fft16<+1>(v);
 #pragma unroll
-    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tw[(4 * i * m) & 1023]);
+    for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tw[kTwW2 + 16 * m + i]);
     // exchange inside each group a: write rows m (padded 64 -> 68), read columns
 #pragma unroll
     for (int m = 0; m < 16; m++) buf[68 * m + lane] = v[m];
@@ -224,7 +224,7 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
     // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-        const float2 w = tw[(a * (i + 16 * t) + 768 * a) & 1023];
+        const float2 w = tw[kTwW3 + 64 * t + lane];
         const float2 p = cmul(v[t], w);
         v[t] = make_float2(quad_sum(p.x), quad_sum(p.y));
     }
@@ -339,10 +339,10 @@ template <int NOUT>  // B / 64
 #define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg)
 #endif
 __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
-    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[kWavesPerWg * kWaveLds];
     const int tid = threadIdx.x;
-    for (int j = tid; j < 1024; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
     __syncthreads();
 
     const int lane = tid & 63;
@@ -647,10 +647,10 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
 __global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict__ hrir, int taps,
                                                         const float2 *__restrict__ twg,
                                                         float4 *__restrict__ htab) {
-    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[576];
     const int lane = threadIdx.x;
-    for (int j = lane; j < 1024; j += 64) s_tw[j] = twg[j];
+    for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
     __syncthreads();
     const int row = blockIdx.x;
     float2 Xe[2][8];
@@ -675,10 +675,10 @@ __global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict
 __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict__ win,
                                                        const float2 *__restrict__ twg,
                                                        float2 *__restrict__ spec) {
-    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[576];
     const int lane = threadIdx.x;
-    for (int j = lane; j < 1024; j += 64) s_tw[j] = twg[j];
+    for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
     __syncthreads();
     const float *x = win + (size_t)blockIdx.x * kN;
     float2 z[8], X[8];
