@@ -347,11 +347,13 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = blockIdx.x * kWavesPerWg + wave;
     const int n_items = P.K * P.S;
-    if (item >= n_items) return;
     float2 *buf = s_buf + wave * kWaveLds;
     constexpr int B = 64 * NOUT;
+    // Persistent workgroups: the grid is sized to the machine (launch_fused), the twiddle pack
+    // is staged once, and every wave strides over the (block, source) items.
+#pragma unroll 1
+    for (int item = blockIdx.x * kWavesPerWg + wave; item < n_items; item += gridDim.x * kWavesPerWg) {
     const int b = item / P.S;
     const int s = item - b * P.S;
 
@@ -419,8 +421,8 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     const int a = lane & 3, i = lane >> 2;
     if (n_new <= 0) {  // not interpolable: silence (the reference has no defined output here)
 #pragma unroll
-        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j) - 0] = make_float2(0.f, 0.f);
-        return;
+        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = make_float2(0.f, 0.f);
+        continue;
     }
 
     // ---- forward FFT, 1/N scale (GPUSoundSource.cu:344-346), times D[k]
@@ -469,6 +471,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
             }
         }
     }
+    }  // item loop
 }
 
 // ---------------------------------------------------------------- mixing --
@@ -726,7 +729,22 @@ hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *
 
 hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
     const int n_items = P.K * P.S;
-    const dim3 grid((n_items + kWavesPerWg - 1) / kWavesPerWg), block(64 * kWavesPerWg);
+    // one workgroup per CU slot the kernel can occupy (LDS-bound: 1 x 16 waves, 3 x 4 waves, ...)
+    static int max_wgs = 0;
+    if (max_wgs == 0) {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        const int lds_per_wg = (kTwPack + kWavesPerWg * 1088) * (int)sizeof(float2);
+        int per_cu = (160 * 1024) / lds_per_wg;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * kWavesPerWg > 16) per_cu = (16 / kWavesPerWg) > 0 ? 16 / kWavesPerWg : 1;
+        max_wgs = cus * per_cu;
+    }
+    int wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
+    if (wgs > max_wgs) wgs = max_wgs;
+    const dim3 grid(wgs), block(64 * kWavesPerWg);
     switch (P.B / 64) {
     case 1: hipLaunchKernelGGL(fused_block_kernel<1>, grid, block, 0, st, P); break;
     case 2: hipLaunchKernelGGL(fused_block_kernel<2>, grid, block, 0, st, P); break;
