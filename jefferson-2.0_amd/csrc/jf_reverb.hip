@@ -130,12 +130,14 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
 }
 
 // ---------------------------------------------------------------- stage B --
-// One workgroup (4 waves) per (block k, source s): the 4 waves split the P partitions,
-// each lane owns B/64 consecutive bins; LDS reduce; wave 0 inverts and writes the wet block.
+// One workgroup (16 waves) per (block k, source s): the waves split the P partitions (so that a
+// real-time call with K*S ~ #CUs still puts 16 waves of loads in flight on every CU), each lane
+// owns B/64 consecutive bins; LDS reduce; wave 0 inverts and writes the wet block.
+constexpr int kMacWaves = 16;
 template <int B>
-__global__ __launch_bounds__(256) void reverb_mac_kernel(const ReverbParams P) {
+__global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const ReverbParams P) {
     constexpr int NB = B / 64;
-    __shared__ float2 s_red[4][B];
+    __shared__ float2 s_red[kMacWaves][B];
     __shared__ float2 s_fft[2 * B];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(256) void reverb_mac_kernel(const ReverbParams P) {
     for (int i = 0; i < NB; i++) acc[i] = make_float2(0.f, 0.f);
     int slot = (P.head + k - wave) % P.Rg;
     if (slot < 0) slot += P.Rg;
-#pragma unroll 2
-    for (int p = wave; p < P.P; p += 4) {
+#pragma unroll 4
+    for (int p = wave; p < P.P; p += kMacWaves) {
         float2 x[NB], h[NB];
         const float2 *xp = fdl + (size_t)slot * B;
         const float2 *hp = hs + (size_t)p * B;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void reverb_mac_kernel(const ReverbParams P) {
         }
         acc0.x += x[0].x * h[0].x;
         acc0.y += x[0].y * h[0].y;
-        slot -= 4;
+        slot -= kMacWaves;
         if (slot < 0) slot += P.Rg;
     }
     if (lane == 0) acc[0] = acc0;
@@ -186,8 +188,12 @@ __global__ __launch_bounds__(256) void reverb_mac_kernel(const ReverbParams P) {
 
     // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
     float2 *ybuf = s_fft, *zbuf = s_fft + B;
-    for (int q = lane; q < B; q += 64)
-        ybuf[q] = rv_add(rv_add(s_red[0][q], s_red[1][q]), rv_add(s_red[2][q], s_red[3][q]));
+    for (int q = lane; q < B; q += 64) {
+        float2 acc = s_red[0][q];
+#pragma unroll
+        for (int w = 1; w < kMacWaves; w++) acc = rv_add(acc, s_red[w][q]);
+        ybuf[q] = acc;
+    }
     JF_RV_SYNC();
     for (int q = lane; q < B; q += 64) {
         const float2 yk = ybuf[q];
@@ -259,19 +265,19 @@ hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float sca
 }
 
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
-    const dim3 ga((P.K * P.S + 3) / 4), gb(P.K * P.S), blk(256);
+    const dim3 ga((P.K * P.S + 3) / 4), gb(P.K * P.S), blk(256), blkb(64 * kMacWaves);
     switch (P.B) {
     case 64:
         hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<64>, gb, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<64>, gb, blkb, 0, st, P);
         break;
     case 128:
         hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<128>, gb, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<128>, gb, blkb, 0, st, P);
         break;
     case 256:
         hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<256>, gb, blk, 0, st, P);
+        hipLaunchKernelGGL(reverb_mac_kernel<256>, gb, blkb, 0, st, P);
         break;
     default: return hipErrorInvalidValue;
     }
