@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 B = 256
 SOURCES_PER_GPU = 1024
-BLOCKS_PER_STEP = 64
+BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "64"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
