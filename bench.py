@@ -119,6 +119,8 @@ def main():
     eng = jf.Engine(B, 512, S, hrir=hrir, device=local_rank, max_batch_blocks=KB)
     for s, sid in enumerate(src_ids):
         eng.set_signal(s, wl.source_signal_and_start(sid)[0])
+    if os.environ.get("JF_SOURCE_GROUP"):
+        eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
     if ir is not None:
         eng.set_reverb(ir, 0.5)
     pos = wl.trajectories(jf, src_ids, total_blocks, moving=not args.stationary)

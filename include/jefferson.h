@@ -196,7 +196,8 @@ int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix);
 int jf_synchronize(jf_engine *e);
 /* Device pointers owned by the engine (valid until destroy). */
 float *jf_batch_mix_device(jf_engine *e);     /* [max_batch_blocks][2*B] */
-float *jf_batch_partial_device(jf_engine *e); /* [max_batch_blocks][n_sources][2*B], per-source blocks of the last run */
+float *jf_batch_partial_device(jf_engine *e); /* [blocks][n_sources / G][2*B]: stereo blocks of the last run, summed over
+                                                 groups of G consecutive sources (jf_debug_set_source_group) */
 /* hipStream_t the engine launches on, as void*. */
 void *jf_engine_stream(jf_engine *e);
 
@@ -208,6 +209,13 @@ int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix
 int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb kernels, same launches */
 
 /* ---- debugging / parity taps ------------------------------------------ */
+
+/* Sources one wavefront processes back to back and sums in registers before writing a stereo block
+ * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (4 for large batches);
+ * must divide n_sources.  The mix is the same sum in a different association. */
+int jf_debug_set_source_group(jf_engine *e, int group);
+/* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
+int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
 /* Copy of the device HRTF spectrum table in the REFERENCE layout
  * fft_hrtf[(j*2 + ear)*Nc + k] (hrtf_signals.cu:90-98), complex64 -> 2 floats. */

@@ -74,6 +74,8 @@ _SIGS = {
     "jf_reverb_set_ir": (C.c_int, [C.c_void_p, _f, C.c_size_t, C.c_float]),
     "jf_reverb_rms_gain": (C.c_float, [_f, C.c_size_t, _f, C.c_size_t]),
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
     "jf_debug_rfft_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
@@ -292,6 +294,14 @@ class Engine:
         r = C.c_double()
         self._chk(lib().jf_profile_read_reverb(self.h, C.byref(r)))
         return r.value
+
+    def set_source_group(self, g):
+        self._chk(lib().jf_debug_set_source_group(self.h, int(g)))
+
+    def read_device(self, ptr, shape):
+        out = np.zeros(shape, np.float32)
+        self._chk(lib().jf_debug_copy_from_device(self.h, ptr, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
 
     def read_table(self):
         t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)

@@ -15,7 +15,8 @@
 //   state  SrcState[2][S]     count / old_ele / old_azi (ping-pong per call).
 //   pos    float[K][S][5]     latched positions {ele, azi, x, y, z} per block.
 //   desc   ItemDesc[K][S]     per (block, source) rows/weights/distance terms.
-//   partial float[K][S][2B]   per-source stereo blocks (reference: intermediate).
+//   partial float[K][S/G][2B] stereo blocks of groups of G consecutive sources (G = 1: the
+//                             reference's per-source `intermediate`).
 //   mix    float[K][2B]       sum over sources in source order.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -93,8 +94,9 @@ struct FusedParams {
     const float *hist_in;   // [S][1024]
     float *hist_out;        // [S][1024]
     const float *pos;       // [K][S][5] (window of the uploaded trajectory)
-    float *partial;         // [K][S][2B]
+    float *partial;         // [K][S/G][2B]
     int S, K, B;
+    int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
 };
 
 // Convolution reverb stage (jf_reverb.hip): uniformly partitioned overlap-save with a

@@ -63,6 +63,7 @@ struct jf_engine {
     float *d_traj = nullptr;    // [total][S][5]
     int traj_blocks = 0;
     int cur = 0;  // parity of the valid state/history
+    int src_group = 0;  // 0 = automatic
 
     std::vector<float *> d_signal;  // per source
     std::vector<SrcSignal> h_sigs;
@@ -175,11 +176,14 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     P.S = e->S;
     P.K = K;
     P.B = e->B;
+    // sources summed in registers per wavefront: fewer, larger partial blocks for the mix kernel
+    const int G = e->src_group > 0 ? e->src_group : ((e->S % 4 == 0 && (long long)K * e->S >= 16384) ? 4 : 1);
+    P.G = (e->S % G == 0) ? G : 1;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
     if (em) JF_HIP(e, hipEventRecord(em->a, e->stream));
-    JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S, K, e->B, e->stream));
+    JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
     if (em) JF_HIP(e, hipEventRecord(em->b, e->stream));
     if (e->profiling) e->ev_used++;
     e->cur = p ^ 1;
@@ -700,6 +704,19 @@ int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix
 }
 
 // ---- debugging taps -----------------------------------------------------------
+int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes) {
+    if (!e || !device_ptr || !host) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    JF_HIP(e, hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost));
+    return JF_OK;
+}
+
+int jf_debug_set_source_group(jf_engine *e, int group) {
+    if (!e || group < 0 || (group > 0 && e->S % group)) return JF_ERR_ARG;
+    e->src_group = group;
+    return JF_OK;
+}
+
 int jf_debug_read_table(jf_engine *e, float *out) {
     if (!e || !out) return JF_ERR_ARG;
     std::vector<float4> h((size_t)kNumHrtf * 512);

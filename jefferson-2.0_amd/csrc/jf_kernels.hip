@@ -347,15 +347,26 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_items = P.K * P.S;
     float2 *buf = s_buf + wave * kWaveLds;
     constexpr int B = 64 * NOUT;
     // Persistent workgroups: the grid is sized to the machine (launch_fused), the twiddle pack
-    // is staged once, and every wave strides over the (block, source) items.
+    // is staged once, and every wave strides over the work units.  A unit = one block of G
+    // consecutive sources, processed one after the other and summed in source order in
+    // registers, so only one stereo block per group is written (G = 1: per-source blocks).
+    const int G = P.G, SG = P.S / G;
+    const int n_units = P.K * SG;
+    const int a = lane & 3, i = lane >> 2;
 #pragma unroll 1
-    for (int item = blockIdx.x * kWavesPerWg + wave; item < n_items; item += gridDim.x * kWavesPerWg) {
-    const int b = item / P.S;
-    const int s = item - b * P.S;
+    for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+    const int b = unit / SG;
+    const int s0 = (unit - b * SG) * G;
+    float2 acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+    const int s = s0 + g;
+    const int item = b * P.S + s;
 
     // ---- descriptor (wave-uniform -> scalar loads)
     const ItemDesc *dp = P.desc + item;
@@ -417,13 +428,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         }
     }
 
-    float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)item * B;
-    const int a = lane & 3, i = lane >> 2;
-    if (n_new <= 0) {  // not interpolable: silence (the reference has no defined output here)
-#pragma unroll
-        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = make_float2(0.f, 0.f);
-        continue;
-    }
+    if (n_new <= 0) continue;  // not interpolable: silence (the reference has no defined output here)
 
     // ---- forward FFT, 1/N scale (GPUSoundSource.cu:344-346), times D[k]
     float2 xd[8];
@@ -467,11 +472,15 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
                     r1 = make_float2(res[j].x * (1.0f - fn) + r1.x * fn,
                                      res[j].y * (1.0f - fn) + r1.y * fn);
                 }
-                out[n_out] = r1;
+                acc[j] = cadd(acc[j], r1);
             }
         }
     }
-    }  // item loop
+    }  // sources of the group
+    float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = acc[j];
+    }  // unit loop
 }
 
 // ---------------------------------------------------------------- mixing --
@@ -728,7 +737,8 @@ hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *
 }
 
 hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
-    const int n_items = P.K * P.S;
+    if (P.G <= 0 || P.S % P.G) return hipErrorInvalidValue;
+    const int n_items = P.K * (P.S / P.G);
     // one workgroup per CU slot the kernel can occupy (LDS-bound: 1 x 16 waves, 3 x 4 waves, ...)
     static int max_wgs = 0;
     if (max_wgs == 0) {

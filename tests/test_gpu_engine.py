@@ -180,28 +180,20 @@ def test_full_size_moving_workload_properties(jf, hrir):
     """BASELINE.json configs[2] at full width (1024 moving sources, B = 256): the oracle is too
     slow to replay it all in a test, so check (1) a sample of sources against the oracle,
     (2) mix == ordered sum of the per-source blocks, (3) linearity in the signals."""
-    import ctypes
     wl = _workload()
     S, K, B = 1024, 8, 256
     ids = np.arange(S)
     pos = wl.trajectories(jf, ids, K)
     sigs = [wl.source_signal_and_start(s, 4096)[0] for s in ids]
     e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    e.set_source_group(1)   # per-source blocks (the reference's `intermediate`) for check (1)
     for s in ids:
         e.set_signal(int(s), sigs[s])
     e.upload_positions(pos)
     e.batch_run(0, K)
     e.synchronize()
-    import torch
-    n_part = K * S * 2 * B
-    part = torch.empty(n_part, dtype=torch.float32)
-    mix = torch.empty(K * 2 * B, dtype=torch.float32)
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    assert hip.hipMemcpy(part.data_ptr(), e.partial_device_ptr(), n_part * 4, 2) == 0
-    assert hip.hipMemcpy(mix.data_ptr(), e.mix_device_ptr(), K * 2 * B * 4, 2) == 0
-    part = part.numpy().reshape(K, S, 2 * B)
-    mix = mix.numpy().reshape(K, 2 * B)
+    part = e.read_device(e.partial_device_ptr(), (K, S, 2 * B))
+    mix = e.read_device(e.mix_device_ptr(), (K, 2 * B))
     e.close()
 
     # (1) sampled sources vs the float64 model
@@ -225,11 +217,31 @@ def test_full_size_moving_workload_properties(jf, hrir):
 
     # (3) linearity: halving every signal halves the mix (exact in float: powers of two)
     e2 = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    e2.set_source_group(1)
     for s in ids:
         e2.set_signal(int(s), (0.5 * sigs[s]).astype(np.float32))
     half = e2.process_batch(pos)
     e2.close()
     assert np.array_equal(half, (0.5 * mix).astype(np.float32))
+
+    # (4) the default grouping (4 consecutive sources summed in registers per wavefront) is the same
+    # sum in another association: groups of 4 in source order, 16 mix groups of 16 partials, in order
+    e3 = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    e3.set_source_group(4)
+    for s in ids:
+        e3.set_signal(int(s), sigs[s])
+    grouped = e3.process_batch(pos)
+    e3.close()
+    g4 = np.zeros((K, S // 4, 2 * B), np.float32)
+    for j in range(4):
+        g4 = g4 + part[:, j::4] if j == 0 else g4 + part[:, j::4]
+    acc = np.zeros((K, 2 * B), np.float32)
+    for g in range(16):
+        gsum = np.zeros((K, 2 * B), np.float32)
+        for u in range(16 * g, 16 * (g + 1)):
+            gsum = gsum + g4[:, u]
+        acc = gsum if g == 0 else acc + gsum
+    assert np.array_equal(grouped, acc)
 
 
 def _write_compact_dir(root, hrir):
