@@ -201,9 +201,10 @@ float *jf_batch_partial_device(jf_engine *e); /* [blocks][n_sources / G][2*B]: s
 /* hipStream_t the engine launches on, as void*. */
 void *jf_engine_stream(jf_engine *e);
 
-/* Timing of the fused kernel inside jf_batch_run with HIP events recorded on
- * the engine's stream.  enable != 0 arms it; jf_profile_read waits and returns
- * the accumulated milliseconds and launch count since arming. */
+/* Timing with HIP events recorded on the engine's stream.  enable = 1 brackets the fused kernel
+ * only (two events per call: what bench.py needs for the roofline), 2 brackets every kernel (prep,
+ * reverb, fused, mix), 0 switches it off; jf_profile_read waits and returns the accumulated
+ * milliseconds and launch count since arming (prep/mix are 0 at level 1). */
 int jf_profile_enable(jf_engine *e, int enable);
 int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches);
 int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb kernels, same launches */

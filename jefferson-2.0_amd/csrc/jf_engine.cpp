@@ -77,7 +77,7 @@ struct jf_engine {
     bool in_flight = false;         // a submitted block not yet collected
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 = time the fused kernel only (2 events per call), 2 = every kernel
     std::vector<EventPair> ev_prep, ev_fused, ev_mix, ev_reverb;
     size_t ev_used = 0;
 
@@ -124,10 +124,13 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
     if (e->profiling) {
-        ep = next_events(e, e->ev_prep);
         ef = next_events(e, e->ev_fused);
+        if (!ef) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
+    }
+    if (e->profiling >= 2) {
+        ep = next_events(e, e->ev_prep);
         em = next_events(e, e->ev_mix);
-        if (!ep || !ef || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
+        if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
     JF_HIP(e, launch_prep(ring_table(), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
@@ -135,7 +138,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     if (e->rv_P > 0) {
         // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring (this call's K blocks)
         EventPair *er = nullptr;
-        if (e->profiling) {
+        if (e->profiling >= 2) {
             er = next_events(e, e->ev_reverb);
             if (!er) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
             JF_HIP(e, hipEventRecord(er->a, e->stream));
@@ -615,7 +618,7 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
     if (!e || !reverb_ms) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     double r = 0;
-    for (size_t i = 0; i < e->ev_used && i < e->ev_reverb.size(); i++) {
+    for (size_t i = 0; e->profiling >= 2 && e->rv_P > 0 && i < e->ev_used && i < e->ev_reverb.size(); i++) {
         float ms = 0;
         JF_HIP(e, hipEventElapsedTime(&ms, e->ev_reverb[i].a, e->ev_reverb[i].b));
         r += ms;
@@ -678,7 +681,7 @@ void *jf_engine_stream(jf_engine *e) { return e ? (void *)e->stream : nullptr; }
 int jf_profile_enable(jf_engine *e, int enable) {
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
-    e->profiling = enable != 0;
+    e->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     e->ev_used = 0;
     return JF_OK;
 }
@@ -691,10 +694,12 @@ int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix
         float ms = 0;
         JF_HIP(e, hipEventElapsedTime(&ms, e->ev_fused[i].a, e->ev_fused[i].b));
         f += ms;
-        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_prep[i].a, e->ev_prep[i].b));
-        p += ms;
-        JF_HIP(e, hipEventElapsedTime(&ms, e->ev_mix[i].a, e->ev_mix[i].b));
-        m += ms;
+        if (e->profiling >= 2) {
+            JF_HIP(e, hipEventElapsedTime(&ms, e->ev_prep[i].a, e->ev_prep[i].b));
+            p += ms;
+            JF_HIP(e, hipEventElapsedTime(&ms, e->ev_mix[i].a, e->ev_mix[i].b));
+            m += ms;
+        }
     }
     if (fused_ms) *fused_ms = f;
     if (prep_ms) *prep_ms = p;
