@@ -126,20 +126,32 @@ def main():
     pos = wl.trajectories(jf, src_ids, total_blocks, moving=not args.stationary)
     eng.upload_positions(pos)
 
-    # the mix lands in a torch tensor so that RCCL can reduce it in place
-    mix = torch.zeros((KB, 2 * B), dtype=torch.float32, device="cuda")
+    # The mix lands in a torch tensor so that RCCL can reduce it in place.  Two buffers: the
+    # (latency-bound, K * 2 KB) reduce of step i runs on RCCL's stream while the engine's stream
+    # already computes step i + 1; a buffer is reused only after its reduce has completed.
+    mixes = [torch.zeros((KB, 2 * B), dtype=torch.float32, device="cuda") for _ in range(2)]
+    pending = [None, None]
     ext = torch.cuda.ExternalStream(eng.stream_ptr())
 
     def step(i):
-        eng.batch_run(i * KB, KB, mix.data_ptr())
-        if world > 1:
+        j = i & 1
+        if pending[j] is not None:
             with torch.cuda.stream(ext):
+                pending[j].wait()  # stream-level wait: the engine stream must not overwrite mixes[j] early
+            pending[j] = None
+        eng.batch_run(i * KB, KB, mixes[j].data_ptr())
+        if world > 1:
+            with torch.cuda.stream(ext):  # the collective is ordered after the kernels just enqueued
                 if backend == "nccl":
-                    dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: K * 2 KB per GPU
+                    pending[j] = dist.reduce(mixes[j], dst=0, op=dist.ReduceOp.SUM, async_op=True)
                 else:
-                    dist.all_reduce(mix, op=dist.ReduceOp.SUM)     # gloo has no GPU reduce
+                    pending[j] = dist.all_reduce(mixes[j], op=dist.ReduceOp.SUM, async_op=True)  # gloo: no GPU reduce
 
     def fence():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
         eng.synchronize()
         torch.cuda.synchronize()
         if world > 1:
