@@ -187,7 +187,7 @@ def main():
         achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and ir is None and not args.stationary:  # measured for this workload only
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
