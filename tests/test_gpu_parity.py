@@ -157,3 +157,35 @@ def test_multi_source_mix_vs_oracle(jf, hrir, castanets):
     eng.close()
     assert np.abs(mix - mix64).max() <= TOL64 * 2  # six sources summed
     assert np.abs(mix - mix32).max() <= TOL32 * 2
+
+
+@pytest.mark.parametrize("B", [128, 256])
+def test_full_benchmark_testing_harness(jf, hrir, castanets, B):
+    """BASELINE.json configs[0]/[1]: the reference's complete end-to-end harness, not a short form:
+    benchmarkTesting (precision_test.cu:2154-2201) = 4 start positions x (172 blocks per position,
+    azimuth + 5 degrees x 72 rounds) = 4 x 12 556 blocks, default input looped, r = 0.5.  The HIP
+    path (batched through the C ABI) against the float32 C oracle over EVERY block, and against the
+    float64 model over the first 3 positions of each scenario."""
+    n_dwell, n_rounds = 172, 72
+    worst32 = worst64 = 0.0
+    for name, (azi0, ele0) in SCENARIOS.items():
+        traj = scenario_positions(azi0, ele0, n_dwell, n_rounds)
+        pos = np.stack([jf.position_from_spherical(e, a, r) for (e, a, r) in traj])[:, None, :]
+        eng = jf.Engine(B, 512, 1, hrir=hrir, max_batch_blocks=512)
+        ora = oracle_lib.Engine(B, 512, 1, hrir)
+        for x in (eng, ora):
+            x.set_signal(0, castanets)
+            x.reset(0)
+        got = eng.process_batch(pos)
+        want = ora.process_batch(pos, n_threads=1)
+        eng.close()
+        assert got.shape == (n_dwell * (n_rounds + 1), 2 * B)
+        worst32 = max(worst32, float(np.abs(got - want).max()))
+        mod = model64.Model(B, 512, 1, hrir)
+        mod.set_signal(0, castanets)
+        mod.reset(0)
+        m64, _ = mod.process_batch(pos[: 3 * n_dwell])
+        worst64 = max(worst64, float(np.abs(got[: 3 * n_dwell] - m64).max()))
+    print(f"B={B}: max|hip-oracle32| = {worst32:.3e}, max|hip-model64| = {worst64:.3e}")
+    assert worst32 <= TOL32
+    assert worst64 <= TOL64
