@@ -215,6 +215,10 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb k
  * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (4 for large batches);
  * must divide n_sources.  The mix is the same sum in a different association. */
 int jf_debug_set_source_group(jf_engine *e, int group);
+/* Per-block calls (jf_process_block / jf_submit_block / jf_callback) with at most n sources use the
+ * one-launch real-time kernel (descriptors + spatialisation + mix in one workgroup, pinned host I/O);
+ * above that, the batch pipeline with one block.  Default 16; 0 disables the real-time kernel. */
+int jf_debug_set_rt_max_sources(jf_engine *e, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 

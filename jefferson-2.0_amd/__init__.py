@@ -76,6 +76,7 @@ _SIGS = {
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "jf_debug_set_rt_max_sources": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
     "jf_debug_rfft_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
@@ -302,6 +303,9 @@ class Engine:
         out = np.zeros(shape, np.float32)
         self._chk(lib().jf_debug_copy_from_device(self.h, ptr, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
+
+    def set_rt_max_sources(self, n):
+        self._chk(lib().jf_debug_set_rt_max_sources(self.h, int(n)))
 
     def read_table(self):
         t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)

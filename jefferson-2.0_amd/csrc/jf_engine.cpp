@@ -24,6 +24,7 @@ hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *
                        int K, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st);
@@ -72,8 +73,10 @@ struct jf_engine {
     std::vector<HostPos> pos;
     bool paused = false;
 
-    float *h_pos_pinned = nullptr;  // [S][5]
-    float *h_out_pinned = nullptr;  // [2B]
+    float *h_pos_pinned = nullptr;  // [S][5]   pinned + mapped: the real-time kernel reads it in place
+    float *h_out_pinned = nullptr;  // [2B]     pinned + mapped: ... and writes the stereo block in place
+    float *hd_pos = nullptr, *hd_out = nullptr;  // their device addresses
+    int rt_max_sources = 16;        // per-block calls with at most this many sources take the one-launch path
     bool in_flight = false;         // a submitted block not yet collected
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
@@ -312,8 +315,10 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
-        JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5));
-        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B));
+        JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5, hipHostMallocMapped));
+        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B, hipHostMallocMapped));
+        JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
+        JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
         e->d_signal.assign(S, nullptr);
         JF_HIP(e, hipMalloc(&e->d_zero, sizeof(float) * kN));
         JF_HIP(e, hipMemset(e->d_zero, 0, sizeof(float) * kN));
@@ -503,6 +508,30 @@ int jf_submit_block(jf_engine *e) {
         JF_HIP(e, hipMemsetAsync(e->d_mix, 0, sizeof(float) * 2 * e->B, e->stream));
     } else {
         snapshot_positions(e, e->h_pos_pinned);
+        if (e->S <= e->rt_max_sources && e->rv_P == 0 && !e->profiling) {
+            // few sources: ONE launch does descriptors, spatialisation and mix, reading the positions
+            // from and writing the stereo block to pinned host memory -- no copies, one sync
+            const int p = e->cur;
+            FusedParams P;
+            P.htab = e->d_htab;
+            P.tw = e->d_twpack;
+            P.desc = nullptr;
+            P.sigs = e->d_sigs;
+            P.st_in = e->d_state[p];
+            P.st_out = e->d_state[p ^ 1];
+            P.hist_in = e->d_hist[p];
+            P.hist_out = e->d_hist[p ^ 1];
+            P.pos = e->hd_pos;
+            P.partial = nullptr;
+            P.S = e->S;
+            P.K = 1;
+            P.B = e->B;
+            P.G = 1;
+            JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, e->stream));
+            e->cur = p ^ 1;
+            e->in_flight = true;
+            return JF_OK;
+        }
         JF_HIP(e, hipMemcpyAsync(e->d_pos_rt, e->h_pos_pinned, sizeof(float) * 5 * e->S, hipMemcpyHostToDevice,
                                  e->stream));
         int rc = run_blocks(e, e->d_pos_rt, 1, e->d_mix);
@@ -713,6 +742,12 @@ int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, 
     if (!e || !device_ptr || !host) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     JF_HIP(e, hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost));
+    return JF_OK;
+}
+
+int jf_debug_set_rt_max_sources(jf_engine *e, int n) {
+    if (!e || n < 0) return JF_ERR_ARG;
+    e->rt_max_sources = n;
     return JF_OK;
 }
 

@@ -332,44 +332,16 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
 // ------------------------------------------------------------ fused kernel --
 constexpr int kWaveLds = 1088;  // float2 per wave (8704 B): inverse exchange; forward uses 576
 
-template <int NOUT>  // B / 64
-#if JF_MIN_WAVES > 0
-#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg, JF_MIN_WAVES)
-#else
-#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg)
-#endif
-__global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
-    __shared__ float2 s_tw[kTwPack];
-    __shared__ float2 s_buf[kWavesPerWg * kWaveLds];
-    const int tid = threadIdx.x;
-    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *buf = s_buf + wave * kWaveLds;
+// One (block b, source s) work item by one wavefront: everything from the window gather to the
+// crossfaded stereo frames, which are ADDED to acc (B/64 frames per lane: frame i + 16 (NOUT a + j),
+// lane = 4 i + a).  dp: this item's descriptor (global memory in the batch kernel, LDS in the
+// real-time kernel); pos_rec: its latched position record.  buf: this wave's LDS; s_tw: twiddle pack.
+template <int NOUT>
+JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
+                            float2 *buf, const float2 *s_tw, int lane, float2 (&acc)[NOUT]) {
     constexpr int B = 64 * NOUT;
-    // Persistent workgroups: the grid is sized to the machine (launch_fused), the twiddle pack
-    // is staged once, and every wave strides over the work units.  A unit = one block of G
-    // consecutive sources, processed one after the other and summed in source order in
-    // registers, so only one stereo block per group is written (G = 1: per-source blocks).
-    const int G = P.G, SG = P.S / G;
-    const int n_units = P.K * SG;
     const int a = lane & 3, i = lane >> 2;
-#pragma unroll 1
-    for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
-    const int b = unit / SG;
-    const int s0 = (unit - b * SG) * G;
-    float2 acc[NOUT];
-#pragma unroll
-    for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-    const int s = s0 + g;
-    const int item = b * P.S + s;
-
     // ---- descriptor (wave-uniform -> scalar loads)
-    const ItemDesc *dp = P.desc + item;
     const int n_new = dp->n_new;
     const int n_old = dp->n_old;
     const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
@@ -420,7 +392,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         if (lane == 0) {
             SrcState st;
             st.count = (int)(((long long)count0 + (long long)P.K * B) % L);
-            const float *pp = P.pos + (size_t)item * 5;
+            const float *pp = pos_rec;
             st.old_ele = pp[0];
             st.old_azi = pp[1];
             st.pad = 0;
@@ -428,7 +400,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         }
     }
 
-    if (n_new <= 0) continue;  // not interpolable: silence (the reference has no defined output here)
+    if (n_new <= 0) return;  // not interpolable: silence (the reference has no defined output here)
 
     // ---- forward FFT, 1/N scale (GPUSoundSource.cu:344-346), times D[k]
     float2 xd[8];
@@ -476,11 +448,48 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
             }
         }
     }
-    }  // sources of the group
-    float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+}
+
+template <int NOUT>  // B / 64
+#if JF_MIN_WAVES > 0
+#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg, JF_MIN_WAVES)
+#else
+#define JF_FUSED_BOUNDS __launch_bounds__(64 * kWavesPerWg)
+#endif
+__global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
+    __shared__ float2 s_tw[kTwPack];
+    __shared__ float2 s_buf[kWavesPerWg * kWaveLds];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = s_buf + wave * kWaveLds;
+    constexpr int B = 64 * NOUT;
+    // Persistent workgroups: the grid is sized to the machine (launch_fused), the twiddle pack
+    // is staged once, and every wave strides over the work units.  A unit = one block of G
+    // consecutive sources, processed one after the other and summed in source order in
+    // registers, so only one stereo block per group is written (G = 1: per-source blocks).
+    const int G = P.G, SG = P.S / G;
+    const int n_units = P.K * SG;
+    const int a = lane & 3, i = lane >> 2;
+#pragma unroll 1
+    for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+        const int b = unit / SG;
+        const int s0 = (unit - b * SG) * G;
+        float2 acc[NOUT];
 #pragma unroll
-    for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = acc[j];
-    }  // unit loop
+        for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const int item = b * P.S + s0 + g;
+            spatialise_item<NOUT>(P, P.desc + item, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, acc);
+        }
+        float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = acc[j];
+    }
 }
 
 // ---------------------------------------------------------------- mixing --
@@ -592,22 +601,11 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
     return 4;
 }
 
-__global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, const SrcState *__restrict__ st,
-                            ItemDesc *__restrict__ desc, int S, int K) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= S * K) return;
-    const int b = item / S, s = item - b * S;
-    const float *p = pos + (size_t)item * 5;
+// Descriptor of one work item from its latched position record and the position of the block
+// before (GPUSoundSource.cu:81-90 and :325-335).
+JF_DEV void make_desc(const RingTable &rt, const float *p /* ele, azi, x, y, z */, float old_ele, float old_azi,
+                      ItemDesc &d) {
     const float ele = p[0], azi = p[1];
-    float old_ele, old_azi;
-    if (b == 0) {
-        old_ele = st[s].old_ele;
-        old_azi = st[s].old_azi;
-    } else {
-        old_ele = p[-5 * S];
-        old_azi = p[-5 * S + 1];
-    }
-    ItemDesc d;
     d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new);
     d.n_old = 0;
     // GPUSoundSource.cu:331-335
@@ -636,6 +634,24 @@ __global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, c
     d.inv_frac = 1.0f / frac;
     if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
     d.pad = 0;
+}
+
+__global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, const SrcState *__restrict__ st,
+                            ItemDesc *__restrict__ desc, int S, int K) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= S * K) return;
+    const int b = item / S, s = item - b * S;
+    const float *p = pos + (size_t)item * 5;
+    float old_ele, old_azi;
+    if (b == 0) {
+        old_ele = st[s].old_ele;
+        old_azi = st[s].old_azi;
+    } else {
+        old_ele = p[-5 * S];
+        old_azi = p[-5 * S + 1];
+    }
+    ItemDesc d;
+    make_desc(rt, p, old_ele, old_azi, d);
     desc[item] = d;
 }
 
@@ -652,6 +668,54 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
     }
 }
 #pragma clang fp contract(fast)
+
+// ------------------------------------------------------- real-time kernel --
+// One audio block for a handful of sources in ONE launch (the per-block call of the reference's
+// audio callback): a single workgroup; wave w takes sources w, w + 16, ...; lane 0 builds the
+// descriptor in LDS (no prep launch), the wave spatialises, the waves' stereo blocks are summed
+// in wave order through LDS (no mix launch).  pos and out may be host-mapped pinned memory, so a
+// block costs one launch and one synchronisation, no copies.
+constexpr int kRtWaves = 16;
+template <int NOUT>
+__global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedParams P, const RingTable rt,
+                                                                 const float *__restrict__ pos,
+                                                                 float2 *__restrict__ out) {
+    __shared__ float2 s_tw[kTwPack];
+    __shared__ float2 s_buf[kRtWaves * kWaveLds];
+    __shared__ ItemDesc s_desc[kRtWaves];
+    constexpr int B = 64 * NOUT;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < kTwPack; j += 64 * kRtWaves) s_tw[j] = P.tw[j];
+    __syncthreads();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = s_buf + wave * kWaveLds;
+    const int a = lane & 3, i = lane >> 2;
+    float2 acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int s = wave; s < P.S; s += kRtWaves) {
+        const float *p = pos + 5 * s;
+        if (lane == 0) {
+            ItemDesc d;
+            make_desc(rt, p, P.st_in[s].old_ele, P.st_in[s].old_azi, d);
+            s_desc[wave] = d;
+        }
+        JF_WAVE_LDS_SYNC();
+        spatialise_item<NOUT>(P, &s_desc[wave], p, 0, s, buf, s_tw, lane, acc);
+        JF_WAVE_LDS_SYNC();
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) buf[i + 16 * (NOUT * a + j)] = acc[j];
+    __syncthreads();
+    for (int n = tid; n < B; n += 64 * kRtWaves) {
+        float2 t = s_buf[n];
+#pragma unroll
+        for (int w = 1; w < kRtWaves; w++) t = cadd(t, s_buf[w * kWaveLds + n]);
+        out[n] = t;
+    }
+}
 
 // ------------------------------------------------ table build and FFT tap --
 // hrtf_signals.cu:107-153: unnormalised r2c of every zero-padded HRIR, written
@@ -760,6 +824,20 @@ hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
     case 2: hipLaunchKernelGGL(fused_block_kernel<2>, grid, block, 0, st, P); break;
     case 3: hipLaunchKernelGGL(fused_block_kernel<3>, grid, block, 0, st, P); break;
     case 4: hipLaunchKernelGGL(fused_block_kernel<4>, grid, block, 0, st, P); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, hipStream_t st) {
+    if (P.K != 1) return hipErrorInvalidValue;
+    const dim3 grid(1), block(64 * kRtWaves);
+    float2 *o = reinterpret_cast<float2 *>(out);
+    switch (P.B / 64) {
+    case 1: hipLaunchKernelGGL(rt_block_kernel<1>, grid, block, 0, st, P, rt, pos, o); break;
+    case 2: hipLaunchKernelGGL(rt_block_kernel<2>, grid, block, 0, st, P, rt, pos, o); break;
+    case 3: hipLaunchKernelGGL(rt_block_kernel<3>, grid, block, 0, st, P, rt, pos, o); break;
+    case 4: hipLaunchKernelGGL(rt_block_kernel<4>, grid, block, 0, st, P, rt, pos, o); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
