@@ -1,0 +1,88 @@
+"""The one-launch real-time kernel (per-block calls with few sources) against the batch pipeline and
+the oracle, on a real MI355X."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 4e-7
+
+
+def _setup(jf, hrir, castanets, S, B, rt_max):
+    e = jf.Engine(B, 512, S, hrir=hrir)
+    e.set_rt_max_sources(rt_max)
+    for s in range(S):
+        e.set_signal(s, 0.3 * np.roll(castanets, 777 * s)[: 9000 + 101 * s])
+    return e
+
+
+def _run(e, S, K, oracle=None):
+    out, ref = [], []
+    for b in range(K):
+        for s in range(S):
+            ele, azi, r = -35 + (6 * s) % 120, (11 * s + 4 * (b // 2) * (1 + s % 3)) % 360, 0.4 + 0.2 * (s % 5)
+            e.set_spherical(s, ele, azi, r)
+            if oracle is not None:
+                oracle.set_spherical(s, ele, azi, r)
+        out.append(e.process_block())
+        if oracle is not None:
+            ref.append(oracle.process_block())
+    return np.array(out), (np.array(ref) if oracle is not None else None)
+
+
+@pytest.mark.parametrize("B", [128, 256])
+@pytest.mark.parametrize("S", [1, 7, 16])
+def test_realtime_kernel_equals_batch_pipeline(jf, hrir, castanets, S, B):
+    """Same items, same arithmetic, same sum order for S <= 16 (one source per wave, waves added in
+    order = the mix kernel's order): bit-identical to prep + fused + mix with one block per call."""
+    rt = _setup(jf, hrir, castanets, S, B, 16)
+    ref = _setup(jf, hrir, castanets, S, B, 0)
+    a, _ = _run(rt, S, 9)
+    b, _ = _run(ref, S, 9)
+    rt.close()
+    ref.close()
+    assert np.abs(a).max() > 0.01
+    assert np.array_equal(a, b)
+
+
+def test_realtime_kernel_more_sources_than_waves(jf, hrir, castanets):
+    """rt_max raised to 40: wave w takes sources w, w + 16, w + 32 -- a different association of the
+    same sum, so compared with the oracle to tolerance."""
+    S, B, K = 37, 256, 6
+    e = _setup(jf, hrir, castanets, S, B, 40)
+    o = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        o.set_signal(s, 0.3 * np.roll(castanets, 777 * s)[: 9000 + 101 * s])
+    got, want = _run(e, S, K, o)
+    e.close()
+    assert np.abs(got - want).max() <= TOL32 * 4
+
+
+def test_realtime_kernel_state_carries_into_batch_calls(jf, hrir, castanets):
+    """Windows, play positions and crossfade state written by the real-time kernel are the ones the
+    batch kernels continue from (and vice versa)."""
+    S, B = 3, 256
+    a = _setup(jf, hrir, castanets, S, B, 16)
+    b = _setup(jf, hrir, castanets, S, B, 0)
+    pos = np.zeros((8, S, 5), np.float32)
+    for k in range(8):
+        for s in range(S):
+            pos[k, s] = jf.position_from_spherical(10 * s, (20 * s + 5 * k) % 360, 0.6)
+    outs = []
+    for e in (a, b):
+        o = []
+        for k in range(3):                       # per-block calls
+            for s in range(S):
+                e.set_spherical(s, pos[k, s, 0], pos[k, s, 1], 0.6)
+            o.append(e.process_block())
+        e2 = e.process_batch(pos[3:4])           # a batch call of one block (maxK = 1)
+        o.append(e2[0])
+        for k in range(4, 8):                    # and back
+            for s in range(S):
+                e.set_spherical(s, pos[k, s, 0], pos[k, s, 1], 0.6)
+            o.append(e.process_block())
+        outs.append(np.array(o))
+        e.close()
+    assert np.array_equal(outs[0], outs[1])
