@@ -90,7 +90,8 @@ int jf_num_sources(const jf_engine *e);       /* Data::num_sources (DataTag.cuh:
  * Replaces `source.buf / source.length / source.count = 0` set by cudaFFT()
  * (cudaPart.cu:198-199).  mono float32, looped playback as in
  * copyIncomingBlock (GPUSoundSource.cu:481-513).  The engine copies (host ->
- * device); n == 0 silences the source.
+ * device); n == 0 silences the source.  Like jf_source_reset and jf_reverb_set_ir it waits for the
+ * engine's stream: call it from the thread that processes blocks, between blocks.
  */
 int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n);
 

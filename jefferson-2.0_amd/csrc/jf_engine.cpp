@@ -574,7 +574,10 @@ int jf_callback(jf_engine *e, float *out) {
 
 int jf_pa_callback(const void *, void *output, unsigned long frames, const void *, unsigned long, void *user) {
     jf_engine *e = (jf_engine *)user;
-    if (e && output && frames == (unsigned long)e->B) jf_callback(e, (float *)output);
+    if (!output) return 0;
+    // a stream opened with another buffer size, or an engine error: hand PortAudio silence, never garbage
+    if (!e || frames != (unsigned long)e->B || jf_callback(e, (float *)output) != JF_OK)
+        memset(output, 0, sizeof(float) * 2 * frames);
     return 0;
 }
 

@@ -47,7 +47,6 @@ JF_DEV float2 cmul(float2 a, float2 b) {
 JF_DEV float2 cmulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
-JF_DEV float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
 // twiddle from the e^{+i} table: forward transforms use the conjugate
 template <int DIR>
