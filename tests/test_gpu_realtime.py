@@ -86,3 +86,43 @@ def test_realtime_kernel_state_carries_into_batch_calls(jf, hrir, castanets):
         outs.append(np.array(o))
         e.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_setters_from_another_thread(jf, hrir, castanets):
+    """graphics.cu:378 writes the position from the GLUT thread while the PortAudio thread runs the
+    callback (no lock in the reference).  Here the setters are mutex-protected: hammer them from a
+    second thread during processing; every block must be a valid rendering of SOME latched position
+    (finite, bounded), and the last block must match the final position exactly once the writer stops."""
+    import threading
+    e = _setup(jf, hrir, castanets, 2, 256, 16)
+    stop = threading.Event()
+
+    def writer():
+        k = 0
+        while not stop.is_set():
+            e.set_cartesian(0, 0.5 * np.cos(0.01 * k), 0.1, 0.5 * np.sin(0.01 * k))
+            e.set_spherical(1, 10, k % 360, 0.8)
+            k += 1
+
+    t = threading.Thread(target=writer)
+    t.start()
+    try:
+        for _ in range(300):
+            y = e.process_block()
+            assert np.isfinite(y).all() and np.abs(y).max() < 2.0
+    finally:
+        stop.set()
+        t.join()
+    pa, pb = e.get_position(0), e.get_position(1)
+    e.process_block()                 # latches the final positions (crossfade block)
+    y = e.process_block()             # stationary block at the final positions
+    ref = _setup(jf, hrir, castanets, 2, 256, 16)
+    # replay: same number of blocks consumed, then the same final positions
+    for _ in range(300):
+        ref.process_block()
+    ref.set_cartesian(0, float(pa[3]), float(pa[4]), float(pa[5]))
+    ref.set_spherical(1, float(pb[0]), float(pb[1]), float(pb[2]))
+    ref.process_block()
+    assert np.array_equal(ref.process_block(), y)
+    e.close()
+    ref.close()
