@@ -33,6 +33,25 @@ BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "64"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def cpu_share():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (a GPU box hands each GPU user a share of the node; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
     """The oracle (CPU restatement of the reference's path) on the first n_blocks blocks of
     the first n_sources sources of the same workload, all host threads, parallel over sources."""
@@ -42,7 +61,7 @@ def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
     for s in range(n_sources):
         ora.set_signal(s, wl.source_signal_and_start(s)[0])
     pos = wl.trajectories(jf, np.arange(n_sources), n_blocks)
-    threads = oracle_lib.lib().jfo_num_threads()
+    threads = min(oracle_lib.lib().jfo_num_threads(), cpu_share())
     ora.process_batch(pos[:2], n_threads=threads)  # warm the thread pool
     for s in range(n_sources):
         ora.reset(s)
@@ -53,7 +72,8 @@ def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
     return {"value": n_sources * n_blocks * B / dt, "unit": "source-frames/s", "cores": threads,
             "kind": "port",
             "sample": f"{n_sources} sources x {n_blocks} blocks of the same moving-source workload, "
-                      f"{dt:.2f} s wall on {threads} threads (float32 C oracle, OpenMP over sources)"}
+                      f"{dt:.2f} s wall on {threads} threads = the host-CPU share of this process "
+                      f"(float32 C oracle, OpenMP over sources)"}
 
 
 def main():
