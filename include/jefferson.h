@@ -152,6 +152,17 @@ int jf_callback(jf_engine *e, float *out);
 int jf_pa_callback(const void *input, void *output, unsigned long frames_per_buffer,
                    const void *time_info, unsigned long status_flags, void *user_data);
 
+/*
+ * Data::type (DataTag.cuh:16, enum processes Universal.cuh:25-32), read at every block (Audio.cu:104).
+ * JF_MODE_FD_COMPLEX = GPU_FD_COMPLEX / CPU_FD_COMPLEX, the interpolated path (default).
+ * JF_MODE_FD_BASIC   = *_FD_BASIC (CPUSoundSource.cpp:113-142): nearest HRTF (pick_hrtf), no
+ *   interpolation, no distance factor, no crossfade.  The time-domain modes (*_TD, 512-tap direct
+ *   convolution with the same nearest HRIR, CPUSoundSource.cpp:66-112) compute the same samples:
+ *   B + taps - 1 <= PAD_LEN makes the circular product a linear convolution (tested).
+ */
+enum { JF_MODE_FD_COMPLEX = 0, JF_MODE_FD_BASIC = 1 };
+int jf_set_mode(jf_engine *e, int mode);
+
 /* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed. */
 int jf_set_pause(jf_engine *e, int paused);
 

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("JF_LIB") or os.path.join(_HERE, "libjefferson_hip.so"
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
 
 JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+JF_MODE_FD_COMPLEX, JF_MODE_FD_BASIC = 0, 1
 NUM_HRTF = 710
 PAD_LEN = 1024
 NC = 513
@@ -60,6 +61,7 @@ _SIGS = {
     "jf_collect_block": (C.c_int, [C.c_void_p, _f]),
     "jf_callback": (C.c_int, [C.c_void_p, _f]),
     "jf_pa_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p, C.c_ulong, C.c_void_p]),
+    "jf_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_set_pause": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_process_batch": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
     "jf_batch_upload_positions": (C.c_int, [C.c_void_p, C.c_int, _f]),
@@ -246,6 +248,9 @@ class Engine:
         out = np.zeros(2 * self.B, np.float32)
         self._chk(lib().jf_callback(self.h, _fp(out)))
         return out
+
+    def set_mode(self, mode):
+        self._chk(lib().jf_set_mode(self.h, int(mode)))
 
     def set_pause(self, p):
         self._chk(lib().jf_set_pause(self.h, int(p)))

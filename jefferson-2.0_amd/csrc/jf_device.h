@@ -97,6 +97,7 @@ struct FusedParams {
     float *partial;         // [K][S/G][2B]
     int S, K, B;
     int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
+    int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
 };
 
 // Convolution reverb stage (jf_reverb.hip): uniformly partitioned overlap-save with a

@@ -20,8 +20,8 @@ hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw,
 hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
                                float *d_w, int *d_nt, int n, hipStream_t st);
-hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc, int S,
-                       int K, hipStream_t st);
+hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
+                       int S, int K, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, hipStream_t st);
@@ -65,6 +65,7 @@ struct jf_engine {
     int traj_blocks = 0;
     int cur = 0;  // parity of the valid state/history
     int src_group = 0;  // 0 = automatic
+    int mode = 0;       // Data::type: 0 = FD_COMPLEX, 1 = FD_BASIC
 
     std::vector<float *> d_signal;  // per source
     std::vector<SrcSignal> h_sigs;
@@ -136,7 +137,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
-    JF_HIP(e, launch_prep(ring_table(), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
+    JF_HIP(e, launch_prep(ring_table(), e->mode, d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
     if (e->rv_P > 0) {
         // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring (this call's K blocks)
@@ -185,6 +186,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     // sources summed in registers per wavefront: fewer, larger partial blocks for the mix kernel
     const int G = e->src_group > 0 ? e->src_group : ((e->S % 4 == 0 && (long long)K * e->S >= 16384) ? 4 : 1);
     P.G = (e->S % G == 0) ? G : 1;
+    P.mode = e->mode;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
@@ -527,6 +529,7 @@ int jf_submit_block(jf_engine *e) {
             P.K = 1;
             P.B = e->B;
             P.G = 1;
+            P.mode = e->mode;
             JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, e->stream));
             e->cur = p ^ 1;
             e->in_flight = true;
@@ -579,6 +582,12 @@ int jf_pa_callback(const void *, void *output, unsigned long frames, const void 
     if (!e || frames != (unsigned long)e->B || jf_callback(e, (float *)output) != JF_OK)
         memset(output, 0, sizeof(float) * 2 * frames);
     return 0;
+}
+
+int jf_set_mode(jf_engine *e, int mode) {
+    if (!e || (mode != JF_MODE_FD_COMPLEX && mode != JF_MODE_FD_BASIC)) return fail(e, JF_ERR_ARG, "unknown mode");
+    e->mode = mode;  // read at the next block, like Data::type (Audio.cu:104)
+    return JF_OK;
 }
 
 int jf_set_pause(jf_engine *e, int paused) {

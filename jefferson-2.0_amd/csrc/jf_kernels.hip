@@ -546,6 +546,22 @@ JF_DEV int dev_pick_azi(const RingTable &rt, int ring, float obj_azi) {
     return rt.offset[ring] + best;
 }
 
+// hrtf_signals.cu:20-51 in full: nearest elevation ring, then nearest azimuth on it
+JF_DEV int dev_pick_hrtf(const RingTable &rt, float obj_ele, float obj_azi) {
+    obj_ele = roundf(obj_ele / 10) * 10;
+    float dmin = 1e37f;
+    int ring = 0;
+    for (int e = 0; e < kNumElev; e++) {
+        float d = obj_ele - d_elev_pos[e];
+        d = d > 0 ? d : -d;
+        if (d < dmin) {
+            dmin = d;
+            ring = e;
+        }
+    }
+    return dev_pick_azi(rt, ring, obj_azi);
+}
+
 // returns number of terms (1, 2, 4) or 0 when the elevation ring does not exist
 JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[4], float w[4]) {
     if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return 0;
@@ -602,9 +618,27 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
 
 // Descriptor of one work item from its latched position record and the position of the block
 // before (GPUSoundSource.cu:81-90 and :325-335).
-JF_DEV void make_desc(const RingTable &rt, const float *p /* ele, azi, x, y, z */, float old_ele, float old_azi,
-                      ItemDesc &d) {
+JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi, x, y, z */, float old_ele,
+                      float old_azi, ItemDesc &d) {
     const float ele = p[0], azi = p[1];
+    if (mode == 1) {
+        // *_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): the nearest table row, weight 1, no
+        // distance factor (D = 1), no crossfade
+        const bool ok = (ele > -1.0e6f && ele < 1.0e6f) && (azi > -1.0e6f && azi < 1.0e6f);
+        const int row = ok ? dev_pick_hrtf(rt, ele, azi) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            d.rows_new[t] = d.rows_old[t] = row;
+            d.w_new[t] = t == 0 ? 1.0f : 0.0f;
+            d.w_old[t] = 0.0f;
+        }
+        d.n_new = ok ? 1 : 0;
+        d.n_old = 0;
+        d.c_fix = 0;
+        d.inv_frac = 1.0f;
+        d.pad = 0;
+        return;
+    }
     d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new);
     d.n_old = 0;
     // GPUSoundSource.cu:331-335
@@ -635,8 +669,8 @@ JF_DEV void make_desc(const RingTable &rt, const float *p /* ele, azi, x, y, z *
     d.pad = 0;
 }
 
-__global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, const SrcState *__restrict__ st,
-                            ItemDesc *__restrict__ desc, int S, int K) {
+__global__ void prep_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
+                            const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= S * K) return;
     const int b = item / S, s = item - b * S;
@@ -650,7 +684,7 @@ __global__ void prep_kernel(const RingTable rt, const float *__restrict__ pos, c
         old_azi = p[-5 * S + 1];
     }
     ItemDesc d;
-    make_desc(rt, p, old_ele, old_azi, d);
+    make_desc(rt, mode, p, old_ele, old_azi, d);
     desc[item] = d;
 }
 
@@ -698,7 +732,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
         const float *p = pos + 5 * s;
         if (lane == 0) {
             ItemDesc d;
-            make_desc(rt, p, P.st_in[s].old_ele, P.st_in[s].old_azi, d);
+            make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, d);
             s_desc[wave] = d;
         }
         JF_WAVE_LDS_SYNC();
@@ -792,10 +826,10 @@ hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const fl
     return hipGetLastError();
 }
 
-hipError_t launch_prep(const RingTable &rt, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
+hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
                        int S, int K, hipStream_t st) {
     const int n = S * K;
-    hipLaunchKernelGGL(prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, d_pos, d_st, d_desc, S, K);
+    hipLaunchKernelGGL(prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, mode, d_pos, d_st, d_desc, S, K);
     return hipGetLastError();
 }
 

@@ -371,6 +371,7 @@ typedef struct {
 
 struct jfo_engine {
     int B, L, N, Nc, n_sources;
+    int mode; /* 0 = FD_COMPLEX (interpolated), 1 = FD_BASIC (nearest HRTF) */
     float *table; /* [710][2][Nc][2] */
     jfo_source *src;
     jfo_plan ph, pf;
@@ -422,6 +423,8 @@ void jfo_destroy(jfo_engine *e) {
 }
 
 int jfo_pad_len(const jfo_engine *e) { return e->N; }
+
+void jfo_set_mode(jfo_engine *e, int mode) { e->mode = mode; }
 
 int jfo_source_set_signal(jfo_engine *e, int s, const float *mono, int n) {
     if (s < 0 || s >= e->n_sources || n < 0) return -1;
@@ -542,6 +545,22 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
     int idx[4], rows[4], oidx[4], orows[4];
     float om[6], w[4], oom[6], ow[4];
     int nt = 0, ont = 0;
+    if (e->mode == 1) {
+        /* CPU_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): nearest table row, no interpolation,
+         * no distance factor, no crossfade */
+        rows[0] = jfo_pick_hrtf(ele, azi);
+        w[0] = 1.0f;
+        for (int k = 0; k < Nc; k++) {
+            D[2 * k] = 1.0f;
+            D[2 * k + 1] = 0.0f;
+        }
+        filter_set(e, X, D, 1, rows, w, Y, z1);
+        memcpy(blk, z1 + 2 * (N - B), sizeof(float) * 2 * (size_t)B);
+        q->old_azi = azi;
+        q->old_ele = ele;
+        memmove(q->x, q->x + B, sizeof(float) * (size_t)(N - B));
+        return 0;
+    }
     if (jfo_interp(ele, azi, idx, om)) rc = -1;
     int xfade = (q->old_azi != azi || q->old_ele != ele);
     if (xfade && jfo_interp(q->old_ele, q->old_azi, oidx, oom)) rc = -1;

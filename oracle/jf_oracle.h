@@ -76,6 +76,8 @@ jfo_engine *jfo_create(int frames_per_buffer, int hrtf_len, int n_sources,
                        const float *hrir /* [710][2][taps] */, int taps);
 void jfo_destroy(jfo_engine *e);
 int jfo_pad_len(const jfo_engine *e);
+/* Data::type (DataTag.cuh:16): 0 = *_FD_COMPLEX, 1 = *_FD_BASIC (CPUSoundSource.cpp:113-142) */
+void jfo_set_mode(jfo_engine *e, int mode);
 /* cudaPart.cu:198-199 (buf/length); the engine copies. */
 int jfo_source_set_signal(jfo_engine *e, int s, const float *mono, int n);
 int jfo_source_set_spherical(jfo_engine *e, int s, float ele, float azi, float r);

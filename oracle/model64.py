@@ -222,6 +222,7 @@ class Model:
         fn = (i / f32(self.B - 1.0)).astype(np.float32)  # kernels.cu:134
         self.fade_new = fn.astype(np.float64)
         self.fade_old = (f32(1.0) - fn).astype(np.float64)
+        self.mode = 0  # 0 = FD_COMPLEX, 1 = FD_BASIC (nearest HRTF, CPUSoundSource.cpp:113-142)
 
     def set_signal(self, s, mono):
         self.src[s].buf = np.asarray(mono, np.float32).copy()
@@ -262,6 +263,15 @@ class Model:
             q.count = int((q.count + B) % L)
         q.x[N - B:] = new
         X = np.fft.rfft(q.x) / N
+        if self.mode == 1:
+            Y = X[None, :] * self.table[pick_hrtf(ele, azi)]
+            Y[:, 0] = Y[:, 0].real
+            Y[:, -1] = Y[:, -1].real
+            y = (np.fft.irfft(Y, n=N, axis=-1) * N)[:, N - B:]
+            q.old_azi, q.old_ele = f32(azi), f32(ele)
+            q.x[:N - B] = q.x[B:].copy()
+            q.last = y.T.copy().reshape(-1)
+            return q.last
         cur = interp(ele, azi)
         xfade = (q.old_azi != azi) or (q.old_ele != ele)
         old = interp(q.old_ele, q.old_azi) if xfade else None

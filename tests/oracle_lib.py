@@ -53,6 +53,7 @@ def lib():
         L.jfo_destroy.argtypes = [C.c_void_p]
         L.jfo_pad_len.argtypes = [C.c_void_p]
         L.jfo_pad_len.restype = C.c_int
+        L.jfo_set_mode.argtypes = [C.c_void_p, C.c_int]
         L.jfo_source_set_signal.argtypes = [C.c_void_p, C.c_int, _f, C.c_int]
         L.jfo_source_set_signal.restype = C.c_int
         L.jfo_source_set_spherical.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 3
@@ -171,6 +172,9 @@ class Engine:
 
     def __del__(self):
         self.close()
+
+    def set_mode(self, mode):
+        lib().jfo_set_mode(self.h, int(mode))
 
     def set_signal(self, s, mono):
         mono = np.ascontiguousarray(mono, np.float32)
