@@ -271,8 +271,34 @@ def test_directory_loader_and_offline_driver(jf, hrir, castanets, tmp_path):
     kemar = str(tmp_path / "compact")
     _write_compact_dir(kemar, hrir)
     eng = jf.Engine(256, 512, 1, hrir_dir=kemar)
-    assert np.array_equal(eng.read_table(), jf.Engine(256, 512, 1, hrir=hrir).read_table())
+    ref_table = jf.Engine(256, 512, 1, hrir=hrir).read_table()
+    assert np.array_equal(eng.read_table(), ref_table)
     eng.close()
+
+    # the reference's own "full" layout (full/elev%d/L%de%03da.wav + R..., mono files, hrtf_signals.cu:124,131)
+    full = str(tmp_path / "full")
+    for j, (e, a) in enumerate(model64.table_positions()):
+        d = os.path.join(full, f"elev{e}")
+        os.makedirs(d, exist_ok=True)
+        for ear, tag in enumerate("LR"):
+            with wave.open(os.path.join(d, f"{tag}{e}e{a:03d}a.wav"), "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(44100)
+                w.writeframes(np.round(hrir[j, ear] * 32768.0).astype(np.int16).tobytes())
+    eng = jf.Engine(256, 512, 1, hrir_dir=full)
+    assert np.array_equal(eng.read_table(), ref_table)
+    eng.close()
+    # a stereo file where the full layout wants mono is the reference's "incorrect number of channels"
+    bad = os.path.join(full, "elev0", "L0e000a.wav")
+    with wave.open(bad, "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(44100)
+        w.writeframes(np.zeros((128, 2), np.int16).tobytes())
+    with pytest.raises(jf.JfError) as ei:
+        jf.Engine(256, 512, 1, hrir_dir=full)
+    assert ei.value.code == jf.JF_ERR_IO
 
     ex = np.load(os.path.join(ROOT, "tests", "golden", "castanets_441_excerpt_i24.npy"))[:30000]
     inp = str(tmp_path / "in.wav")
