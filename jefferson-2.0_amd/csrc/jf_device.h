@@ -37,6 +37,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_CHUNK_LOADS
 #define JF_CHUNK_LOADS 8  // table-row loads (16 B per lane each) a wave keeps in flight per round
 #endif
+#ifndef JF_SPLIT_EXCHANGE
+#define JF_SPLIT_EXCHANGE 0  // 1: halve the per-wave LDS exchange buffer (re and im separately)
+#endif
 #ifndef JF_MIN_WAVES
 #define JF_MIN_WAVES 0
 #endif

@@ -213,12 +213,32 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
 #pragma unroll
     for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tw[kTwW2 + 16 * m + i]);
     // exchange inside each group a: write rows m (padded 64 -> 68), read columns
+#if JF_SPLIT_EXCHANGE
+    // real and imaginary parts one after the other through a float image of half the size
+    // (4352 B per wave instead of 8704 B: 20 waves per CU fit beside the twiddle pack)
+    {
+        float *fb = reinterpret_cast<float *>(buf);
+#pragma unroll
+        for (int m = 0; m < 16; m++) fb[68 * m + lane] = v[m].x;
+        JF_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j].x = fb[68 * i + 4 * j + a];
+        JF_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int m = 0; m < 16; m++) fb[68 * m + lane] = v[m].y;
+        JF_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j].y = fb[68 * i + 4 * j + a];
+        JF_WAVE_LDS_SYNC();
+    }
+#else
 #pragma unroll
     for (int m = 0; m < 16; m++) buf[68 * m + lane] = v[m];
     JF_WAVE_LDS_SYNC();
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = buf[68 * i + 4 * j + a];
     JF_WAVE_LDS_SYNC();
+#endif
     fft16<+1>(v);  // s_a[i + 16 t]
     // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t
 #pragma unroll
@@ -329,7 +349,11 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
 }
 
 // ------------------------------------------------------------ fused kernel --
+#if JF_SPLIT_EXCHANGE
+constexpr int kWaveLds = 576;   // float2 per wave (4608 B): forward passes; the inverse exchange goes in two halves
+#else
 constexpr int kWaveLds = 1088;  // float2 per wave (8704 B): inverse exchange; forward uses 576
+#endif
 
 // One (block b, source s) work item by one wavefront: everything from the window gather to the
 // crossfaded stereo frames, which are ADDED to acc (B/64 frames per lane: frame i + 16 (NOUT a + j),
@@ -836,19 +860,28 @@ hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const 
 hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
     if (P.G <= 0 || P.S % P.G) return hipErrorInvalidValue;
     const int n_items = P.K * (P.S / P.G);
-    // one workgroup per CU slot the kernel can occupy (LDS-bound: 1 x 16 waves, 3 x 4 waves, ...)
-    static int max_wgs = 0;
-    if (max_wgs == 0) {
-        int dev = 0, cus = 256;
+    // Persistent grid: as many workgroups as the GPU holds at once (CUs x resident workgroups per CU
+    // for this build's LDS and register footprint, from the occupancy query; an over-estimate only
+    // queues the surplus workgroups -- the item loop is a plain stride, there is no grid barrier).
+    static int max_wgs_of[5] = {0, 0, 0, 0, 0};
+    const int nb = P.B / 64;
+    if (nb < 1 || nb > 4) return hipErrorInvalidValue;
+    if (max_wgs_of[nb] == 0) {
+        int dev = 0, cus = 256, per_cu = 1;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
-        const int lds_per_wg = (kTwPack + kWavesPerWg * 1088) * (int)sizeof(float2);
-        int per_cu = (160 * 1024) / lds_per_wg;
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu * kWavesPerWg > 16) per_cu = (16 / kWavesPerWg) > 0 ? 16 / kWavesPerWg : 1;
-        max_wgs = cus * per_cu;
+        hipError_t q = hipErrorUnknown;
+        switch (nb) {
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<1>, 64 * kWavesPerWg, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<2>, 64 * kWavesPerWg, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<3>, 64 * kWavesPerWg, 0); break;
+        default: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<4>, 64 * kWavesPerWg, 0); break;
+        }
+        if (q != hipSuccess || per_cu < 1) per_cu = 1;
+        max_wgs_of[nb] = cus * per_cu;
     }
+    const int max_wgs = max_wgs_of[nb];
     int wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
     if (wgs > max_wgs) wgs = max_wgs;
     const dim3 grid(wgs), block(64 * kWavesPerWg);
