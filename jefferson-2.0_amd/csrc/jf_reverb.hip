@@ -130,69 +130,86 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
 }
 
 // ---------------------------------------------------------------- stage B --
-// One workgroup (16 waves) per (block k, source s): the waves split the P partitions (so that a
-// real-time call with K*S ~ #CUs still puts 16 waves of loads in flight on every CU), each lane
-// owns B/64 consecutive bins; LDS reduce; wave 0 inverts and writes the wet block.
+// One workgroup (16 waves) per (block k, group of T consecutive sources): the waves split the P
+// partitions (so that a real-time call with K*S ~ #CUs still puts 16 waves of loads in flight on
+// every CU), each lane owns B/64 consecutive bins of every source of the group; an IR spectrum H_p is
+// loaded once and used for the T sources (T = 4 in batch calls: 1.25 instead of 2 loads per
+// multiply-accumulate); LDS reduce; waves 0..T-1 each invert one source and write its wet block.
 constexpr int kMacWaves = 16;
-template <int B>
+template <int B, int T>
 __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const ReverbParams P) {
     constexpr int NB = B / 64;
-    __shared__ float2 s_red[kMacWaves][B];
-    __shared__ float2 s_fft[2 * B];
+    __shared__ float2 s_red[kMacWaves][T][B];
+    __shared__ float2 s_fft[T][2 * B];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = blockIdx.x / P.S, s = blockIdx.x - k * P.S;
+    const int SG = P.S / T;
+    const int k = blockIdx.x / SG, s0 = (blockIdx.x - k * SG) * T;
 
-    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + lane * NB;
+    const float2 *fdl = P.fdl + (size_t)s0 * P.Rg * B + lane * NB;
     const float2 *hs = P.hspec + lane * NB;
-    float2 acc[NB];
-    float2 acc0 = make_float2(0.f, 0.f);  // bin 0 is two packed real bins
+    float2 acc[T][NB];
+    float2 acc0[T];  // bin 0 is two packed real bins
 #pragma unroll
-    for (int i = 0; i < NB; i++) acc[i] = make_float2(0.f, 0.f);
+    for (int t = 0; t < T; t++) {
+        acc0[t] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NB; i++) acc[t][i] = make_float2(0.f, 0.f);
+    }
     int slot = (P.head + k - wave) % P.Rg;
     if (slot < 0) slot += P.Rg;
-#pragma unroll 4
+#pragma unroll 2
     for (int p = wave; p < P.P; p += kMacWaves) {
-        float2 x[NB], h[NB];
-        const float2 *xp = fdl + (size_t)slot * B;
+        float2 h[NB];
         const float2 *hp = hs + (size_t)p * B;
         if (NB == 2) {
-            const float4 xv = *reinterpret_cast<const float4 *>(xp);
             const float4 hv = *reinterpret_cast<const float4 *>(hp);
-            x[0] = make_float2(xv.x, xv.y);
-            x[NB - 1] = make_float2(xv.z, xv.w);
             h[0] = make_float2(hv.x, hv.y);
             h[NB - 1] = make_float2(hv.z, hv.w);
         } else {
 #pragma unroll
-            for (int i = 0; i < NB; i++) {
-                x[i] = xp[i];
-                h[i] = hp[i];
-            }
+            for (int i = 0; i < NB; i++) h[i] = hp[i];
         }
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            acc[i].x += x[i].x * h[i].x - x[i].y * h[i].y;
-            acc[i].y += x[i].x * h[i].y + x[i].y * h[i].x;
+        for (int t = 0; t < T; t++) {
+            float2 x[NB];
+            const float2 *xp = fdl + ((size_t)t * P.Rg + slot) * B;
+            if (NB == 2) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xp);
+                x[0] = make_float2(xv.x, xv.y);
+                x[NB - 1] = make_float2(xv.z, xv.w);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; i++) x[i] = xp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                acc[t][i].x += x[i].x * h[i].x - x[i].y * h[i].y;
+                acc[t][i].y += x[i].x * h[i].y + x[i].y * h[i].x;
+            }
+            acc0[t].x += x[0].x * h[0].x;
+            acc0[t].y += x[0].y * h[0].y;
         }
-        acc0.x += x[0].x * h[0].x;
-        acc0.y += x[0].y * h[0].y;
         slot -= kMacWaves;
         if (slot < 0) slot += P.Rg;
     }
-    if (lane == 0) acc[0] = acc0;
 #pragma unroll
-    for (int i = 0; i < NB; i++) s_red[wave][lane * NB + i] = acc[i];
+    for (int t = 0; t < T; t++) {
+        if (lane == 0) acc[t][0] = acc0[t];
+#pragma unroll
+        for (int i = 0; i < NB; i++) s_red[wave][t][lane * NB + i] = acc[t][i];
+    }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave >= T) return;
+    const int t = wave, s = s0 + t;
 
     // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
-    float2 *ybuf = s_fft, *zbuf = s_fft + B;
+    float2 *ybuf = s_fft[t], *zbuf = s_fft[t] + B;
     for (int q = lane; q < B; q += 64) {
-        float2 acc = s_red[0][q];
+        float2 a = s_red[0][t][q];
 #pragma unroll
-        for (int w = 1; w < kMacWaves; w++) acc = rv_add(acc, s_red[w][q]);
-        ybuf[q] = acc;
+        for (int w = 1; w < kMacWaves; w++) a = rv_add(a, s_red[w][t][q]);
+        ybuf[q] = a;
     }
     JF_RV_SYNC();
     for (int q = lane; q < B; q += 64) {
@@ -264,20 +281,27 @@ hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float sca
     return hipGetLastError();
 }
 
+template <int B, int T>
+static void launch_mac(const ReverbParams &P, hipStream_t st) {
+    hipLaunchKernelGGL((reverb_mac_kernel<B, T>), dim3(P.K * (P.S / T)), dim3(64 * kMacWaves), 0, st, P);
+}
+
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
-    const dim3 ga((P.K * P.S + 3) / 4), gb(P.K * P.S), blk(256), blkb(64 * kMacWaves);
+    const dim3 ga((P.K * P.S + 3) / 4), blk(256);
+    // groups of sources share the IR spectra when there are enough (block, group) units to fill the GPU
+    const bool grouped = P.S % 4 == 0 && (long long)P.K * P.S / 4 >= 512;
     switch (P.B) {
     case 64:
         hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<64>, gb, blkb, 0, st, P);
+        if (grouped) launch_mac<64, 4>(P, st); else launch_mac<64, 1>(P, st);
         break;
     case 128:
         hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<128>, gb, blkb, 0, st, P);
+        if (grouped) launch_mac<128, 4>(P, st); else launch_mac<128, 1>(P, st);
         break;
     case 256:
         hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        hipLaunchKernelGGL(reverb_mac_kernel<256>, gb, blkb, 0, st, P);
+        if (grouped) launch_mac<256, 2>(P, st); else launch_mac<256, 1>(P, st);
         break;
     default: return hipErrorInvalidValue;
     }
