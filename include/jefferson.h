@@ -227,6 +227,11 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb k
  * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (4 for large batches);
  * must divide n_sources.  The mix is the same sum in a different association. */
 int jf_debug_set_source_group(jf_engine *e, int group);
+/* Form of the reverb's multiply-accumulate stage: 0 = by call size (default); 1 = one workgroup per
+ * (block, source) -- what real-time calls use; 2 = groups of sources share each IR partition spectrum;
+ * 3 = tiles of consecutive blocks share a sliding window of input spectra (large batch calls).  The
+ * forms add the same products in different associations. */
+int jf_debug_set_reverb_form(jf_engine *e, int form);
 /* Per-block calls (jf_process_block / jf_submit_block / jf_callback) with at most n sources use the
  * one-launch real-time kernel (descriptors + spatialisation + mix in one workgroup, pinned host I/O);
  * above that, the batch pipeline with one block.  Default 16; 0 disables the real-time kernel. */

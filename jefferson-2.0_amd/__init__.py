@@ -77,6 +77,7 @@ _SIGS = {
     "jf_reverb_rms_gain": (C.c_float, [_f, C.c_size_t, _f, C.c_size_t]),
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_set_reverb_form": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jf_debug_set_rt_max_sources": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
@@ -303,6 +304,9 @@ class Engine:
 
     def set_source_group(self, g):
         self._chk(lib().jf_debug_set_source_group(self.h, int(g)))
+
+    def set_reverb_form(self, form):
+        self._chk(lib().jf_debug_set_reverb_form(self.h, int(form)))
 
     def read_device(self, ptr, shape):
         out = np.zeros(shape, np.float32)

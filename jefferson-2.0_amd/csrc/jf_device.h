@@ -122,6 +122,7 @@ struct ReverbParams {
     float *wet;
     const SrcState *st_in;    // count = wet-ring position of the first new sample of this call
     int S, K, B, P, Rg, Wr, head;
+    int mac_form;             // 0 = chosen by call size; 1 per (block, source), 2 source groups, 3 block tiles
 };
 
 }  // namespace jf

@@ -65,6 +65,7 @@ struct jf_engine {
     int traj_blocks = 0;
     int cur = 0;  // parity of the valid state/history
     int src_group = 0;  // 0 = automatic
+    int rv_form = 0;    // 0 = automatic
     int mode = 0;       // Data::type: 0 = FD_COMPLEX, 1 = FD_BASIC
 
     std::vector<float *> d_signal;  // per source
@@ -165,6 +166,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
         R.Rg = e->rv_Rg;
         R.Wr = e->rv_Wr;
         R.head = e->rv_head;
+        R.mac_form = e->rv_form;
         JF_HIP(e, launch_reverb(R, e->stream));
         if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
         e->rv_head = (e->rv_head + K) % e->rv_Rg;
@@ -766,6 +768,12 @@ int jf_debug_set_rt_max_sources(jf_engine *e, int n) {
 int jf_debug_set_source_group(jf_engine *e, int group) {
     if (!e || group < 0 || (group > 0 && e->S % group)) return JF_ERR_ARG;
     e->src_group = group;
+    return JF_OK;
+}
+
+int jf_debug_set_reverb_form(jf_engine *e, int form) {
+    if (!e || form < 0 || form > 3) return JF_ERR_ARG;
+    e->rv_form = form;
     return JF_OK;
 }
 

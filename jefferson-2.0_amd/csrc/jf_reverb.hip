@@ -26,6 +26,19 @@ JF_DEV float2 rv_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b
 JF_DEV float2 rv_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 JF_DEV float2 rv_mulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
+// acc += x * h (complex) as two packed f32 FMAs -- the f32 vector peak needs v_pk_fma_f32 -- with the
+// operand halves picked by op_sel (written as asm: the compiler materialises the broadcast pairs with
+// v_mov instead, +32 VGPRs for a tile's window), and the element-wise acc += x .* h for the packed
+// pair of real bins 0 and B.
+typedef float rv_v2 __attribute__((ext_vector_type(2)));
+JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(h));  // (x.re, x.re) * (h.re, h.im)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"   // (x.im, x.im) * (-h.im, h.re)
+        : "+v"(acc)
+        : "v"(x), "v"(h));
+}
+JF_DEV void rv_mac2(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = __builtin_elementwise_fma(x, h, acc); }
+
 // Wave-private LDS hand-off (see jf_kernels.hip)
 #define JF_RV_SYNC()                                            \
     do {                                                        \
@@ -129,6 +142,46 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
     }
 }
 
+// Last step of stage B for one (block k, source s), by one wavefront: add the NW partial spectra
+// (red, red + stride, ...), untangle the packed real spectrum, inverse FFT, write the wet block.
+template <int B, int NW>
+JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const ReverbParams &P, int s, int k, int lane) {
+    // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
+    float2 *ybuf = fftbuf, *zbuf = fftbuf + B;
+    for (int q = lane; q < B; q += 64) {
+        float2 a = red[q];
+#pragma unroll
+        for (int w = 1; w < NW; w++) a = rv_add(a, red[(size_t)w * stride + q]);
+        ybuf[q] = a;
+    }
+    JF_RV_SYNC();
+    for (int q = lane; q < B; q += 64) {
+        const float2 yk = ybuf[q];
+        const float2 ym = ybuf[(B - q) & (B - 1)];
+        float2 z;
+        if (q == 0) {
+            z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));  // E0 + j O0 from (Y[0], Y[B])
+        } else {
+            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+            const float2 o = rv_mul(d, P.tw[q * (512 / B)]);  // W^-q = exp(+2 pi i q / 2B)
+            z = make_float2(e.x - o.y, e.y + o.x);
+        }
+        zbuf[q] = z;
+    }
+    JF_RV_SYNC();
+    const float2 *zt = cfft_small<B, +1>(zbuf, ybuf, P.tw, lane);
+    // overlap-save: time samples B..2B-1 = z[m], m >= B/2 (even, odd interleaved)
+    const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
+    float *wet = P.wet + (size_t)s * P.Wr;
+    const int w0 = (int)(((long long)c0 + (long long)k * B) % P.Wr);
+    for (int m = B / 2 + lane; m < B; m += 64) {
+        const float2 v = zt[m];
+        const int n = 2 * m - B;  // 0..B-2, even; the ring length is a multiple of B, w0 too
+        *reinterpret_cast<float2 *>(wet + w0 + n) = v;
+    }
+}
+
 // ---------------------------------------------------------------- stage B --
 // One workgroup (16 waves) per (block k, group of T consecutive sources): the waves split the P
 // partitions (so that a real-time call with K*S ~ #CUs still puts 16 waves of loads in flight on
@@ -201,42 +254,90 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     }
     __syncthreads();
     if (wave >= T) return;
-    const int t = wave, s = s0 + t;
+    mac_finish<B, kMacWaves>(&s_red[0][wave][0], T * B, s_fft[wave], P, s0 + wave, k, lane);
+}
 
-    // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
-    float2 *ybuf = s_fft[t], *zbuf = s_fft[t] + B;
-    for (int q = lane; q < B; q += 64) {
-        float2 a = s_red[0][t][q];
+// Batch form of stage B (many blocks per call): one workgroup per (source, KB consecutive blocks).
+// Block k + i at partition p needs FDL slot head + k + i - p, so the KB blocks of a tile use a
+// sliding window of KB spectra: per partition ONE new X load and one H load feed KB multiply-
+// accumulates (0.25 loads per MAC at KB = 8, against 2 in the real-time form) -- the FDL is
+// L2/Infinity-Cache resident here and the cache bandwidth, not HBM, is what the loads queue on.
+// The waves split the partitions in contiguous chunks (multiples of KB, so that the window's register
+// indices are static); waves 0..KB-1 then each finish one block.
+constexpr int kTileWaves = 8;
+#ifndef JF_TILE_ATTR
+#define JF_TILE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU: 128 VGPRs
+#endif
+template <int B, int KB>
+__global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled_kernel(const ReverbParams P) {
+    constexpr int NB = B / 64;
+    static_assert(KB <= kTileWaves, "one finishing wave per block of the tile");
+    __shared__ float2 s_red[kTileWaves][KB][B];
+    __shared__ float2 s_fft[KB][2 * B];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt = blockIdx.x / P.S, s = blockIdx.x - kt * P.S;
+    const int k0 = kt * KB;
+
+    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + lane * NB;
+    const float2 *hs = P.hspec + lane * NB;
+    rv_v2 acc[KB][NB], acc0[KB], xr[KB][NB];
 #pragma unroll
-        for (int w = 1; w < kMacWaves; w++) a = rv_add(a, s_red[w][t][q]);
-        ybuf[q] = a;
+    for (int i = 0; i < KB; i++) {
+        acc0[i] = rv_v2{0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NB; n++) acc[i][n] = rv_v2{0.f, 0.f};
     }
-    JF_RV_SYNC();
-    for (int q = lane; q < B; q += 64) {
-        const float2 yk = ybuf[q];
-        const float2 ym = ybuf[(B - q) & (B - 1)];
-        float2 z;
-        if (q == 0) {
-            z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));  // E0 + j O0 from (Y[0], Y[B])
+    const int chunk = (P.P + kTileWaves * KB - 1) / (kTileWaves * KB) * KB;
+    const int pa = wave * chunk;
+    const int pb = pa + chunk < P.P ? pa + chunk : P.P;
+    auto load_bins = [&](rv_v2 *dst, const float2 *src) {  // this lane's NB consecutive bins
+        if (NB == 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            dst[0] = rv_v2{v.x, v.y};
+            dst[NB - 1] = rv_v2{v.z, v.w};
         } else {
-            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-            const float2 o = rv_mul(d, P.tw[q * (512 / B)]);  // W^-q = exp(+2 pi i q / 2B)
-            z = make_float2(e.x - o.y, e.y + o.x);
+#pragma unroll
+            for (int n = 0; n < NB; n++) dst[n] = rv_v2{src[n].x, src[n].y};
         }
-        zbuf[q] = z;
+    };
+    auto load_x = [&](rv_v2 *dst, int u) {  // the spectrum of block k0 + u (u may be far in the past)
+        int slot = (P.head + k0 + u) % P.Rg;
+        if (slot < 0) slot += P.Rg;
+        load_bins(dst, fdl + (size_t)slot * B);
+    };
+    // window before the chunk's first partition: X(i - pa), i = 1..KB-1, kept at xr[(i - pa) mod KB] = xr[i]
+#pragma unroll
+    for (int i = 1; i < KB; i++) load_x(xr[i], i - pa);
+    auto step = [&](int j, int p) {  // j = p mod KB, a constant after unrolling
+        rv_v2 h[NB];
+        load_bins(h, hs + (size_t)p * B);
+        load_x(xr[(KB - j) % KB], -p);  // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const rv_v2 *x = xr[(i + KB - j) % KB];  // X(i - p)
+#pragma unroll
+            for (int n = 0; n < NB; n++) rv_cmac(acc[i][n], x[n], h[n]);
+            rv_mac2(acc0[i], x[0], h[0]);
+        }
+    };
+    int p0 = pa;
+    for (; p0 + KB <= pb; p0 += KB) {  // straight-line groups: loads of later steps may move above earlier MACs
+#pragma unroll
+        for (int j = 0; j < KB; j++) step(j, p0 + j);
     }
-    JF_RV_SYNC();
-    const float2 *zt = cfft_small<B, +1>(zbuf, ybuf, P.tw, lane);
-    // overlap-save: time samples B..2B-1 = z[m], m >= B/2 (even, odd interleaved)
-    const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
-    float *wet = P.wet + (size_t)s * P.Wr;
-    const int w0 = (int)(((long long)c0 + (long long)k * B) % P.Wr);
-    for (int m = B / 2 + lane; m < B; m += 64) {
-        const float2 v = zt[m];
-        const int n = 2 * m - B;  // 0..B-2, even; the ring length is a multiple of B, w0 too
-        *reinterpret_cast<float2 *>(wet + w0 + n) = v;
+#pragma unroll
+    for (int j = 0; j < KB; j++)
+        if (p0 + j < pb) step(j, p0 + j);  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        if (lane == 0) acc[i][0] = acc0[i];
+#pragma unroll
+        for (int n = 0; n < NB; n++) s_red[wave][i][lane * NB + n] = make_float2(acc[i][n].x, acc[i][n].y);
     }
+    __syncthreads();
+    if (wave >= KB || k0 + wave >= P.K) return;
+    mac_finish<B, kTileWaves>(&s_red[0][wave][0], KB * B, s_fft[wave], P, s, k0 + wave, lane);
 }
 
 // ------------------------------------------------------------- IR spectra --
@@ -285,23 +386,35 @@ template <int B, int T>
 static void launch_mac(const ReverbParams &P, hipStream_t st) {
     hipLaunchKernelGGL((reverb_mac_kernel<B, T>), dim3(P.K * (P.S / T)), dim3(64 * kMacWaves), 0, st, P);
 }
+template <int B, int KB>
+static void launch_mac_tiled(const ReverbParams &P, hipStream_t st) {
+    hipLaunchKernelGGL((reverb_mac_tiled_kernel<B, KB>), dim3((P.K + KB - 1) / KB * P.S), dim3(64 * kTileWaves), 0, st, P);
+}
+// Form of stage B by the amount of work in the call: block-tiled when the tiles alone fill the GPU,
+// else source-grouped, else (real-time calls) one workgroup per (block, source).
+template <int B, int T, int KB>
+static void launch_mac_any(const ReverbParams &P, hipStream_t st) {
+    const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
+    const long long tiles = (long long)((P.K + KB - 1) / KB) * P.S;
+    if (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) launch_mac_tiled<B, KB>(P, st);
+    else if (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) launch_mac<B, T>(P, st);
+    else launch_mac<B, 1>(P, st);
+}
 
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
     const dim3 ga((P.K * P.S + 3) / 4), blk(256);
-    // groups of sources share the IR spectra when there are enough (block, group) units to fill the GPU
-    const bool grouped = P.S % 4 == 0 && (long long)P.K * P.S / 4 >= 512;
     switch (P.B) {
     case 64:
         hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        if (grouped) launch_mac<64, 4>(P, st); else launch_mac<64, 1>(P, st);
+        launch_mac_any<64, 4, 8>(P, st);
         break;
     case 128:
         hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        if (grouped) launch_mac<128, 4>(P, st); else launch_mac<128, 1>(P, st);
+        launch_mac_any<128, 4, 8>(P, st);
         break;
     case 256:
         hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        if (grouped) launch_mac<256, 2>(P, st); else launch_mac<256, 1>(P, st);
+        launch_mac_any<256, 2, 4>(P, st);
         break;
     default: return hipErrorInvalidValue;
     }

@@ -34,8 +34,9 @@ def _wet_stream(dry, n_total, ir, gain):
     return gain * wet
 
 
-def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False):
+def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False, form=0):
     eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max_k)
+    eng.set_reverb_form(form)
     for s in range(S):
         eng.set_signal(s, sigs[s])
     eng.set_reverb(ir, gain)
@@ -107,6 +108,27 @@ def test_reverb_blockwise_equals_batch(jf, hrir, castanets):
     a = _run(jf, hrir, B, S, K, 4, ir, 0.5, sigs, pos)
     b = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("B,P,max_k", [(128, 21, 11), (256, 9, 7), (64, 70, 16), (128, 3, 8)])
+def test_reverb_mac_forms_agree(jf, hrir, castanets, B, P, max_k):
+    """The three forms of the multiply-accumulate stage (per (block, source); source groups sharing the IR
+    spectra; block tiles sharing a sliding window of input spectra) add the same products in different
+    associations: each within the float64 tolerance, and within 2 * tol of one another.  max_k is
+    chosen so that calls end in partial tiles (K % 8 != 0), P so that the waves' partition chunks are
+    ragged or empty."""
+    S, K = 4, 27
+    ir = _ir(P * B - 5)
+    gain = 0.6
+    sigs = [castanets[3000 * s: 3000 * s + 8000 + 77 * s] for s in range(S)]
+    pos = _positions(jf, S, K)
+    want = _model(hrir, B, S, K, ir, gain, sigs, pos)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * S
+    outs = [_run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, form=f) for f in (1, 2, 3)]
+    assert np.abs(want).max() > 0.05
+    for o in outs:
+        assert np.abs(o - want).max() <= tol
+    assert not np.array_equal(outs[0], outs[2]) or P <= 8   # really different code paths
 
 
 def test_reverb_identity_ir_is_the_dry_path(jf, hrir, castanets):
