@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
+#include "jf_packed.h"
 
 namespace jf {
 
@@ -26,17 +27,11 @@ JF_DEV float2 rv_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b
 JF_DEV float2 rv_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 JF_DEV float2 rv_mulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
-// acc += x * h (complex) as two packed f32 FMAs -- the f32 vector peak needs v_pk_fma_f32 -- with the
-// operand halves picked by op_sel (written as asm: the compiler materialises the broadcast pairs with
-// v_mov instead, +32 VGPRs for a tile's window), and the element-wise acc += x .* h for the packed
-// pair of real bins 0 and B.
-typedef float rv_v2 __attribute__((ext_vector_type(2)));
-JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(h));  // (x.re, x.re) * (h.re, h.im)
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"   // (x.im, x.im) * (-h.im, h.re)
-        : "+v"(acc)
-        : "v"(x), "v"(h));
-}
+// acc += x * h (complex) as two packed f32 FMAs (jf_packed.h: the f32 vector peak needs v_pk_fma_f32;
+// written as asm because the compiler materialises the broadcast pairs with v_mov instead, +32 VGPRs for
+// a tile's window), and the element-wise acc += x .* h for the packed pair of real bins 0 and B.
+typedef c2 rv_v2;
+JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = pcmac(x, h, acc); }
 JF_DEV void rv_mac2(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = __builtin_elementwise_fma(x, h, acc); }
 
 // Wave-private LDS hand-off (see jf_kernels.hip)

@@ -1,18 +1,25 @@
 #!/bin/bash
-# one PMC pass: VALU/SALU/LDS instruction counts and wave cycles of the fused kernel
+# PMC passes over the fused kernel of one build: profiles/quick_pmc.sh <tag> [lib-tag]
+# (lib-tag = a variant built with `make variant TAG=...`; empty = the product library)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/qpmc_${1:-x}
+[ -n "$2" ] && export JF_LIB=$REPO/jefferson-2.0_amd/libjefferson_hip_$2.so
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p0 -- python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/p0.log 2>&1
+i=0
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+         "SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES"; do
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  i=$((i+1))
+done
 python3 - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob("$OUT/p0/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "fused_block_kernel" not in row.get("Kernel_Name", ""): continue
         tot[row["Counter_Name"]][0] += float(row["Counter_Value"]); tot[row["Counter_Name"]][1] += 1
 w = tot["SQ_WAVES"][0] / max(tot["SQ_WAVES"][1], 1)
 for c in sorted(tot):
     s, n = tot[c]
-    print(f"{c:22s} per-wave {s/n/w:10.1f}")
+    print(f"{c:22s} per-launch {s/n:14.0f}  per-wave {s/n/w:10.1f}")
 PY
