@@ -245,8 +245,18 @@ def main():
             out["reverb_roofline"] = {"bound": "hbm", "achieved": rb / t / 1e9 if t > 0 else 0.0,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None,
-                                      "kernel": "reverb_fft_kernel + reverb_mac_kernel",
-                                      "algorithmic_bytes_per_launch": rb, "avg_launch_ms": t * 1e3}
+                                      "kernel": "reverb_fft_kernel + reverb_mac_tiled_kernel",
+                                      "algorithmic_bytes_per_launch": rb, "avg_launch_ms": t * 1e3,
+                                      # the block-tiled form reads each delay-line slot once per tile of 8
+                                      # blocks and keeps the delay line (S*P KB) in the Infinity Cache, so the
+                                      # per-source-block figure above is what it AVOIDS reading; what one
+                                      # launch must move through HBM at least: the delay line once, the IR
+                                      # spectra once, the new slots and wet blocks written
+                                      "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4),
+                                      "multiply_accumulates_per_launch": S * KB * P * B,
+                                      "note": "frac > 1 = delay-line reuse across the blocks of a tile; the kernel "
+                                              "is bound by L2->L1 load bandwidth and packed-f32 FMA issue "
+                                              "(DESIGN.md section 7)"}
         if world == 1 and not args.no_cpu_baseline and ir is None:
             out["cpu_baseline"] = cpu_baseline(jf, wl, hrir, S, args.cpu_sample_blocks)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
