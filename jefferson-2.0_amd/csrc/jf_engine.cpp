@@ -377,13 +377,32 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
 }  // namespace
 
 // =============================================================== C ABI ====
+// Nothing may propagate through the C ABI: host allocations (std::vector, std::string) can throw.
+template <class F>
+static int jf_guard(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        try { g_create_error = "out of host memory"; } catch (...) {}
+        return JF_ERR_NOMEM;
+    } catch (const std::exception &ex) {
+        try { g_create_error = ex.what(); } catch (...) {}
+        return JF_ERR_DEVICE;
+    } catch (...) {
+        return JF_ERR_DEVICE;
+    }
+}
+
 extern "C" {
 
 int jf_engine_create(const jf_config *cfg, const float *hrir, int taps, jf_engine **out) {
+    return jf_guard([&]() -> int {
     return create_engine(cfg, hrir, taps, out);
+    });
 }
 
 int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_engine **out) {
+    return jf_guard([&]() -> int {
     if (!cfg || !hrir_dir || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
     std::vector<float> hrir;
     int taps = 0;
@@ -391,6 +410,7 @@ int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_eng
     int rc = load_hrir_dir(hrir_dir, &hrir, &taps, &err);
     if (rc) return fail(nullptr, rc, err);
     return create_engine(cfg, hrir.data(), taps, out);
+    });
 }
 
 void jf_engine_destroy(jf_engine *e) { destroy_engine(e); }
@@ -402,6 +422,7 @@ int jf_pad_len(const jf_engine *e) { return e ? kN : JF_ERR_ARG; }
 int jf_num_sources(const jf_engine *e) { return e ? e->S : JF_ERR_ARG; }
 
 int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
+    return jf_guard([&]() -> int {
     if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     // The device copy always has length >= PAD_LEN so that the kernel wraps the loop with
@@ -436,9 +457,11 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     else
         JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));
     return JF_OK;
+    });
 }
 
 int jf_source_set_cartesian(jf_engine *e, int src, float x, float y, float z) {
+    return jf_guard([&]() -> int {
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     float rec[5], r;
     int rc = host_from_cartesian(x, y, z, rec, &r);
@@ -447,9 +470,11 @@ int jf_source_set_cartesian(jf_engine *e, int src, float x, float y, float z) {
     std::lock_guard<std::mutex> lk(e->pos_mu);
     e->pos[src] = HostPos{rec[0], rec[1], r, x, y, z};
     return JF_OK;
+    });
 }
 
 int jf_source_set_spherical(jf_engine *e, int src, float ele, float azi, float r) {
+    return jf_guard([&]() -> int {
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     float rec[5];
     host_from_spherical(ele, azi, r, rec);
@@ -458,9 +483,11 @@ int jf_source_set_spherical(jf_engine *e, int src, float ele, float azi, float r
     std::lock_guard<std::mutex> lk(e->pos_mu);
     e->pos[src] = HostPos{rec[0], rec[1], r, rec[2], rec[3], rec[4]};
     return JF_OK;
+    });
 }
 
 int jf_source_get_position(const jf_engine *e, int src, float out[6]) {
+    return jf_guard([&]() -> int {
     if (!valid_src(e, src) || !out) return JF_ERR_ARG;
     jf_engine *m = const_cast<jf_engine *>(e);
     std::lock_guard<std::mutex> lk(m->pos_mu);
@@ -472,40 +499,52 @@ int jf_source_get_position(const jf_engine *e, int src, float out[6]) {
     out[4] = q.y;
     out[5] = q.z;
     return JF_OK;
+    });
 }
 
 int jf_source_reset(jf_engine *e, int src) {
+    return jf_guard([&]() -> int {
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     return reset_sources(e, src);
+    });
 }
 
 int jf_position_from_spherical(float ele, float azi, float r, float out[JF_POS_FLOATS]) {
+    return jf_guard([&]() -> int {
     if (!out) return JF_ERR_ARG;
     host_from_spherical(ele, azi, r, out);
     return JF_OK;
+    });
 }
 
 int jf_position_from_cartesian(float x, float y, float z, float out[JF_POS_FLOATS]) {
+    return jf_guard([&]() -> int {
     if (!out) return JF_ERR_ARG;
     return host_from_cartesian(x, y, z, out, nullptr);
+    });
 }
 
 int jf_positions_from_spherical(size_t n, const float *ele, const float *azi, const float *r, float *out) {
+    return jf_guard([&]() -> int {
     if (n && (!ele || !azi || !r || !out)) return JF_ERR_ARG;
     for (size_t i = 0; i < n; i++) host_from_spherical(ele[i], azi[i], r[i], out + 5 * i);
     return JF_OK;
+    });
 }
 
 int jf_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
+    return jf_guard([&]() -> int {
     if (!idx || !omegas) return JF_ERR_ARG;
     return host_interpolation(ele, azi, idx, omegas);
+    });
 }
 
 int jf_pick_hrtf(float ele, float azi) { return host_pick_hrtf(ele, azi); }
 
 // ---- per-block -----------------------------------------------------------
 int jf_submit_block(jf_engine *e) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a block is already in flight");
     if (e->paused) {  // Audio.cu:101: nothing is consumed, output is silence
@@ -545,24 +584,30 @@ int jf_submit_block(jf_engine *e) {
     JF_HIP(e, hipMemcpyAsync(e->h_out_pinned, e->d_mix, sizeof(float) * 2 * e->B, hipMemcpyDeviceToHost, e->stream));
     e->in_flight = true;
     return JF_OK;
+    });
 }
 
 int jf_collect_block(jf_engine *e, float *out) {
+    return jf_guard([&]() -> int {
     if (!e || !out) return JF_ERR_ARG;
     if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     memcpy(out, e->h_out_pinned, sizeof(float) * 2 * e->B);
     e->in_flight = false;
     return JF_OK;
+    });
 }
 
 int jf_process_block(jf_engine *e, float *out) {
+    return jf_guard([&]() -> int {
     int rc = jf_submit_block(e);
     if (rc) return rc;
     return jf_collect_block(e, out);
+    });
 }
 
 int jf_callback(jf_engine *e, float *out) {
+    return jf_guard([&]() -> int {
     if (!e || !out) return JF_ERR_ARG;
     int rc;
     if (e->have_prev) {
@@ -575,31 +620,39 @@ int jf_callback(jf_engine *e, float *out) {
     if (rc) return rc;
     e->have_prev = true;
     return JF_OK;
+    });
 }
 
 int jf_pa_callback(const void *, void *output, unsigned long frames, const void *, unsigned long, void *user) {
+    return jf_guard([&]() -> int {
     jf_engine *e = (jf_engine *)user;
     if (!output) return 0;
     // a stream opened with another buffer size, or an engine error: hand PortAudio silence, never garbage
     if (!e || frames != (unsigned long)e->B || jf_callback(e, (float *)output) != JF_OK)
         memset(output, 0, sizeof(float) * 2 * frames);
     return 0;
+    });
 }
 
 int jf_set_mode(jf_engine *e, int mode) {
+    return jf_guard([&]() -> int {
     if (!e || (mode != JF_MODE_FD_COMPLEX && mode != JF_MODE_FD_BASIC)) return fail(e, JF_ERR_ARG, "unknown mode");
     e->mode = mode;  // read at the next block, like Data::type (Audio.cu:104)
     return JF_OK;
+    });
 }
 
 int jf_set_pause(jf_engine *e, int paused) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     e->paused = paused != 0;
     return JF_OK;
+    });
 }
 
 // ---- convolution reverb ----------------------------------------------------
 int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
+    return jf_guard([&]() -> int {
     if (!e || (n_ir && !ir) || n_ir > (size_t)1 << 26) return fail(e, JF_ERR_ARG, "bad impulse response");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -650,14 +703,20 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     e->rv_Wr = Wr;
     e->rv_head = 0;
     return reset_sources(e, -1);
+    });
 }
 
 float jf_reverb_rms_gain(const float *signal, size_t n, const float *ir, size_t n_ir) {
     if (!signal || !ir || n == 0 || n_ir == 0) return 1.0f;
-    return host_reverb_rms_gain(signal, n, ir, n_ir);
+    try {
+        return host_reverb_rms_gain(signal, n, ir, n_ir);
+    } catch (...) {
+        return 1.0f;
+    }
 }
 
 int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
+    return jf_guard([&]() -> int {
     if (!e || !reverb_ms) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     double r = 0;
@@ -668,10 +727,12 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
     }
     *reverb_ms = r;
     return JF_OK;
+    });
 }
 
 // ---- batch -----------------------------------------------------------------
 int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *positions) {
+    return jf_guard([&]() -> int {
     if (!e || total_blocks <= 0 || !positions) return fail(e, JF_ERR_ARG, "bad trajectory");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     const size_t bytes = sizeof(float) * 5 * (size_t)e->S * (size_t)total_blocks;
@@ -684,24 +745,30 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     e->traj_blocks = total_blocks;
     JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
     return JF_OK;
+    });
 }
 
 int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     if (n_blocks <= 0 || n_blocks > e->maxK) return fail(e, JF_ERR_ARG, "n_blocks exceeds max_batch_blocks");
     if (first_block < 0 || first_block + n_blocks > e->traj_blocks)
         return fail(e, JF_ERR_ARG, "window outside the uploaded trajectory");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
     return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix);
+    });
 }
 
 int jf_synchronize(jf_engine *e) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     return JF_OK;
+    });
 }
 
 int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *out_mix) {
+    return jf_guard([&]() -> int {
     if (!e || !positions || !out_mix || n_blocks <= 0) return fail(e, JF_ERR_ARG, "bad batch arguments");
     int rc = jf_batch_upload_positions(e, n_blocks, positions);
     if (rc) return rc;
@@ -715,6 +782,7 @@ int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *
         JF_HIP(e, hipStreamSynchronize(e->stream));
     }
     return JF_OK;
+    });
 }
 
 float *jf_batch_mix_device(jf_engine *e) { return e ? e->d_mix : nullptr; }
@@ -722,14 +790,17 @@ float *jf_batch_partial_device(jf_engine *e) { return e ? e->d_partial : nullptr
 void *jf_engine_stream(jf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int jf_profile_enable(jf_engine *e, int enable) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     e->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     e->ev_used = 0;
     return JF_OK;
+    });
 }
 
 int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches) {
+    return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     double f = 0, p = 0, m = 0;
@@ -749,35 +820,45 @@ int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix
     if (mix_ms) *mix_ms = m;
     if (launches) *launches = (long)e->ev_used;
     return JF_OK;
+    });
 }
 
 // ---- debugging taps -----------------------------------------------------------
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes) {
+    return jf_guard([&]() -> int {
     if (!e || !device_ptr || !host) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     JF_HIP(e, hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost));
     return JF_OK;
+    });
 }
 
 int jf_debug_set_rt_max_sources(jf_engine *e, int n) {
+    return jf_guard([&]() -> int {
     if (!e || n < 0) return JF_ERR_ARG;
     e->rt_max_sources = n;
     return JF_OK;
+    });
 }
 
 int jf_debug_set_source_group(jf_engine *e, int group) {
+    return jf_guard([&]() -> int {
     if (!e || group < 0 || (group > 0 && e->S % group)) return JF_ERR_ARG;
     e->src_group = group;
     return JF_OK;
+    });
 }
 
 int jf_debug_set_reverb_form(jf_engine *e, int form) {
+    return jf_guard([&]() -> int {
     if (!e || form < 0 || form > 3) return JF_ERR_ARG;
     e->rv_form = form;
     return JF_OK;
+    });
 }
 
 int jf_debug_read_table(jf_engine *e, float *out) {
+    return jf_guard([&]() -> int {
     if (!e || !out) return JF_ERR_ARG;
     std::vector<float4> h((size_t)kNumHrtf * 512);
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -802,10 +883,12 @@ int jf_debug_read_table(jf_engine *e, float *out) {
         }
     }
     return JF_OK;
+    });
 }
 
 int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *azi, int *rows, float *weights,
                            int *nterms) {
+    return jf_guard([&]() -> int {
     if (!e || n <= 0 || !ele || !azi || !rows || !weights || !nterms) return JF_ERR_ARG;
     float *d_e = nullptr, *d_a = nullptr, *d_w = nullptr;
     int *d_r = nullptr, *d_n = nullptr;
@@ -831,9 +914,11 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
     (void)hipFree(d_r);
     (void)hipFree(d_n);
     return rc;
+    });
 }
 
 int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spectra) {
+    return jf_guard([&]() -> int {
     if (!e || n <= 0 || !windows || !spectra) return JF_ERR_ARG;
     float *d_w = nullptr;
     float2 *d_s = nullptr;
@@ -850,23 +935,28 @@ int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spect
     (void)hipFree(d_w);
     (void)hipFree(d_s);
     return rc;
+    });
 }
 
 // ---- WAV -----------------------------------------------------------------------
 int jf_wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate) {
+    return jf_guard([&]() -> int {
     if (!path || !out || !n_frames) return JF_ERR_ARG;
     std::string err;
     int rc = wav_read_mono(path, out, n_frames, sample_rate, &err);
     if (rc) g_create_error = err;
     return rc;
+    });
 }
 
 int jf_wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate) {
+    return jf_guard([&]() -> int {
     if (!path || (!interleaved && n_frames)) return JF_ERR_ARG;
     std::string err;
     int rc = wav_write_stereo24(path, interleaved, n_frames, sample_rate, &err);
     if (rc) g_create_error = err;
     return rc;
+    });
 }
 
 void jf_free(void *p) { free(p); }

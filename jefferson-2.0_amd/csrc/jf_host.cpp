@@ -184,6 +184,13 @@ int wav_open(const char *path, FILE **fp, WavInfo *wi, std::string *err) {
         } else if (!memcmp(ch, "data", 4)) {
             wi->data_off = ftell(f);
             wi->data_bytes = sz;
+            // never trust the header for an allocation: a truncated (or hostile) file yields what is present
+            if (wi->data_off >= 0 && fseek(f, 0, SEEK_END) == 0) {
+                const long end = ftell(f);
+                const size_t present = end > wi->data_off ? (size_t)(end - wi->data_off) : 0;
+                if (wi->data_bytes > present) wi->data_bytes = present;
+                fseek(f, wi->data_off, SEEK_SET);
+            }
             if (!have_fmt) break;
             *fp = f;
             return JF_OK;

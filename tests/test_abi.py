@@ -135,6 +135,42 @@ def test_wav_reader_scaling_and_stereo_downmix(jf, tmp_path):
         jf.wav_read_mono(str(tmp_path / "junk.wav"))
 
 
+def test_wav_reader_survives_malformed_files(jf, tmp_path):
+    """The loader is on the drop-in boundary (cudaPart.cu:21-63 took any path from the command line): random
+    corruptions and truncations of valid files must end in an error code or a bounded result, never a crash,
+    an exception through the C ABI or an allocation sized by a lying header."""
+    rng = np.random.default_rng(7)
+    base = []
+    for sw, nch in ((2, 1), (3, 2), (1, 1)):
+        q = str(tmp_path / f"b{sw}{nch}.wav")
+        _write_wav(q, rng.integers(0, 256, 600 * sw * nch, dtype=np.uint8).tobytes(), sw, nch=nch)
+        base.append(open(q, "rb").read())
+    p = str(tmp_path / "fuzz.wav")
+    outcomes = {"ok": 0, "err": 0}
+    for trial in range(400):
+        b = bytearray(base[trial % len(base)])
+        kind = trial % 4
+        if kind == 0:      # flip a few header bytes
+            for _ in range(3):
+                b[rng.integers(0, 44)] = rng.integers(0, 256)
+        elif kind == 1:    # truncate anywhere
+            b = b[: rng.integers(0, len(b))]
+        elif kind == 2:    # sizes that lie (4 GB data chunk, huge fmt chunk)
+            off = 40 if rng.integers(0, 2) else 16
+            b[off:off + 4] = struct.pack("<I", int(rng.integers(2 ** 31, 2 ** 32)))
+        else:              # random bytes after a valid RIFF/WAVE tag
+            b = bytearray(b[:12]) + bytearray(rng.integers(0, 256, 200, dtype=np.uint8).tobytes())
+        with open(p, "wb") as f:
+            f.write(bytes(b))
+        try:
+            x, _ = jf.wav_read_mono(p)
+            assert x.size <= len(b)            # never more samples than bytes present
+            outcomes["ok"] += 1
+        except jf.JfError:
+            outcomes["err"] += 1
+    assert outcomes["ok"] > 20 and outcomes["err"] > 20
+
+
 def test_wav_reader_on_the_castanets_fixture(jf, castanets, tmp_path):
     ex = np.load(os.path.join(GOLD, "castanets_441_excerpt_i24.npy"))
     raw = b"".join(struct.pack("<i", int(v))[:3] for v in ex[:5000])
