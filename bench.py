@@ -79,8 +79,10 @@ def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    # defaults: 256 warm-up steps (80 ms) because the first ~100 steps after an idle GPU run 10-15 % slower
+    # (clock ramp; profiles/r01_experiments.md), then 512 timed steps = 32 768 blocks x 1024 sources
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
     ap.add_argument("--reverb", action="store_true",
                     help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
@@ -143,7 +145,12 @@ def main():
         eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
     if ir is not None:
         eng.set_reverb(ir, 0.5)
-    pos = wl.trajectories(jf, src_ids, total_blocks, moving=not args.stationary)
+    # The trajectories are periodic (azimuth + 1 degree per block: 360 blocks), so a long run walks one
+    # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
+    # costs the same 20 B x sources x lcm(360, blocks per step) of host and device memory.
+    period = int(np.lcm(360, KB))
+    n_pos = total_blocks if total_blocks <= period else period
+    pos = wl.trajectories(jf, src_ids, n_pos, moving=not args.stationary)
     eng.upload_positions(pos)
 
     # The mix lands in a torch tensor so that RCCL can reduce it in place.  Two buffers: the
@@ -159,7 +166,7 @@ def main():
             with torch.cuda.stream(ext):
                 pending[j].wait()  # stream-level wait: the engine stream must not overwrite mixes[j] early
             pending[j] = None
-        eng.batch_run(i * KB, KB, mixes[j].data_ptr())
+        eng.batch_run((i * KB) % n_pos, KB, mixes[j].data_ptr())
         if world > 1:
             with torch.cuda.stream(ext):  # the collective is ordered after the kernels just enqueued
                 if backend == "nccl":
@@ -201,8 +208,21 @@ def main():
         frames = world * S * KB * K * B
         value = frames / dt
         # algorithmic bytes of the timed windows of THIS rank (every rank has the same mix of cases)
-        first_old = pos[W * KB - 1, :, :2].astype(np.int64) if W > 0 else None
-        abytes, rows, items = wl.algorithmic_bytes(jf, pos[W * KB:], B, first_old=first_old)
+        if n_pos == total_blocks:
+            first_old = pos[W * KB - 1, :, :2].astype(np.int64) if W > 0 else None
+            abytes, rows, items = wl.algorithmic_bytes(jf, pos[W * KB:], B, first_old=first_old)
+        else:
+            # the run walked the uploaded period cyclically: price each step of the period once (its
+            # predecessor block is the one before it on the circle) and count how often each was timed
+            terms = wl.n_terms_table(jf)
+            per_step = []
+            for j in range(n_pos // KB):
+                first_old = pos[(j * KB - 1) % n_pos, :, :2].astype(np.int64)
+                per_step.append(wl.algorithmic_bytes(jf, pos[j * KB:(j + 1) * KB], B, first_old=first_old, terms=terms))
+            abytes = rows = items = 0
+            for i in range(W, W + K):
+                a_, r_, i_ = per_step[i % (n_pos // KB)]
+                abytes, rows, items = abytes + a_, rows + r_, items + i_
         fused_s = prof["fused_ms"] * 1e-3
         achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         traffic = None
