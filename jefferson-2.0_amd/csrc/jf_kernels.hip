@@ -61,6 +61,19 @@ JF_DEV float2 cmulk(float2 v, float c, float s) {
     return make_float2(v.x * c - v.y * d, v.x * d + v.y * c);
 }
 
+// v * (h + i*DIR*h) and v * (-h + i*DIR*h), h = sqrt(1/2): an add, a subtract and two multiplies
+// (2.7 issue cycles each) instead of two multiplies and two FMAs (4.3)
+template <int DIR>
+JF_DEV float2 cmul_h(float2 v) {
+    constexpr float h = 0.70710678118654752440f;
+    return DIR > 0 ? make_float2(h * (v.x - v.y), h * (v.x + v.y)) : make_float2(h * (v.x + v.y), h * (v.y - v.x));
+}
+template <int DIR>
+JF_DEV float2 cmul_nh(float2 v) {
+    constexpr float h = 0.70710678118654752440f;
+    return DIR > 0 ? make_float2(-h * (v.x + v.y), h * (v.x - v.y)) : make_float2(h * (v.y - v.x), -h * (v.x + v.y));
+}
+
 // v * (DIR * i)
 template <int DIR>
 JF_DEV float2 cmuli(float2 v) {
@@ -80,14 +93,13 @@ JF_DEV void fft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
 // in-register 8-point DFT, natural order in and out
 template <int DIR>
 JF_DEV void fft8(float2 (&v)[8]) {
-    constexpr float h = 0.70710678118654752440f;
     float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
     float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     fft4<DIR>(e0, e1, e2, e3);
     fft4<DIR>(o0, o1, o2, o3);
-    o1 = cmulk<DIR>(o1, h, h);
+    o1 = cmul_h<DIR>(o1);
     o2 = cmuli<DIR>(o2);
-    o3 = cmulk<DIR>(o3, -h, h);
+    o3 = cmul_nh<DIR>(o3);
     v[0] = cadd(e0, o0);
     v[4] = csub(e0, o0);
     v[1] = cadd(e1, o1);
@@ -107,20 +119,19 @@ JF_DEV void cswap(float2 &a, float2 &b) {
 // in-register 16-point DFT, natural order in and out
 template <int DIR>
 JF_DEV void fft16(float2 (&v)[16]) {
-    constexpr float h = 0.70710678118654752440f;
     constexpr float c1 = 0.92387953251128675613f;  // cos(pi/8)
     constexpr float s1 = 0.38268343236508977173f;  // sin(pi/8)
 #pragma unroll
     for (int n1 = 0; n1 < 4; n1++) fft4<DIR>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
     // v[n1 + 4*k2] *= W16^(n1*k2)
     v[5] = cmulk<DIR>(v[5], c1, s1);     // 1
-    v[9] = cmulk<DIR>(v[9], h, h);       // 2
+    v[9] = cmul_h<DIR>(v[9]);            // 2
     v[13] = cmulk<DIR>(v[13], s1, c1);   // 3
-    v[6] = cmulk<DIR>(v[6], h, h);       // 2
+    v[6] = cmul_h<DIR>(v[6]);            // 2
     v[10] = cmuli<DIR>(v[10]);           // 4
-    v[14] = cmulk<DIR>(v[14], -h, h);    // 6
+    v[14] = cmul_nh<DIR>(v[14]);         // 6
     v[7] = cmulk<DIR>(v[7], s1, c1);     // 3
-    v[11] = cmulk<DIR>(v[11], -h, h);    // 6
+    v[11] = cmul_nh<DIR>(v[11]);         // 6
     v[15] = cmulk<DIR>(v[15], -c1, -s1); // 9
 #pragma unroll
     for (int k2 = 0; k2 < 4; k2++) fft4<DIR>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
@@ -151,8 +162,9 @@ JF_DEV float quad_sum(float v) {
 // ------------------------------------------------------------ forward FFT --
 // Real FFT of 1024 samples through a 512-point complex FFT.
 // In : z[r] = (x[2(lane+64r)], x[2(lane+64r)+1]), r = 0..7
-// Out: X[q] = bin (lane + 64 q), q = 0..7, UNNORMALISED; on lane 0, X[0] is
-//      packed as (X[0].re, X[512].re) (both bins are real).
+// Out: X[q] = TWICE bin (lane + 64 q), q = 0..7, unnormalised (the halving of the split pass is left to
+//      the caller's scale factor: a power of two, so nothing rounds differently); on lane 0, X[0] is
+//      packed as 2 (X[0].re, X[512].re) (both bins are real).
 // buf: >= 576 float2 of this wave's LDS; tw: the twiddle pack (jf_device.h) in LDS.
 JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const float2 *tw, int lane) {
     // pass A (sub-length 1): no twiddles; store 8 contiguous, row padded 8 -> 9
@@ -183,7 +195,7 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
     for (int r = 1; r < 8; r++) u[r] = ctw<-1>(u[r], tw[kTwWC + 64 * r + lane]);
     fft8<-1>(u);
     JF_WAVE_LDS_SYNC();
-    // split: X[k] = E + (-i) W^k O, E = (Z[k] + conj Z[512-k])/2, O = (Z[k] - conj Z[512-k])/2
+    // split: 2 X[k] = E + (-i) W^k O, E = Z[k] + conj Z[512-k], O = Z[k] - conj Z[512-k]
     const int src = (64 - lane) & 63;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -191,14 +203,14 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
         const float2 own = u[(8 - q) & 7];       // lane 0: Z[(512 - 64 q) mod 512]
         if (lane == 0) zm = own;
         const float2 zk = u[q];
-        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 e = make_float2(zk.x + zm.x, zk.y - zm.y);
+        const float2 o = make_float2(zk.x - zm.x, zk.y + zm.y);
         // (-i) * conj(W^k) * o
         const float2 wo = cmulc(o, tw[kTwU + 64 * q + lane]);
         X[q] = make_float2(e.x + wo.y, e.y - wo.x);
     }
     // lane 0: bins 0 and 512 are real: Re(Z0) +/- Im(Z0)
-    X[0] = lane == 0 ? make_float2(u[0].x + u[0].y, u[0].x - u[0].y) : X[0];
+    X[0] = lane == 0 ? make_float2(2.0f * (u[0].x + u[0].y), 2.0f * (u[0].x - u[0].y)) : X[0];
 }
 
 // ------------------------------------------------------------ inverse FFT --
@@ -407,6 +419,15 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
             z[r] = make_float2(xv[0], xv[1]);
         }
     }
+    // ---- distance factor while the window loads are in flight (needs the descriptor only).  The 1/N of
+    // the forward transform (GPUSoundSource.cu:344-346) and the 1/2 of its split pass ride on 1/frac:
+    // powers of two, exact
+    float2 dq[8];
+    const float sinv = inv_frac * (1.0f / 2048.0f);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dq[q] = distance_factor(c_hi, c_lo, sinv, lane + 64 * q);
+    const float d512x = distance_factor(c_hi, c_lo, sinv, 512).x;
+    __builtin_amdgcn_sched_barrier(0);
     if (b == P.K - 1) {
         // last block of the call: leave the window and the counters for the next call
         float *ho = P.hist_out + (size_t)s * kN;
@@ -430,15 +451,10 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
     {
         float2 X[8];
         rfft1024_wave(z, X, buf, s_tw, lane);
-        constexpr float scale = 1.0f / 1024.0f;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const float2 d = distance_factor(c_hi, c_lo, inv_frac, lane + 64 * q);
-            xd[q] = cmul(make_float2(X[q].x * scale, X[q].y * scale), d);
-        }
+        for (int q = 0; q < 8; q++) xd[q] = cmul(X[q], dq[q]);
         {
-            const float2 d512 = distance_factor(c_hi, c_lo, inv_frac, 512);
-            const float2 x0 = make_float2(X[0].x * scale * inv_frac, X[0].y * scale * d512.x);
+            const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
             xd[0] = lane == 0 ? x0 : xd[0];
         }
     }
@@ -801,7 +817,8 @@ __global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
-        htab[(size_t)row * 512 + lane + 64 * q] = make_float4(Xe[0][q].x, Xe[0][q].y, Xe[1][q].x, Xe[1][q].y);
+        htab[(size_t)row * 512 + lane + 64 * q] =  // rfft1024_wave returns twice the spectrum
+            make_float4(0.5f * Xe[0][q].x, 0.5f * Xe[0][q].y, 0.5f * Xe[1][q].x, 0.5f * Xe[1][q].y);
 }
 
 // parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
@@ -818,6 +835,8 @@ __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 8; r++) z[r] = *reinterpret_cast<const float2 *>(x + 2 * (lane + 64 * r));
     rfft1024_wave(z, X, s_buf, s_tw, lane);
+#pragma unroll
+    for (int q = 0; q < 8; q++) X[q] = make_float2(0.5f * X[q].x, 0.5f * X[q].y);  // twice the spectrum
     float2 *o = spec + (size_t)blockIdx.x * kNc;
 #pragma unroll
     for (int q = 0; q < 8; q++) {

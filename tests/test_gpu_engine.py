@@ -224,24 +224,26 @@ def test_full_size_moving_workload_properties(jf, hrir):
     e2.close()
     assert np.array_equal(half, (0.5 * mix).astype(np.float32))
 
-    # (4) the default grouping (4 consecutive sources summed in registers per wavefront) is the same
-    # sum in another association: groups of 4 in source order, 16 mix groups of 16 partials, in order
-    e3 = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
-    e3.set_source_group(4)
-    for s in ids:
-        e3.set_signal(int(s), sigs[s])
-    grouped = e3.process_batch(pos)
-    e3.close()
-    g4 = np.zeros((K, S // 4, 2 * B), np.float32)
-    for j in range(4):
-        g4 = g4 + part[:, j::4] if j == 0 else g4 + part[:, j::4]
-    acc = np.zeros((K, 2 * B), np.float32)
-    for g in range(16):
-        gsum = np.zeros((K, 2 * B), np.float32)
-        for u in range(16 * g, 16 * (g + 1)):
-            gsum = gsum + g4[:, u]
-        acc = gsum if g == 0 else acc + gsum
-    assert np.array_equal(grouped, acc)
+    # (4) the default grouping (G = 4 or 8 consecutive sources summed in registers per wavefront) is the same
+    # sum in another association: groups of G in source order, 16 mix groups of S/G/16 partials, in order
+    for G in (4, 8):
+        e3 = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+        e3.set_source_group(G)
+        for s in ids:
+            e3.set_signal(int(s), sigs[s])
+        grouped = e3.process_batch(pos)
+        e3.close()
+        gg = np.zeros((K, S // G, 2 * B), np.float32)
+        for j in range(G):
+            gg = gg + part[:, j::G] if j == 0 else gg + part[:, j::G]
+        per = S // G // 16
+        acc = np.zeros((K, 2 * B), np.float32)
+        for g in range(16):
+            gsum = np.zeros((K, 2 * B), np.float32)
+            for u in range(per * g, per * (g + 1)):
+                gsum = gsum + gg[:, u]
+            acc = gsum if g == 0 else acc + gsum
+        assert np.array_equal(grouped, acc), G
 
 
 def _write_compact_dir(root, hrir):
