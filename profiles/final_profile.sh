@@ -8,11 +8,11 @@ mkdir -p $OUT
 cd $REPO
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --stationary --no-cpu-baseline > $OUT/bench_stationary.json 2>> $OUT/bench.err; echo "bench stationary rc=$?"
-timeout -k 10 300 python3 bench.py --reverb --steps 16 --warmup 2 > $OUT/bench_reverb.json 2>> $OUT/bench.err; echo "bench reverb rc=$?"
+timeout -k 10 300 python3 bench.py --reverb --steps 256 --warmup 128 > $OUT/bench_reverb.json 2>> $OUT/bench.err; echo "bench reverb rc=$?"
 timeout -k 10 120 python3 profiles/latency.py > $OUT/latency.txt 2>> $OUT/bench.err; echo "latency rc=$?"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1; echo "trace rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reverb -- python3 $REPO/bench.py --reverb --steps 16 --warmup 2 --no-cpu-baseline > $OUT/trace_reverb.log 2>&1; echo "trace reverb rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 64 --warmup 200 --no-cpu-baseline > $OUT/trace.log 2>&1; echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reverb -- python3 $REPO/bench.py --reverb --steps 64 --warmup 128 --no-cpu-baseline > $OUT/trace_reverb.log 2>&1; echo "trace reverb rc=$?"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-24)
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.log 2>&1; echo "pmc $N rc=$?"
