@@ -134,7 +134,6 @@ def main():
         rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
         ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
         ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
-    total_blocks = (K + W) * KB
     src_lo = rank * S  # weak scaling: every rank brings its own 1024 sources
     src_ids = np.arange(src_lo, src_lo + S)
 
@@ -149,7 +148,7 @@ def main():
     # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
     # costs the same 20 B x sources x lcm(360, blocks per step) of host and device memory.
     period = int(np.lcm(360, KB))
-    n_pos = total_blocks if total_blocks <= period else period
+    n_pos = period
     pos = wl.trajectories(jf, src_ids, n_pos, moving=not args.stationary)
     eng.upload_positions(pos)
 
@@ -185,13 +184,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(W):
+    # Clock ramp: the first ~100 steps after an idle GPU run 10-15 % slower.  Whatever --warmup says, at
+    # least 256 untimed steps run before the timed region; the extra ones are reported as "prewarm_steps".
+    prewarm = max(0, 256 - W)
+    for i in range(prewarm):
         step(i)
+    fence()
+    for i in range(W):
+        step(prewarm + i)
     fence()
     if not os.environ.get("JF_NO_EVENTS"):  # tuning runs: how much do the event records cost?
         eng.profile_enable(2 if ir is not None else 1)  # level 1: two events around the fused kernel
     t0 = time.perf_counter()
-    for i in range(W, W + K):
+    for i in range(prewarm + W, prewarm + W + K):
         step(i)
     fence()
     dt = time.perf_counter() - t0
@@ -208,21 +213,17 @@ def main():
         frames = world * S * KB * K * B
         value = frames / dt
         # algorithmic bytes of the timed windows of THIS rank (every rank has the same mix of cases)
-        if n_pos == total_blocks:
-            first_old = pos[W * KB - 1, :, :2].astype(np.int64) if W > 0 else None
-            abytes, rows, items = wl.algorithmic_bytes(jf, pos[W * KB:], B, first_old=first_old)
-        else:
-            # the run walked the uploaded period cyclically: price each step of the period once (its
-            # predecessor block is the one before it on the circle) and count how often each was timed
-            terms = wl.n_terms_table(jf)
-            per_step = []
-            for j in range(n_pos // KB):
-                first_old = pos[(j * KB - 1) % n_pos, :, :2].astype(np.int64)
-                per_step.append(wl.algorithmic_bytes(jf, pos[j * KB:(j + 1) * KB], B, first_old=first_old, terms=terms))
-            abytes = rows = items = 0
-            for i in range(W, W + K):
-                a_, r_, i_ = per_step[i % (n_pos // KB)]
-                abytes, rows, items = abytes + a_, rows + r_, items + i_
+        # the run walks the uploaded period cyclically: price each step of the period once (its
+        # predecessor block is the one before it on the circle) and count how often each was timed
+        terms = wl.n_terms_table(jf)
+        per_step = []
+        for j in range(n_pos // KB):
+            first_old = pos[(j * KB - 1) % n_pos, :, :2].astype(np.int64)
+            per_step.append(wl.algorithmic_bytes(jf, pos[j * KB:(j + 1) * KB], B, first_old=first_old, terms=terms))
+        abytes = rows = items = 0
+        for i in range(prewarm + W, prewarm + W + K):
+            a_, r_, i_ = per_step[i % (n_pos // KB)]
+            abytes, rows, items = abytes + a_, rows + r_, items + i_
         fused_s = prof["fused_ms"] * 1e-3
         achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         traffic = None
@@ -235,6 +236,7 @@ def main():
         out = {
             "metric": "source-frames/s (sources x frames/sec) at 256-sample blocks",
             "value": value, "unit": "source-frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "prewarm_steps": prewarm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
