@@ -144,19 +144,28 @@ JF_DEV void fft16(float2 (&v)[16]) {
     cswap(v[11], v[14]);
 }
 
-JF_DEV float bperm(int src_lane, float v) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-JF_DEV float2 bperm2(int src_lane, float2 v) {
-    return make_float2(bperm(src_lane, v.x), bperm(src_lane, v.y));
-}
-
 // sum over the 4 lanes of a quad, result in all 4 (DPP quad_perm)
 JF_DEV float quad_sum(float v) {
     // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
     return v;
+}
+
+// Hermitian mirror across the wave: out[j] = in[7 - j] of lane 64 - lane; lane 0, whose partner would be
+// "lane 64", gets its own in[(8 - j) & 7] (bins 0 / 512 and the multiples of 64 live on lane 0).  Through
+// LDS rather than ds_bpermute: lane l writes slot l + 64 q, lane 0 also writes in[0] to slot 512, and
+// every lane reads slots (64 - l) + 64 (7 - j) -- for lane 0 that is 64 (8 - j): exactly its own values,
+// so the lane-0 exception costs one masked store instead of two selects per value.
+JF_DEV void mirror8(float2 *buf, const float2 (&in)[8], float2 (&out)[8], int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) buf[lane + 64 * q] = in[q];
+    if (lane == 0) buf[512] = in[0];
+    JF_WAVE_LDS_SYNC();
+    const float2 *rd = buf + (64 - lane);
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = rd[64 * (7 - j)];
+    JF_WAVE_LDS_SYNC();
 }
 
 // ------------------------------------------------------------ forward FFT --
@@ -196,12 +205,11 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
     fft8<-1>(u);
     JF_WAVE_LDS_SYNC();
     // split: 2 X[k] = E + (-i) W^k O, E = Z[k] + conj Z[512-k], O = Z[k] - conj Z[512-k]
-    const int src = (64 - lane) & 63;
+    float2 um[8];  // lanes >= 1: Z[512 - k]; lane 0: Z[(512 - 64 q) mod 512]
+    mirror8(buf, u, um, lane);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        float2 zm = bperm2(src, u[7 - q]);       // lanes >= 1: Z[512 - k]
-        const float2 own = u[(8 - q) & 7];       // lane 0: Z[(512 - 64 q) mod 512]
-        if (lane == 0) zm = own;
+        const float2 zm = um[q];
         const float2 zk = u[q];
         const float2 e = make_float2(zk.x + zm.x, zk.y - zm.y);
         const float2 o = make_float2(zk.x - zm.x, zk.y + zm.y);
@@ -349,14 +357,11 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
     else
         filtered_bins<1>(htab, rows, w, xd, v, mir, lane);
     // upper half: Z[lane + 64 r], r = 8..15, lives mirrored on lane 64 - lane
-    const int src = (64 - lane) & 63;
+    // (lane 0: r = 8 -> Z[512], else Z[N - 64 (16 - r)])
+    float2 up[8];
+    mirror8(buf, mir, up, lane);
 #pragma unroll
-    for (int r = 8; r < 16; r++) {
-        float2 z = bperm2(src, mir[15 - r]);
-        const float2 own = mir[(16 - r) & 7];  // lane 0: r = 8 -> Z[512], else Z[N - 64 (16 - r)]
-        if (lane == 0) z = own;
-        v[r] = z;
-    }
+    for (int r = 8; r < 16; r++) v[r] = up[r - 8];
     ifft1024_lastq_wave(v, buf, tw, lane);
 }
 
