@@ -144,12 +144,26 @@ JF_DEV void fft16(float2 (&v)[16]) {
     cswap(v[11], v[14]);
 }
 
-// sum over the 4 lanes of a quad, result in all 4 (DPP quad_perm)
-JF_DEV float quad_sum(float v) {
-    // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    return v;
+// Sum over the 4 lanes of a quad, result in all 4 (DPP quad_perm), for two complex values at once.
+// Written as asm: the compiler turns a third of the second-step adds into v_mov_b32_dpp + v_add_f32.  A DPP
+// source written by one of the two preceding VALU instructions is a hazard the compiler cannot see inside
+// asm; with four values per step the second step is already four instructions behind the first, so only the
+// entry needs its two wait states spelled out.
+JF_DEV void quad_sum4(float2 &a, float2 &b) {
+    float ax, ay, bx, by;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(ax), "=&v"(ay), "=&v"(bx), "=&v"(by)
+        : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    a = make_float2(ax, ay);
+    b = make_float2(bx, by);
 }
 
 // Hermitian mirror across the wave: out[j] = in[7 - j] of lane 64 - lane; lane 0, whose partner would be
@@ -262,10 +276,12 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
     fft16<+1>(v);  // s_a[i + 16 t]
     // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const float2 w = tw[kTwW3 + 64 * t + lane];
-        const float2 p = cmul(v[t], w);
-        v[t] = make_float2(quad_sum(p.x), quad_sum(p.y));
+    for (int t = 0; t < 16; t += 2) {
+        float2 p0 = cmul(v[t], tw[kTwW3 + 64 * t + lane]);
+        float2 p1 = cmul(v[t + 1], tw[kTwW3 + 64 * (t + 1) + lane]);
+        quad_sum4(p0, p1);
+        v[t] = p0;
+        v[t + 1] = p1;
     }
 }
 
