@@ -144,27 +144,41 @@ JF_DEV void fft16(float2 (&v)[16]) {
     cswap(v[11], v[14]);
 }
 
-// Sum over the 4 lanes of a quad, result in all 4 (DPP quad_perm), for two complex values at once.
-// Written as asm: the compiler turns a third of the second-step adds into v_mov_b32_dpp + v_add_f32.  A DPP
-// source written by one of the two preceding VALU instructions is a hazard the compiler cannot see inside
-// asm; with four values per step the second step is already four instructions behind the first, so only the
-// entry needs its two wait states spelled out.
-JF_DEV void quad_sum4(float2 &a, float2 &b) {
-    float ax, ay, bx, by;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(ax), "=&v"(ay), "=&v"(bx), "=&v"(by)
-        : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
-    a = make_float2(ax, ay);
-    b = make_float2(bx, by);
+// keep + (send of the lane quad_perm points at), as DPP adds, two complex values (or one) per asm block.
+// Written as asm: the compiler turns a third of such adds into v_mov_b32_dpp + v_add_f32.  A DPP source
+// written by one of the two preceding VALU instructions is a hazard the compiler cannot see inside asm:
+// the two wait states are spelled out at the entry of each block.
+// XOR1: partner lane = lane ^ 1 (quad_perm [1,0,3,2]); else lane ^ 2 (quad_perm [2,3,0,1]).
+#define JF_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define JF_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+template <bool XOR1>
+JF_DEV void quad_exchange_add(float2 &k0, float2 s0, float2 &k1, float2 s1) {
+    if (XOR1)
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %4, %0 " JF_QP1 "\n\tv_add_f32_dpp %1, %5, %1 " JF_QP1 "\n\t"
+            "v_add_f32_dpp %2, %6, %2 " JF_QP1 "\n\tv_add_f32_dpp %3, %7, %3 " JF_QP1
+            : "+v"(k0.x), "+v"(k0.y), "+v"(k1.x), "+v"(k1.y)
+            : "v"(s0.x), "v"(s0.y), "v"(s1.x), "v"(s1.y));
+    else
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %4, %0 " JF_QP2 "\n\tv_add_f32_dpp %1, %5, %1 " JF_QP2 "\n\t"
+            "v_add_f32_dpp %2, %6, %2 " JF_QP2 "\n\tv_add_f32_dpp %3, %7, %3 " JF_QP2
+            : "+v"(k0.x), "+v"(k0.y), "+v"(k1.x), "+v"(k1.y)
+            : "v"(s0.x), "v"(s0.y), "v"(s1.x), "v"(s1.y));
 }
+template <bool XOR1>
+JF_DEV void quad_exchange_add(float2 &k0, float2 s0) {
+    if (XOR1)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %0 " JF_QP1 "\n\tv_add_f32_dpp %1, %3, %1 " JF_QP1
+            : "+v"(k0.x), "+v"(k0.y)
+            : "v"(s0.x), "v"(s0.y));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %0 " JF_QP2 "\n\tv_add_f32_dpp %1, %3, %1 " JF_QP2
+            : "+v"(k0.x), "+v"(k0.y)
+            : "v"(s0.x), "v"(s0.y));
+}
+#undef JF_QP1
+#undef JF_QP2
 
 // Hermitian mirror across the wave: out[j] = in[7 - j] of lane 64 - lane; lane 0, whose partner would be
 // "lane 64", gets its own in[(8 - j) & 7] (bins 0 / 512 and the multiples of 64 live on lane 0).  Through
@@ -238,9 +252,10 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
 // ------------------------------------------------------------ inverse FFT --
 // Last quarter of the unnormalised inverse 1024-point complex transform.
 // In : Zin[r] = Z[lane + 64 r], r = 0..15.
-// Out: v[t] (t = 0..15) = y[768 + (lane>>2) + 16 t], identical in the 4 lanes
-//      of a quad.  buf: >= 1088 float2 of this wave's LDS.
-JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, int lane) {
+// Out: out[j] = y[1024 - B + (lane>>2) + 16 (NOUT a + j)], a = lane & 3, j < NOUT = B / 64: this lane's
+//      frames of the block.  buf: >= 1088 float2 of this wave's LDS.
+template <int NOUT>
+JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *buf, const float2 *tw, int lane) {
     const int a = lane & 3, i = lane >> 2;
     // lane (i, a) holds S_a[i + 16 r] = Z[4 (i + 16 r) + a]: 16-point inverse over r
     fft16<+1>(v);
@@ -274,15 +289,31 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 *buf, const float2 *tw, 
     JF_WAVE_LDS_SYNC();
 #endif
     fft16<+1>(v);  // s_a[i + 16 t]
-    // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t
+    // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t: the pruned last radix-4, a sum
+    // over the 4 lanes of a quad.  Only t >= T0 is in the block, and lane a keeps t = T0 + a NOUT + j only, so
+    // the sum is a reduce-scatter: exchange with lane ^ 2 for the half of the t's this lane's pair keeps,
+    // then with lane ^ 1 for its own quarter (3 NOUT DPP adds per component instead of 8 NOUT + selects).
+    constexpr int T0 = 16 - 4 * NOUT;
+    const bool hi = (lane & 2) != 0, odd = (lane & 1) != 0;
+    float2 s[2 * NOUT];
 #pragma unroll
-    for (int t = 0; t < 16; t += 2) {
-        float2 p0 = cmul(v[t], tw[kTwW3 + 64 * t + lane]);
-        float2 p1 = cmul(v[t + 1], tw[kTwW3 + 64 * (t + 1) + lane]);
-        quad_sum4(p0, p1);
-        v[t] = p0;
-        v[t + 1] = p1;
+    for (int m = 0; m < 2 * NOUT; m++) {
+        const int t0 = T0 + m, t1 = T0 + 2 * NOUT + m;
+        const float2 p0 = cmul(v[t0], tw[kTwW3 + 64 * t0 + lane]);
+        const float2 p1 = cmul(v[t1], tw[kTwW3 + 64 * t1 + lane]);
+        s[m] = hi ? p1 : p0;      // kept
+        v[m] = hi ? p0 : p1;      // sent to lane ^ 2 (v[] reused as scratch)
     }
+#pragma unroll
+    for (int m = 0; m < 2 * NOUT; m += 2) quad_exchange_add<false>(s[m], v[m], s[m + 1], v[m + 1]);
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) {
+        out[j] = odd ? s[NOUT + j] : s[j];
+        v[j] = odd ? s[j] : s[NOUT + j];
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < NOUT; j += 2) quad_exchange_add<true>(out[j], v[j], out[j + 1], v[j + 1]);
+    if (NOUT & 1) quad_exchange_add<true>(out[NOUT - 1], v[NOUT - 1]);
 }
 
 // ------------------------------------------------------- distance factor --
@@ -362,10 +393,11 @@ JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, cons
 }
 
 // One filter set for this lane's bins, then the inverse transform.
+template <int NOUT>
 JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows, const float *w,
-                       const float2 (&xd)[8], float2 (&v)[16], float2 *buf, const float2 *tw,
+                       const float2 (&xd)[8], float2 (&out)[NOUT], float2 *buf, const float2 *tw,
                        int lane) {
-    float2 mir[8];
+    float2 v[16], mir[8];
     if (nt == 4)
         filtered_bins<4>(htab, rows, w, xd, v, mir, lane);
     else if (nt == 2)
@@ -378,7 +410,7 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
     mirror8(buf, mir, up, lane);
 #pragma unroll
     for (int r = 8; r < 16; r++) v[r] = up[r - 8];
-    ifft1024_lastq_wave(v, buf, tw, lane);
+    ifft1024_lastq_wave<NOUT>(v, out, buf, tw, lane);
 }
 
 // ------------------------------------------------------------ fused kernel --
@@ -482,18 +514,15 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
 
     // ---- filter set(s) + inverse + crossfade (GPUSoundSource.cu:351-381)
     float2 res[NOUT];
-    constexpr int T0 = 16 - 4 * NOUT;  // first t with 16 t + i >= 256 - B
 #pragma unroll 1
     for (int set = (n_old > 0 ? 0 : 1); set < 2; set++) {
         const int *rows = set ? dp->rows_new : dp->rows_old;
         const float *w = set ? dp->w_new : dp->w_old;
-        float2 v[16];
-        filter_set(set ? n_new : n_old, P.htab, rows, w, xd, v, buf, s_tw, lane);
+        float2 mine[NOUT];  // frames i + 16 (NOUT a + j) of the block
+        filter_set<NOUT>(set ? n_new : n_old, P.htab, rows, w, xd, mine, buf, s_tw, lane);
 #pragma unroll
         for (int j = 0; j < NOUT; j++) {
-            const float2 c0 = v[T0 + j], c1 = v[T0 + NOUT + j];
-            const float2 c2 = v[T0 + 2 * NOUT + j], c3 = v[T0 + 3 * NOUT + j];
-            float2 r1 = (a == 0) ? c0 : (a == 1) ? c1 : (a == 2) ? c2 : c3;
+            float2 r1 = mine[j];
             if (set == 0) {
                 res[j] = r1;
             } else {
