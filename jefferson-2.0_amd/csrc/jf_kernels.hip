@@ -321,10 +321,9 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *bu
 // exact integer arithmetic: c = frac(fsvs r'/513) as a 64-bit fraction of a turn, phase(k) =
 // k*c mod 1 (top 32 bits kept, 1.5e-9 rad), split into the nearest quarter turn and a
 // remainder |f| <= 1/2 quarter turn that goes through float minimax kernels.
-JF_DEV float2 distance_factor(unsigned c_hi, unsigned c_lo, float inv_frac, int k) {
-    const unsigned p = (unsigned)k * c_hi + __umulhi((unsigned)k, c_lo);
+// p = the phase word.  Branch-free: the quarter only swaps sin/cos and sets sign bits.
+JF_DEV float2 distance_from_phase(unsigned p, float inv_frac) {
     const unsigned p2 = p + 0x20000000u;  // + 1/8 turn: round to the nearest quarter
-    const int qd = (int)(p2 >> 30);
     const int rem = (int)(p2 & 0x3FFFFFFFu) - 0x20000000;
     // x = remainder in radians, |x| <= pi/4
     const float x = (float)rem * (1.57079632679489661923f / 1073741824.0f);
@@ -333,9 +332,27 @@ JF_DEV float2 distance_factor(unsigned c_hi, unsigned c_lo, float inv_frac, int 
     const float s = x + x * x2 * (-1.6666654611e-1f + x2 * (8.3321608736e-3f + x2 * -1.9515295891e-4f));
     const float c = 1.0f - 0.5f * x2 +
                     x2 * x2 * (4.166664568298827e-2f + x2 * (-1.388731625493765e-3f + x2 * 2.443315711809948e-5f));
-    const float cs = (qd == 0) ? c : (qd == 1) ? -s : (qd == 2) ? -c : s;
-    const float sn = (qd == 0) ? s : (qd == 1) ? c : (qd == 2) ? -s : -c;
-    return make_float2(cs * inv_frac, -sn * inv_frac);
+    // quarter q = p2 >> 30: (cos, sin) = (c, s), (-s, c), (-c, -s), (s, -c); the result is (cos, -sin) * inv_frac
+    const bool odd = (p2 & 0x40000000u) != 0;
+    const float cc = odd ? s : c, ss = odd ? c : s;
+    const unsigned neg_re = (p2 + 0x40000000u) & 0x80000000u;  // quarters 1, 2
+    const unsigned neg_im = ~p2 & 0x80000000u;                 // quarters 0, 1
+    return make_float2(__uint_as_float(__float_as_uint(cc * inv_frac) ^ neg_re),
+                       __uint_as_float(__float_as_uint(ss * inv_frac) ^ neg_im));
+}
+
+// D of this lane's bins lane + 64 q, q = 0..7, and Re D[512].  Phase words by 64-bit accumulation (two
+// adds per bin instead of two quarter-rate 32-bit multiplies): hi32(k c mod 2^64), k = lane + 64 q.
+JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int lane, float2 (&dq)[8], float &d512x) {
+    const unsigned long long c64 = ((unsigned long long)c_hi << 32) | c_lo;
+    unsigned long long ph = (unsigned long long)(unsigned)lane * c64;
+    const unsigned long long step = c64 << 6;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        dq[q] = distance_from_phase((unsigned)(ph >> 32), inv_frac);
+        ph += step;
+    }
+    d512x = distance_from_phase((unsigned)((c64 << 9) >> 32), inv_frac).x;
 }
 
 // ------------------------------------------------------ filter + inverse --
@@ -477,9 +494,8 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
     // powers of two, exact
     float2 dq[8];
     const float sinv = inv_frac * (1.0f / 2048.0f);
-#pragma unroll
-    for (int q = 0; q < 8; q++) dq[q] = distance_factor(c_hi, c_lo, sinv, lane + 64 * q);
-    const float d512x = distance_factor(c_hi, c_lo, sinv, 512).x;
+    float d512x;
+    distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
     __builtin_amdgcn_sched_barrier(0);
     if (b == P.K - 1) {
         // last block of the call: leave the window and the counters for the next call
