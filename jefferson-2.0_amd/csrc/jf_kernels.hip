@@ -253,8 +253,9 @@ JF_DEV void rfft1024_wave(float2 (&z)[8], float2 (&X)[8], float2 *buf, const flo
 // Last quarter of the unnormalised inverse 1024-point complex transform.
 // In : Zin[r] = Z[lane + 64 r], r = 0..15.
 // Out: out[j] = y[1024 - B + (lane>>2) + 16 (NOUT a + j)], a = lane & 3, j < NOUT = B / 64: this lane's
-//      frames of the block.  buf: >= 1088 float2 of this wave's LDS.
-template <int NOUT>
+//      frames of the block.  buf: this wave's LDS, >= 1088 float2, or >= 544 with SPLIT (the exchange then
+//      moves real and imaginary parts one after the other through a float image of half the size).
+template <int NOUT, bool SPLIT>
 JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *buf, const float2 *tw, int lane) {
     const int a = lane & 3, i = lane >> 2;
     // lane (i, a) holds S_a[i + 16 r] = Z[4 (i + 16 r) + a]: 16-point inverse over r
@@ -262,10 +263,7 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *bu
 #pragma unroll
     for (int m = 1; m < 16; m++) v[m] = cmul(v[m], tw[kTwW2 + 16 * m + i]);
     // exchange inside each group a: write rows m (padded 64 -> 68), read columns
-#if JF_SPLIT_EXCHANGE
-    // real and imaginary parts one after the other through a float image of half the size
-    // (4352 B per wave instead of 8704 B: 20 waves per CU fit beside the twiddle pack)
-    {
+    if (SPLIT) {
         float *fb = reinterpret_cast<float *>(buf);
 #pragma unroll
         for (int m = 0; m < 16; m++) fb[68 * m + lane] = v[m].x;
@@ -279,15 +277,14 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *bu
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j].y = fb[68 * i + 4 * j + a];
         JF_WAVE_LDS_SYNC();
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) buf[68 * m + lane] = v[m];
+        JF_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = buf[68 * i + 4 * j + a];
+        JF_WAVE_LDS_SYNC();
     }
-#else
-#pragma unroll
-    for (int m = 0; m < 16; m++) buf[68 * m + lane] = v[m];
-    JF_WAVE_LDS_SYNC();
-#pragma unroll
-    for (int j = 0; j < 16; j++) v[j] = buf[68 * i + 4 * j + a];
-    JF_WAVE_LDS_SYNC();
-#endif
     fft16<+1>(v);  // s_a[i + 16 t]
     // y[768 + n] = sum_a (-i)^a e^{+2 pi i a n / 1024} s_a[n],  n = i + 16 t: the pruned last radix-4, a sum
     // over the 4 lanes of a quad.  Only t >= T0 is in the block, and lane a keeps t = T0 + a NOUT + j only, so
@@ -360,9 +357,10 @@ JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int l
 // float4), Y_ear = (X D)[k] * he_ear, and the two inputs of the inverse transform it yields:
 // v[q] = Z[k] = Y_L + j Y_R and mir[q] = Z[N-k] = conj Y_L + j conj Y_R.
 // xd[q] = X[k] D[k]; on lane 0, xd[0] = (X0*D0.re, X512*D512.re).
-template <int NT>
+// use(q, zk, zm) consumes bin q's pair (stores it for a per-source inverse, or adds it to a group's sums).
+template <int NT, class F>
 JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, const float *w,
-                          const float2 (&xd)[8], float2 (&v)[16], float2 (&mir)[8], int lane) {
+                          const float2 (&xd)[8], int lane, F &&use) {
     const float4 *hp[NT];
     float wt[NT];
 #pragma unroll
@@ -402,57 +400,72 @@ JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, cons
                 zk = lane == 0 ? z0 : zk;
                 zm = lane == 0 ? z512 : zm;
             }
-            v[qc + q] = zk;
-            mir[qc + q] = zm;
+            use(qc + q, zk, zm);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+template <class F>
+JF_DEV void filtered_bins_nt(int nt, const float4 *__restrict__ htab, const int *rows, const float *w,
+                             const float2 (&xd)[8], int lane, F &&use) {
+    if (nt == 4)
+        filtered_bins<4>(htab, rows, w, xd, lane, use);
+    else if (nt == 2)
+        filtered_bins<2>(htab, rows, w, xd, lane, use);
+    else
+        filtered_bins<1>(htab, rows, w, xd, lane, use);
+}
+
+// The inverse of one spectrum given as this lane's Z[k] (zk) and Z[N-k] (zm), k = lane + 64 q: the upper
+// half Z[lane + 64 r], r = 8..15, lives mirrored on lane 64 - lane (lane 0: r = 8 -> Z[512], else
+// Z[N - 64 (16 - r)]).
+template <int NOUT, bool SPLIT>
+JF_DEV void inverse_of(float2 (&v)[16], const float2 (&zm)[8], float2 (&out)[NOUT], float2 *buf, const float2 *tw,
+                       int lane) {
+    float2 up[8];
+    mirror8(buf, zm, up, lane);
+#pragma unroll
+    for (int r = 8; r < 16; r++) v[r] = up[r - 8];
+    ifft1024_lastq_wave<NOUT, SPLIT>(v, out, buf, tw, lane);
+}
+
 // One filter set for this lane's bins, then the inverse transform.
-template <int NOUT>
+template <int NOUT, bool SPLIT>
 JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows, const float *w,
                        const float2 (&xd)[8], float2 (&out)[NOUT], float2 *buf, const float2 *tw,
                        int lane) {
     float2 v[16], mir[8];
-    if (nt == 4)
-        filtered_bins<4>(htab, rows, w, xd, v, mir, lane);
-    else if (nt == 2)
-        filtered_bins<2>(htab, rows, w, xd, v, mir, lane);
-    else
-        filtered_bins<1>(htab, rows, w, xd, v, mir, lane);
-    // upper half: Z[lane + 64 r], r = 8..15, lives mirrored on lane 64 - lane
-    // (lane 0: r = 8 -> Z[512], else Z[N - 64 (16 - r)])
-    float2 up[8];
-    mirror8(buf, mir, up, lane);
-#pragma unroll
-    for (int r = 8; r < 16; r++) v[r] = up[r - 8];
-    ifft1024_lastq_wave<NOUT>(v, out, buf, tw, lane);
+    filtered_bins_nt(nt, htab, rows, w, xd, lane, [&](int q, float2 zk, float2 zm) {
+        v[q] = zk;
+        mir[q] = zm;
+    });
+    inverse_of<NOUT, SPLIT>(v, mir, out, buf, tw, lane);
 }
 
 // ------------------------------------------------------------ fused kernel --
-#if JF_SPLIT_EXCHANGE
-constexpr int kWaveLds = 576;   // float2 per wave (4608 B): forward passes; the inverse exchange goes in two halves
-#else
-constexpr int kWaveLds = 1088;  // float2 per wave (8704 B): inverse exchange; forward uses 576
-#endif
+constexpr bool kSplit = JF_SPLIT_EXCHANGE != 0;
+constexpr int kWaveLds = kSplit ? 576 : 1088;  // float2 per wave: the inverse exchange (8704 B), or with the split
+                                               // exchange the forward passes (4608 B)
+// group kernel: 576 of work space (split exchange) + this lane's 8 sums of Z[N-k] + lane 0's mirror slot
+constexpr int kGroupWork = 576, kGroupWaveLds = kGroupWork + 520;
 
-// One (block b, source s) work item by one wavefront: everything from the window gather to the
-// crossfaded stereo frames, which are ADDED to acc (B/64 frames per lane: frame i + 16 (NOUT a + j),
-// lane = 4 i + a).  dp: this item's descriptor (global memory in the batch kernel, LDS in the
-// real-time kernel); pos_rec: its latched position record.  buf: this wave's LDS; s_tw: twiddle pack.
-template <int NOUT>
-JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
-                            float2 *buf, const float2 *s_tw, int lane, float2 (&acc)[NOUT]) {
+// Front half of one (block b, source s) work item: window gather (Audio.cu:121-139,
+// GPUSoundSource.cu:472-513), write-back of the window and counters at the last block of a call, forward
+// FFT with its 1/N (GPUSoundSource.cu:344-346), times the distance factor: xd[q] = X[k] D[k], k = lane + 64 q
+// (lane 0: xd[0] = (X0 D0.re, X512 D512.re)).  D_EARLY: the distance factors are computed while the window
+// loads are in flight (16 more registers live across the FFT).  False if the item is silent (not
+// interpolable: the reference has no defined output there).
+template <int NOUT, bool D_EARLY>
+JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
+                       float2 *buf, const float2 *s_tw, int lane, float2 (&xd)[8]) {
     constexpr int B = 64 * NOUT;
-    const int a = lane & 3, i = lane >> 2;
     // ---- descriptor (wave-uniform -> scalar loads)
     const int n_new = dp->n_new;
-    const int n_old = dp->n_old;
     const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
     const float inv_frac = dp->inv_frac;
 
-    // ---- window gather (Audio.cu:121-139, GPUSoundSource.cu:472-513)
+    // ---- window gather
     const SrcSignal sg = P.sigs[s];
     const int count0 = P.st_in[s].count;
     const float *hist = P.hist_in + (size_t)s * kN;
@@ -489,14 +502,15 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
             z[r] = make_float2(xv[0], xv[1]);
         }
     }
-    // ---- distance factor while the window loads are in flight (needs the descriptor only).  The 1/N of
-    // the forward transform (GPUSoundSource.cu:344-346) and the 1/2 of its split pass ride on 1/frac:
-    // powers of two, exact
+    // ---- distance factor.  The 1/N of the forward transform and the 1/2 of its split pass ride on
+    // 1/frac: powers of two, exact
     float2 dq[8];
     const float sinv = inv_frac * (1.0f / 2048.0f);
     float d512x;
-    distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
-    __builtin_amdgcn_sched_barrier(0);
+    if (D_EARLY) {
+        distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (b == P.K - 1) {
         // last block of the call: leave the window and the counters for the next call
         float *ho = P.hist_out + (size_t)s * kN;
@@ -513,20 +527,31 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
         }
     }
 
-    if (n_new <= 0) return;  // not interpolable: silence (the reference has no defined output here)
+    if (n_new <= 0) return false;
 
-    // ---- forward FFT, 1/N scale (GPUSoundSource.cu:344-346), times D[k]
-    float2 xd[8];
-    {
-        float2 X[8];
-        rfft1024_wave(z, X, buf, s_tw, lane);
+    float2 X[8];
+    rfft1024_wave(z, X, buf, s_tw, lane);
+    if (!D_EARLY) distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
 #pragma unroll
-        for (int q = 0; q < 8; q++) xd[q] = cmul(X[q], dq[q]);
-        {
-            const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
-            xd[0] = lane == 0 ? x0 : xd[0];
-        }
-    }
+    for (int q = 0; q < 8; q++) xd[q] = cmul(X[q], dq[q]);
+    const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
+    xd[0] = lane == 0 ? x0 : xd[0];
+    return true;
+}
+
+// One (block b, source s) work item by one wavefront: everything from the window gather to the
+// crossfaded stereo frames, which are ADDED to acc (B/64 frames per lane: frame i + 16 (NOUT a + j),
+// lane = 4 i + a).  dp: this item's descriptor (global memory in the batch kernel, LDS in the
+// real-time kernel); pos_rec: its latched position record.  buf: this wave's LDS; s_tw: twiddle pack.
+template <int NOUT>
+JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
+                            float2 *buf, const float2 *s_tw, int lane, float2 (&acc)[NOUT]) {
+    constexpr int B = 64 * NOUT;
+    const int a = lane & 3, i = lane >> 2;
+    const int n_new = dp->n_new;
+    const int n_old = dp->n_old;
+    float2 xd[8];
+    if (!item_front<NOUT, true>(P, dp, pos_rec, b, s, buf, s_tw, lane, xd)) return;
 
     // ---- filter set(s) + inverse + crossfade (GPUSoundSource.cu:351-381)
     float2 res[NOUT];
@@ -535,7 +560,7 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
         const int *rows = set ? dp->rows_new : dp->rows_old;
         const float *w = set ? dp->w_new : dp->w_old;
         float2 mine[NOUT];  // frames i + 16 (NOUT a + j) of the block
-        filter_set<NOUT>(set ? n_new : n_old, P.htab, rows, w, xd, mine, buf, s_tw, lane);
+        filter_set<NOUT, kSplit>(set ? n_new : n_old, P.htab, rows, w, xd, mine, buf, s_tw, lane);
 #pragma unroll
         for (int j = 0; j < NOUT; j++) {
             float2 r1 = mine[j];
@@ -594,6 +619,99 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
 #pragma unroll
         for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = acc[j];
+    }
+}
+
+// The same work with the NEW filter sets of a unit's sources summed as spectra: the inverse transform is
+// linear and the crossfade ramp f = n / (B - 1) is the same for every source, so
+//     sum_s [ old_s (1 - f) + new_s f ]  =  (1 - f) sum_s old_s  +  f IFFT( sum_s Z_new,s ).
+// A unit of G crossfading sources then costs G + 1 inverse transforms instead of 2 G, and a unit in which
+// nothing crossfades exactly one (the inverse is 45 % of a per-source item's instructions).  The sum of
+// Z[k] and Z[N-k] over the sources (32 VGPRs) runs in source order; the old sets stay per source in the
+// time domain -- a second spectral sum would need 32 more registers than a 4-waves-per-SIMD kernel has.
+// A source that does not crossfade inside a unit that does (old_s = new_s) goes through both paths.
+template <int NOUT>
+__global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
+    __shared__ float2 s_tw[kTwPack];
+    __shared__ float2 s_buf[kWavesPerWg * kGroupWaveLds];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *buf = s_buf + wave * kGroupWaveLds;  // FFT work space (split exchange)
+    float2 *zm_sum = buf + kGroupWork + lane;    // + 64 q: this lane's sums of Z[N-k]
+    constexpr int B = 64 * NOUT;
+    const int G = P.G, SG = P.S / G;
+    const int n_units = P.K * SG;
+    const int a = lane & 3, i = lane >> 2;
+#pragma unroll 1
+    for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+        const int b = unit / SG;
+        const int s0 = (unit - b * SG) * G;
+        const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
+        bool any_xfade = false;
+        for (int g = 0; g < G; g++) any_xfade = any_xfade || (d0[g].n_old > 0 && d0[g].n_new > 0);
+        // sums over the sources of the new sets' Z[k] (registers) and Z[N-k] (this lane's LDS slots: the
+        // registers are needed elsewhere), and of the old sets' frames
+        float2 zk_sum[16], old_t[NOUT];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            zk_sum[q] = make_float2(0.f, 0.f);
+            zm_sum[64 * q] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) old_t[j] = make_float2(0.f, 0.f);
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const ItemDesc *dp = d0 + g;
+            const int item = b * P.S + s0 + g;
+            float2 xd[8];
+            if (!item_front<NOUT, true>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) continue;
+            filtered_bins_nt(dp->n_new, P.htab, dp->rows_new, dp->w_new, xd, lane, [&](int q, float2 zk, float2 zm) {
+                zk_sum[q] = cadd(zk_sum[q], zk);
+                zm_sum[64 * q] = cadd(zm_sum[64 * q], zm);
+            });
+            if (any_xfade) {
+                // GPUSoundSource.cu:331-381: the old set on the same window and the same D
+                const bool x = dp->n_old > 0;
+                int rows[4];
+                float w[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {  // wave-uniform values, not pointers: scalar selects
+                    rows[t] = x ? dp->rows_old[t] : dp->rows_new[t];
+                    w[t] = x ? dp->w_old[t] : dp->w_new[t];
+                }
+                float2 mine[NOUT];
+                filter_set<NOUT, true>(x ? dp->n_old : dp->n_new, P.htab, rows, w, xd, mine, buf, s_tw, lane);
+#pragma unroll
+                for (int j = 0; j < NOUT; j++) old_t[j] = cadd(old_t[j], mine[j]);
+            }
+        }
+        // inverse of the summed spectrum: the mirror (see mirror8) reads the Z[N-k] sums where they are
+        if (lane == 0) zm_sum[512] = zm_sum[0];
+        JF_WAVE_LDS_SYNC();
+        {
+            const float2 *rd = buf + kGroupWork + (64 - lane);
+#pragma unroll
+            for (int j = 0; j < 8; j++) zk_sum[8 + j] = rd[64 * (7 - j)];
+        }
+        JF_WAVE_LDS_SYNC();
+        float2 fr[NOUT];
+        ifft1024_lastq_wave<NOUT, true>(zk_sum, fr, buf, s_tw, lane);
+        if (any_xfade) {
+#pragma unroll
+            for (int j = 0; j < NOUT; j++) {
+                // kernels.cu:132-137
+                const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
+                const float fn = (float)n_out / ((float)B - 1.0f);
+                fr[j] = make_float2(old_t[j].x * (1.0f - fn) + fr[j].x * fn, old_t[j].y * (1.0f - fn) + fr[j].y * fn);
+            }
+        }
+        float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
     }
 }
 
@@ -970,6 +1088,18 @@ hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
     int wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
     if (wgs > max_wgs) wgs = max_wgs;
     const dim3 grid(wgs), block(64 * kWavesPerWg);
+    // groups of sources are summed as spectra (one pair of inverse transforms per group); single sources
+    // keep the per-source kernel, whose blocks are the reference's per-source `intermediate`
+    if (P.G > 1) {
+        switch (P.B / 64) {
+        case 1: hipLaunchKernelGGL(fused_group_kernel<1>, grid, block, 0, st, P); break;
+        case 2: hipLaunchKernelGGL(fused_group_kernel<2>, grid, block, 0, st, P); break;
+        case 3: hipLaunchKernelGGL(fused_group_kernel<3>, grid, block, 0, st, P); break;
+        case 4: hipLaunchKernelGGL(fused_group_kernel<4>, grid, block, 0, st, P); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (P.B / 64) {
     case 1: hipLaunchKernelGGL(fused_block_kernel<1>, grid, block, 0, st, P); break;
     case 2: hipLaunchKernelGGL(fused_block_kernel<2>, grid, block, 0, st, P); break;
