@@ -176,6 +176,50 @@ def test_invalid_batch_positions_are_silence_not_faults(jf, hrir, castanets):
     e.close()
 
 
+@pytest.mark.parametrize("B,G", [(64, 4), (128, 8), (192, 2), (256, 8), (256, 16)])
+def test_group_kernel_mixed_units(jf, hrir, castanets, B, G):
+    """fused_group_kernel on units that mix everything: sources that crossfade, sources that do not (inside a
+    unit that does, and in units where nothing moves), silent sources (position not interpolable), ragged
+    signal lengths, the FD_BASIC mode, carried state across two calls -- against the per-source kernel
+    (G = 1) and the float32 oracle."""
+    S, K = 32, 6
+    pos = np.zeros((2 * K, S, 5), np.float32)
+    for k in range(2 * K):
+        for s in range(S):
+            moving = (s % 3 != 0) and not (8 <= s < 16)          # sources 8..15: a unit where nothing crossfades
+            ele = -38 + (5 * s) % 120
+            azi = (17 * s + (k if moving else 0) * (1 + s % 4)) % 360
+            pos[k, s] = jf.position_from_spherical(ele, azi, 0.4 + 0.05 * s)
+    pos[:, 5, 0] = -60.0                                           # no such elevation ring: silence
+    sigs = [np.roll(castanets, 321 * s)[: 5000 + 257 * s] for s in range(S)]
+    outs = {}
+    for g in (1, G):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+        e.set_source_group(g)
+        for s in range(S):
+            e.set_signal(s, sigs[s])
+        first = e.process_batch(pos[:K])
+        e.set_mode(jf.JF_MODE_FD_BASIC)
+        basic = e.process_batch(pos[K:K + 2])
+        e.set_mode(jf.JF_MODE_FD_COMPLEX)
+        second = e.process_batch(pos[K + 2:])
+        e.close()
+        outs[g] = np.concatenate([first, basic, second])
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        ora.set_signal(s, sigs[s])
+    want = [ora.process_batch(pos[:K])]
+    ora.set_mode(1)
+    want.append(ora.process_batch(pos[K:K + 2]))
+    ora.set_mode(0)
+    want.append(ora.process_batch(pos[K + 2:]))
+    want = np.concatenate(want)
+    assert np.abs(want).max() > 0.1
+    assert np.abs(outs[G] - outs[1]).max() <= TOL32 * S / 4
+    assert np.abs(outs[G] - want).max() <= TOL32 * S / 4
+    assert np.abs(outs[1] - want).max() <= TOL32 * S / 4
+
+
 def test_full_size_moving_workload_properties(jf, hrir):
     """BASELINE.json configs[2] at full width (1024 moving sources, B = 256): the oracle is too
     slow to replay it all in a test, so check (1) a sample of sources against the oracle,
