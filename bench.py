@@ -249,7 +249,7 @@ def main():
             "us_per_source_block": dt / (S * KB * K) * 1e6,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fused_block_kernel<4>",
+                         "kernel": "fused_group_kernel<4>",
                          "algorithmic_bytes_per_launch": abytes / prof["launches"] if prof["launches"] else None,
                          "avg_launch_ms": prof["fused_ms"] / prof["launches"] if prof["launches"] else None,
                          "table_rows_per_source_block": rows / items,

@@ -24,7 +24,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        name = "fused" if "fused_block_kernel" in k else "mix" if "mix_kernel" in k else "prep" if "prep_kernel" in k else None
+        name = "fused" if ("fused_group_kernel" in k or "fused_block_kernel" in k) else "mix" if "mix_kernel" in k else "prep" if "prep_kernel" in k else None
         if not name: continue
         t = tot[name][row["Counter_Name"]]
         t[0] += float(row["Counter_Value"]); t[1] += 1
@@ -35,7 +35,7 @@ f = summ.get("fused", {})
 if "FETCH_SIZE" in f and "WRITE_SIZE" in f:
     hbm = f["FETCH_SIZE"] * 1024 * 2 + f["WRITE_SIZE"] * 1024
     json.dump({"hbm_bytes_per_launch": hbm, "fetch_kb_raw": f["FETCH_SIZE"], "write_kb_raw": f["WRITE_SIZE"],
-               "note": "fused_block_kernel, 64 blocks x 1024 moving sources per launch; FETCH_SIZE x2 (gfx950 "
+               "note": "fused_group_kernel, 64 blocks x 1024 moving sources per launch; FETCH_SIZE x2 (gfx950 "
                        "wide-load correction, MI355X_MICROARCH.md), separate --pmc passes"},
               open(out + "/traffic.json", "w"), indent=1)
 json.dump(summ, open(out + "/pmc_summary.json", "w"), indent=1)

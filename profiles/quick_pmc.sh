@@ -16,7 +16,7 @@ import csv, glob, collections
 tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "fused_block_kernel" not in row.get("Kernel_Name", ""): continue
+        if not any(n in row.get("Kernel_Name", "") for n in ("fused_group_kernel", "fused_block_kernel")): continue
         tot[row["Counter_Name"]][0] += float(row["Counter_Value"]); tot[row["Counter_Name"]][1] += 1
 w = tot["SQ_WAVES"][0] / max(tot["SQ_WAVES"][1], 1)
 for c in sorted(tot):
