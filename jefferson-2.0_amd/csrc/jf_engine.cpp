@@ -193,6 +193,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     const int G = e->src_group > 0 ? e->src_group
                   : (e->S % 8 == 0 && n_items >= 32768) ? 8
                   : (e->S % 4 == 0 && n_items >= 16384) ? 4
+                  : (e->S % 2 == 0 && n_items >= 8192)  ? 2
                                                          : 1;
     P.G = (e->S % G == 0) ? G : 1;
     P.mode = e->mode;
