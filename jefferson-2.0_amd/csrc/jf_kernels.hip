@@ -893,12 +893,19 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
     d.pad = 0;
 }
 
+// Two adjacent lanes per item: the even one does the new position's rule and the distance part, the odd one
+// the old position's rule (the kernel is a short dependent chain per thread at one wave per SIMD: halving
+// the chain halves its time).  Same arithmetic as make_desc, which the real-time kernel uses.
 __global__ void prep_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
                             const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= S * K) return;
-    const int b = item / S, s = item - b * S;
-    const float *p = pos + (size_t)item * 5;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int item = tid >> 1;
+    const bool old_half = tid & 1;
+    const bool live = item < S * K;  // both lanes of a pair agree; no early return before the shuffle
+    const int it = live ? item : 0;
+    const int b = it / S, s = it - b * S;
+    const float *p = pos + (size_t)it * 5;
+    const float ele = p[0], azi = p[1];
     float old_ele, old_azi;
     if (b == 0) {
         old_ele = st[s].old_ele;
@@ -907,9 +914,65 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
         old_ele = p[-5 * S];
         old_azi = p[-5 * S + 1];
     }
-    ItemDesc d;
-    make_desc(rt, mode, p, old_ele, old_azi, d);
-    desc[item] = d;
+    ItemDesc &d = desc[it];
+    int rows[4] = {0, 0, 0, 0};
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    const bool moved = old_azi != azi || old_ele != ele;  // GPUSoundSource.cu:331-335
+    if (mode == 1) {
+        // *_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): the nearest table row, weight 1, no
+        // distance factor (D = 1), no crossfade
+        const bool ok = (ele > -1.0e6f && ele < 1.0e6f) && (azi > -1.0e6f && azi < 1.0e6f);
+        const int row = ok ? dev_pick_hrtf(rt, ele, azi) : 0;
+        rows[0] = rows[1] = rows[2] = rows[3] = row;
+        if (!old_half) {
+            w[0] = 1.0f;
+            n = ok ? 1 : 0;
+        }
+    } else if (!old_half) {
+        n = dev_interp_terms(rt, ele, azi, rows, w);
+    } else if (moved) {
+        n = dev_interp_terms(rt, old_ele, old_azi, rows, w);
+    }
+    const int n_other = __shfl_xor(n, 1);
+    if (!live) return;
+    if (old_half) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            d.rows_old[t] = rows[t];
+            d.w_old[t] = w[t];
+        }
+        d.n_old = n;
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        d.rows_new[t] = rows[t];
+        d.w_new[t] = w[t];
+    }
+    d.pad = 0;
+    if (mode == 1) {
+        d.n_new = n;
+        d.c_fix = 0;
+        d.inv_frac = 1.0f;
+        return;
+    }
+    if (moved && n_other == 0) n = 0;  // the old position is not interpolable
+    // GPUSoundSource.cu:81-90
+    const float x = p[2], y = p[3], z = p[4];
+    float r = sqrtf(x * x + y * y + z * z);
+    r /= 5;
+    const float fsvs = (float)(44100.0 / 343.0);
+    const float frac = 1 + fsvs * (float)((double)r * (double)r);
+    {
+        // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+        double c = (double)fsvs * (double)r / 513.0;
+        c -= floor(c);
+        d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
+    }
+    d.inv_frac = 1.0f / frac;
+    if (!(frac >= 1.0f) || !(frac < 3.0e38f)) n = 0;  // NaN / inf coordinates
+    d.n_new = n;
 }
 
 __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const float *azi, int *rows,
@@ -1056,7 +1119,7 @@ hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const fl
 hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
                        int S, int K, hipStream_t st) {
     const int n = S * K;
-    hipLaunchKernelGGL(prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, mode, d_pos, d_st, d_desc, S, K);
+    hipLaunchKernelGGL(prep_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, rt, mode, d_pos, d_st, d_desc, S, K);
     return hipGetLastError();
 }
 
