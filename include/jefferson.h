@@ -233,8 +233,9 @@ int jf_debug_set_source_group(jf_engine *e, int group);
  * forms add the same products in different associations. */
 int jf_debug_set_reverb_form(jf_engine *e, int form);
 /* Per-block calls (jf_process_block / jf_submit_block / jf_callback) with at most n sources use the
- * one-launch real-time kernel (descriptors + spatialisation + mix in one workgroup, pinned host I/O);
- * above that, the batch pipeline with one block.  Default 16; 0 disables the real-time kernel. */
+ * one-launch real-time kernel (descriptors + spatialisation + mix per workgroup of 16 sources, pinned host
+ * I/O, the workgroups' blocks added on the host in order); above that, the batch pipeline with one block.
+ * Default 256; 0 disables the real-time kernel. */
 int jf_debug_set_rt_max_sources(jf_engine *e, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);

@@ -24,7 +24,8 @@ hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const 
                        int S, int K, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
-hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, hipStream_t st);
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
+                           hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st);
@@ -43,6 +44,8 @@ struct EventPair {
     hipEvent_t a, b;
 };
 }  // namespace
+
+constexpr int kRtMaxWgs = 16;  // workgroups (of 16 sources each) of the one-launch real-time kernel
 
 struct jf_engine {
     jf_config cfg{};
@@ -76,9 +79,10 @@ struct jf_engine {
     bool paused = false;
 
     float *h_pos_pinned = nullptr;  // [S][5]   pinned + mapped: the real-time kernel reads it in place
-    float *h_out_pinned = nullptr;  // [2B]     pinned + mapped: ... and writes the stereo block in place
+    float *h_out_pinned = nullptr;  // [kRtMaxWgs][2B] pinned + mapped: ... and writes its workgroups' stereo blocks in place
+    int rt_wgs = 0;                 // partial blocks the block in flight left there (0: one finished block)
     float *hd_pos = nullptr, *hd_out = nullptr;  // their device addresses
-    int rt_max_sources = 16;        // per-block calls with at most this many sources take the one-launch path
+    int rt_max_sources = 256;       // per-block calls with at most this many sources take the one-launch path
     bool in_flight = false;         // a submitted block not yet collected
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
@@ -328,7 +332,7 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
         JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5, hipHostMallocMapped));
-        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B, hipHostMallocMapped));
+        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
         e->d_signal.assign(S, nullptr);
@@ -579,8 +583,12 @@ int jf_submit_block(jf_engine *e) {
             P.B = e->B;
             P.G = 1;
             P.mode = e->mode;
-            JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, e->stream));
+            // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
+            int wgs = (e->S + 15) / 16;
+            if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
+            JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, wgs, e->stream));
             e->cur = p ^ 1;
+            e->rt_wgs = wgs;
             e->in_flight = true;
             return JF_OK;
         }
@@ -590,6 +598,7 @@ int jf_submit_block(jf_engine *e) {
         if (rc) return rc;
     }
     JF_HIP(e, hipMemcpyAsync(e->h_out_pinned, e->d_mix, sizeof(float) * 2 * e->B, hipMemcpyDeviceToHost, e->stream));
+    e->rt_wgs = 0;
     e->in_flight = true;
     return JF_OK;
     });
@@ -601,6 +610,11 @@ int jf_collect_block(jf_engine *e, float *out) {
     if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     memcpy(out, e->h_out_pinned, sizeof(float) * 2 * e->B);
+    // the real-time kernel's workgroups each left the sum of their sources: add them in workgroup order
+    for (int g = 1; g < e->rt_wgs; g++) {
+        const float *pg = e->h_out_pinned + (size_t)g * 2 * e->B;
+        for (int n = 0; n < 2 * e->B; n++) out[n] += pg[n];
+    }
     e->in_flight = false;
     return JF_OK;
     });

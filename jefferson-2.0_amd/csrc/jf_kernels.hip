@@ -990,11 +990,12 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------- real-time kernel --
-// One audio block for a handful of sources in ONE launch (the per-block call of the reference's
-// audio callback): a single workgroup; wave w takes sources w, w + 16, ...; lane 0 builds the
+// One audio block for up to a few hundred sources in ONE launch (the per-block call of the reference's
+// audio callback): workgroup g of n, wave w takes sources 16 g + w, + 16 n, ...; lane 0 builds the
 // descriptor in LDS (no prep launch), the wave spatialises, the waves' stereo blocks are summed
-// in wave order through LDS (no mix launch).  pos and out may be host-mapped pinned memory, so a
-// block costs one launch and one synchronisation, no copies.
+// in wave order through LDS (no mix launch) and workgroup g writes its sum to out + g B.  pos and out
+// may be host-mapped pinned memory, so a block costs one launch and one synchronisation, no copies;
+// the caller adds the n partial blocks (n = 1 for up to 16 sources).
 constexpr int kRtWaves = 16;
 template <int NOUT>
 __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedParams P, const RingTable rt,
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
 #pragma unroll
     for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
 #pragma unroll 1
-    for (int s = wave; s < P.S; s += kRtWaves) {
+    for (int s = blockIdx.x * kRtWaves + wave; s < P.S; s += gridDim.x * kRtWaves) {
         const float *p = pos + 5 * s;
         if (lane == 0) {
             ItemDesc d;
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
         float2 t = s_buf[n];
 #pragma unroll
         for (int w = 1; w < kRtWaves; w++) t = cadd(t, s_buf[w * kWaveLds + n]);
-        out[n] = t;
+        out[(size_t)blockIdx.x * B + n] = t;
     }
 }
 
@@ -1173,9 +1174,10 @@ hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, hipStream_t st) {
-    if (P.K != 1) return hipErrorInvalidValue;
-    const dim3 grid(1), block(64 * kRtWaves);
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
+                           hipStream_t st) {
+    if (P.K != 1 || n_wgs < 1) return hipErrorInvalidValue;
+    const dim3 grid(n_wgs), block(64 * kRtWaves);
     float2 *o = reinterpret_cast<float2 *>(out);
     switch (P.B / 64) {
     case 1: hipLaunchKernelGGL(rt_block_kernel<1>, grid, block, 0, st, P, rt, pos, o); break;
