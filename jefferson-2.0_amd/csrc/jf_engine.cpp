@@ -128,7 +128,41 @@ EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
     return &pool[e->ev_used];
 }
 
-// prep -> fused -> mix on the engine stream, K blocks starting at d_pos.
+// reverb ahead of the spatialiser: dry signal -> FDL -> wet ring, for the K blocks of this call (state parity p)
+static int run_reverb_stage(jf_engine *e, int p, int K) {
+    if (e->rv_P <= 0) return JF_OK;
+    EventPair *er = nullptr;
+    if (e->profiling >= 2) {
+        er = next_events(e, e->ev_reverb);
+        if (!er) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
+        JF_HIP(e, hipEventRecord(er->a, e->stream));
+    }
+    ReverbParams R;
+    R.tw = e->d_tw;
+    R.dry = e->d_sigs;
+    R.dry_count_in = e->d_rv_count[p];
+    R.dry_count_out = e->d_rv_count[p ^ 1];
+    R.prev_in = e->d_rv_prev[p];
+    R.prev_out = e->d_rv_prev[p ^ 1];
+    R.fdl = e->d_rv_fdl;
+    R.hspec = e->d_rv_hspec;
+    R.wet = e->d_rv_wet;
+    R.st_in = e->d_state[p];
+    R.S = e->S;
+    R.K = K;
+    R.B = e->B;
+    R.P = e->rv_P;
+    R.Rg = e->rv_Rg;
+    R.Wr = e->rv_Wr;
+    R.head = e->rv_head;
+    R.mac_form = e->rv_form;
+    JF_HIP(e, launch_reverb(R, e->stream));
+    if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
+    e->rv_head = (e->rv_head + K) % e->rv_Rg;
+    return JF_OK;
+}
+
+// prep -> [reverb] -> fused -> mix on the engine stream, K blocks starting at d_pos.
 int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
@@ -144,36 +178,9 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
     JF_HIP(e, launch_prep(ring_table(), e->mode, d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
-    if (e->rv_P > 0) {
-        // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring (this call's K blocks)
-        EventPair *er = nullptr;
-        if (e->profiling >= 2) {
-            er = next_events(e, e->ev_reverb);
-            if (!er) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
-            JF_HIP(e, hipEventRecord(er->a, e->stream));
-        }
-        ReverbParams R;
-        R.tw = e->d_tw;
-        R.dry = e->d_sigs;
-        R.dry_count_in = e->d_rv_count[p];
-        R.dry_count_out = e->d_rv_count[p ^ 1];
-        R.prev_in = e->d_rv_prev[p];
-        R.prev_out = e->d_rv_prev[p ^ 1];
-        R.fdl = e->d_rv_fdl;
-        R.hspec = e->d_rv_hspec;
-        R.wet = e->d_rv_wet;
-        R.st_in = e->d_state[p];
-        R.S = e->S;
-        R.K = K;
-        R.B = e->B;
-        R.P = e->rv_P;
-        R.Rg = e->rv_Rg;
-        R.Wr = e->rv_Wr;
-        R.head = e->rv_head;
-        R.mac_form = e->rv_form;
-        JF_HIP(e, launch_reverb(R, e->stream));
-        if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
-        e->rv_head = (e->rv_head + K) % e->rv_Rg;
+    {
+        const int rc = run_reverb_stage(e, p, K);
+        if (rc) return rc;
     }
     FusedParams P;
     P.htab = e->d_htab;
@@ -563,15 +570,19 @@ int jf_submit_block(jf_engine *e) {
         JF_HIP(e, hipMemsetAsync(e->d_mix, 0, sizeof(float) * 2 * e->B, e->stream));
     } else {
         snapshot_positions(e, e->h_pos_pinned);
-        if (e->S <= e->rt_max_sources && e->rv_P == 0 && !e->profiling) {
+        if (e->S <= e->rt_max_sources && !e->profiling) {
             // few sources: ONE launch does descriptors, spatialisation and mix, reading the positions
             // from and writing the stereo block to pinned host memory -- no copies, one sync
             const int p = e->cur;
+            {
+                const int rc = run_reverb_stage(e, p, 1);  // the wet ring is then this block's signal
+                if (rc) return rc;
+            }
             FusedParams P;
             P.htab = e->d_htab;
             P.tw = e->d_twpack;
             P.desc = nullptr;
-            P.sigs = e->d_sigs;
+            P.sigs = e->rv_P > 0 ? e->d_sigs_wet : e->d_sigs;
             P.st_in = e->d_state[p];
             P.st_out = e->d_state[p ^ 1];
             P.hist_in = e->d_hist[p];
