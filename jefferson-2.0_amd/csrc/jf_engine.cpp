@@ -259,6 +259,7 @@ int reset_sources(jf_engine *e, int src) {
     if (e->rv_P > 0) {
         const size_t B = (size_t)e->B;
         JF_HIP(e, hipMemset(e->d_rv_fdl + s0 * e->rv_Rg * B, 0, sizeof(float2) * e->rv_Rg * B * ns));
+        JF_HIP(e, hipMemset(e->d_rv_fdl + (size_t)e->S * e->rv_Rg * B + s0 * e->rv_Rg, 0, sizeof(float2) * e->rv_Rg * ns));
         JF_HIP(e, hipMemset(e->d_rv_wet + s0 * e->rv_Wr, 0, sizeof(float) * e->rv_Wr * ns));
         JF_HIP(e, hipMemset(e->d_rv_prev[p] + s0 * B, 0, sizeof(float) * B * ns));
         JF_HIP(e, hipMemset(e->d_rv_count[p] + s0, 0, sizeof(int) * ns));
@@ -704,8 +705,9 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
     float *d_ir = nullptr;
     auto body = [&]() -> int {
-        JF_HIP(e, hipMalloc(&e->d_rv_hspec, sizeof(float2) * (size_t)P * B));
-        JF_HIP(e, hipMalloc(&e->d_rv_fdl, sizeof(float2) * S * Rg * B));
+        // each followed by the compact copies of its packed bin-0 pairs: h0[P], fdl0[S][Rg]
+        JF_HIP(e, hipMalloc(&e->d_rv_hspec, sizeof(float2) * ((size_t)P * B + P)));
+        JF_HIP(e, hipMalloc(&e->d_rv_fdl, sizeof(float2) * (S * Rg * B + S * Rg)));
         JF_HIP(e, hipMalloc(&e->d_rv_wet, sizeof(float) * S * Wr));
         JF_HIP(e, hipMalloc(&e->d_sigs_wet, sizeof(SrcSignal) * S));
         for (int i = 0; i < 2; i++) {

@@ -32,7 +32,6 @@ JF_DEV float2 rv_mulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y *
 // a tile's window), and the element-wise acc += x .* h for the packed pair of real bins 0 and B.
 typedef c2 rv_v2;
 JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = pcmac(x, h, acc); }
-JF_DEV void rv_mac2(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = __builtin_elementwise_fma(x, h, acc); }
 
 // Wave-private LDS hand-off (see jf_kernels.hip)
 #define JF_RV_SYNC()                                            \
@@ -132,14 +131,20 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
         const float2 wo = rv_mulc(o, P.tw[q * (512 / B)]);
         float2 x = make_float2(e.x + wo.y, e.y - wo.x);
-        if (q == 0) x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B]), both real
+        if (q == 0) {
+            x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B]), both real
+            // compact copy of the packed pair for the block-tiled form (fdl0[s][slot], behind the spectra)
+            P.fdl[(size_t)P.S * P.Rg * B + (size_t)s * P.Rg + (size_t)((P.head + k) % P.Rg)] = x;
+        }
         out[q] = x;
     }
 }
 
 // Last step of stage B for one (block k, source s), by one wavefront: add the NW partial spectra
 // (red, red + stride, ...), untangle the packed real spectrum, inverse FFT, write the wet block.
-template <int B, int NW>
+// FIX0: the partial spectra treated the packed pair in bin 0 as a complex number; the true pair
+// (sum_p X0[k-p] .* H0[p]) is formed here from the compact copies, lanes over the partitions.
+template <int B, int NW, bool FIX0 = false>
 JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const ReverbParams &P, int s, int k, int lane) {
     // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
     float2 *ybuf = fftbuf, *zbuf = fftbuf + B;
@@ -148,6 +153,27 @@ JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const Reve
 #pragma unroll
         for (int w = 1; w < NW; w++) a = rv_add(a, red[(size_t)w * stride + q]);
         ybuf[q] = a;
+    }
+    if (FIX0) {
+        const float2 *x0 = P.fdl + (size_t)P.S * P.Rg * B + (size_t)s * P.Rg;
+        const float2 *h0 = P.hspec + (size_t)P.P * B;
+        float2 y0 = make_float2(0.f, 0.f);
+        int slot = (P.head + k - lane) % P.Rg;
+        if (slot < 0) slot += P.Rg;
+        for (int p = lane; p < P.P; p += 64) {
+            const float2 x = x0[slot], h = h0[p];
+            y0.x += x.x * h.x;
+            y0.y += x.y * h.y;
+            slot -= 64;
+            if (slot < 0) slot += P.Rg;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            y0.x += __shfl_xor(y0.x, m);
+            y0.y += __shfl_xor(y0.y, m);
+        }
+        JF_RV_SYNC();  // every lane's sum of partials is in ybuf before lane 0 replaces bin 0
+        if (lane == 0) ybuf[0] = y0;
     }
     JF_RV_SYNC();
     for (int q = lane; q < B; q += 64) {
@@ -255,66 +281,51 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
 // Batch form of stage B (many blocks per call): one workgroup per (source, KB consecutive blocks).
 // Block k + i at partition p needs FDL slot head + k + i - p, so the KB blocks of a tile use a
 // sliding window of KB spectra: per partition ONE new X load and one H load feed KB multiply-
-// accumulates (0.25 loads per MAC at KB = 8, against 2 in the real-time form) -- the FDL is
-// L2/Infinity-Cache resident here and the cache bandwidth, not HBM, is what the loads queue on.
-// The waves split the partitions in contiguous chunks (multiples of KB, so that the window's register
-// indices are static); waves 0..KB-1 then each finish one block.
+// accumulates -- the FDL is L2/Infinity-Cache resident here and the cache bandwidth, not HBM, is what
+// the loads queue on, so a tile is made as deep as the registers allow: KB = 16, with a wave covering 64
+// bins (one per lane; B / 64 waves side by side) of one contiguous chunk of the partitions (a multiple of
+// KB, so that the window's register indices are static).  The packed pair in bin 0 is carried as if it
+// were complex; mac_finish recomputes it from the compact copies.  Waves then each finish two blocks.
 constexpr int kTileWaves = 8;
 #ifndef JF_TILE_ATTR
 #define JF_TILE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU: 128 VGPRs
 #endif
 template <int B, int KB>
 __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled_kernel(const ReverbParams P) {
-    constexpr int NB = B / 64;
-    static_assert(KB <= kTileWaves, "one finishing wave per block of the tile");
-    __shared__ float2 s_red[kTileWaves][KB][B];
-    __shared__ float2 s_fft[KB][2 * B];
+    constexpr int BH = B / 64;          // waves side by side over the bins
+    constexpr int NC = kTileWaves / BH;  // partition chunks
+    static_assert(KB <= 2 * kTileWaves, "each wave finishes at most two blocks");
+    __shared__ float2 s_red[NC][KB][B];
+    __shared__ float2 s_fft[kTileWaves][2 * B];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bh = wave % BH, c = wave / BH;
     const int kt = blockIdx.x / P.S, s = blockIdx.x - kt * P.S;
     const int k0 = kt * KB;
 
-    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + lane * NB;
-    const float2 *hs = P.hspec + lane * NB;
-    rv_v2 acc[KB][NB], acc0[KB], xr[KB][NB];
+    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + 64 * bh + lane;
+    const float2 *hs = P.hspec + 64 * bh + lane;
+    rv_v2 acc[KB], xr[KB];
 #pragma unroll
-    for (int i = 0; i < KB; i++) {
-        acc0[i] = rv_v2{0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < NB; n++) acc[i][n] = rv_v2{0.f, 0.f};
-    }
-    const int chunk = (P.P + kTileWaves * KB - 1) / (kTileWaves * KB) * KB;
-    const int pa = wave * chunk;
+    for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
+    const int chunk = (P.P + NC * KB - 1) / (NC * KB) * KB;
+    const int pa = c * chunk;
     const int pb = pa + chunk < P.P ? pa + chunk : P.P;
-    auto load_bins = [&](rv_v2 *dst, const float2 *src) {  // this lane's NB consecutive bins
-        if (NB == 2) {
-            const float4 v = *reinterpret_cast<const float4 *>(src);
-            dst[0] = rv_v2{v.x, v.y};
-            dst[NB - 1] = rv_v2{v.z, v.w};
-        } else {
-#pragma unroll
-            for (int n = 0; n < NB; n++) dst[n] = rv_v2{src[n].x, src[n].y};
-        }
-    };
-    auto load_x = [&](rv_v2 *dst, int u) {  // the spectrum of block k0 + u (u may be far in the past)
+    auto load_x = [&](int u) {  // this lane's bin of the spectrum of block k0 + u (u may be far in the past)
         int slot = (P.head + k0 + u) % P.Rg;
         if (slot < 0) slot += P.Rg;
-        load_bins(dst, fdl + (size_t)slot * B);
+        const float2 v = fdl[(size_t)slot * B];
+        return rv_v2{v.x, v.y};
     };
     // window before the chunk's first partition: X(i - pa), i = 1..KB-1, kept at xr[(i - pa) mod KB] = xr[i]
 #pragma unroll
-    for (int i = 1; i < KB; i++) load_x(xr[i], i - pa);
+    for (int i = 1; i < KB; i++) xr[i] = load_x(i - pa);
     auto step = [&](int j, int p) {  // j = p mod KB, a constant after unrolling
-        rv_v2 h[NB];
-        load_bins(h, hs + (size_t)p * B);
-        load_x(xr[(KB - j) % KB], -p);  // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
+        const float2 hv = hs[(size_t)p * B];
+        const rv_v2 h = rv_v2{hv.x, hv.y};
+        xr[(KB - j) % KB] = load_x(-p);  // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
 #pragma unroll
-        for (int i = 0; i < KB; i++) {
-            const rv_v2 *x = xr[(i + KB - j) % KB];  // X(i - p)
-#pragma unroll
-            for (int n = 0; n < NB; n++) rv_cmac(acc[i][n], x[n], h[n]);
-            rv_mac2(acc0[i], x[0], h[0]);
-        }
+        for (int i = 0; i < KB; i++) rv_cmac(acc[i], xr[(i + KB - j) % KB], h);  // X(i - p)
     };
     int p0 = pa;
     for (; p0 + KB <= pb; p0 += KB) {  // straight-line groups: loads of later steps may move above earlier MACs
@@ -325,21 +336,19 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
     for (int j = 0; j < KB; j++)
         if (p0 + j < pb) step(j, p0 + j);  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < KB; i++) {
-        if (lane == 0) acc[i][0] = acc0[i];
-#pragma unroll
-        for (int n = 0; n < NB; n++) s_red[wave][i][lane * NB + n] = make_float2(acc[i][n].x, acc[i][n].y);
-    }
+    for (int i = 0; i < KB; i++) s_red[c][i][64 * bh + lane] = make_float2(acc[i].x, acc[i].y);
     __syncthreads();
-    if (wave >= KB || k0 + wave >= P.K) return;
-    mac_finish<B, kTileWaves>(&s_red[0][wave][0], KB * B, s_fft[wave], P, s, k0 + wave, lane);
+#pragma unroll 1
+    for (int i = wave; i < KB; i += kTileWaves)
+        if (k0 + i < P.K) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
 }
 
 // ------------------------------------------------------------- IR spectra --
 // One wavefront per partition p: rfft([h_p (B taps), zeros]) * scale, packed.
 template <int B>
 __global__ __launch_bounds__(64) void reverb_ir_kernel(const float *__restrict__ ir, int n_ir, float scale,
-                                                      const float2 *__restrict__ tw, float2 *__restrict__ hspec) {
+                                                      const float2 *__restrict__ tw, float2 *__restrict__ hspec,
+                                                      float2 *__restrict__ h0 /* [P]: the packed bin-0 pairs */) {
     __shared__ float2 s_buf[2 * B];
     const int lane = threadIdx.x;
     const int p = blockIdx.x;
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(64) void reverb_ir_kernel(const float *__restrict__
         float2 x = make_float2(e.x + wo.y, e.y - wo.x);
         if (q == 0) x = make_float2(zk.x + zk.y, zk.x - zk.y);
         hspec[(size_t)p * B + q] = make_float2(x.x * scale, x.y * scale);
+        if (q == 0) h0[p] = make_float2(x.x * scale, x.y * scale);
     }
 }
 
@@ -369,9 +379,9 @@ __global__ __launch_bounds__(64) void reverb_ir_kernel(const float *__restrict__
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st) {
     switch (B) {
-    case 64: hipLaunchKernelGGL(reverb_ir_kernel<64>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
-    case 128: hipLaunchKernelGGL(reverb_ir_kernel<128>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
-    case 256: hipLaunchKernelGGL(reverb_ir_kernel<256>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec); break;
+    case 64: hipLaunchKernelGGL(reverb_ir_kernel<64>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec, d_hspec + (size_t)P * 64); break;
+    case 128: hipLaunchKernelGGL(reverb_ir_kernel<128>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec, d_hspec + (size_t)P * 128); break;
+    case 256: hipLaunchKernelGGL(reverb_ir_kernel<256>, dim3(P), dim3(64), 0, st, d_ir, n_ir, scale, d_tw, d_hspec, d_hspec + (size_t)P * 256); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -401,15 +411,15 @@ hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
     switch (P.B) {
     case 64:
         hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        launch_mac_any<64, 4, 8>(P, st);
+        launch_mac_any<64, 4, 16>(P, st);
         break;
     case 128:
         hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        launch_mac_any<128, 4, 8>(P, st);
+        launch_mac_any<128, 4, 16>(P, st);
         break;
     case 256:
         hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        launch_mac_any<256, 2, 4>(P, st);
+        launch_mac_any<256, 2, 8>(P, st);
         break;
     default: return hipErrorInvalidValue;
     }
