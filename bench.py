@@ -269,7 +269,7 @@ def main():
                                       "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None,
                                       "kernel": "reverb_fft_kernel + reverb_mac_tiled_kernel",
                                       "algorithmic_bytes_per_launch": rb, "avg_launch_ms": t * 1e3,
-                                      # the block-tiled form reads each delay-line slot once per tile of 8
+                                      # the block-tiled form reads each delay-line slot once per tile of 16
                                       # blocks and keeps the delay line (S*P KB) in the Infinity Cache, so the
                                       # per-source-block figure above is what it AVOIDS reading; what one
                                       # launch must move through HBM at least: the delay line once, the IR
