@@ -12,6 +12,9 @@
  *                  [--dwell 172] [--rounds 72] [--step 5] [--radius 0.5] [--latency]
  *   --latency  use jf_callback (the CUDA path's one-block latency, Audio.cu:104-117)
  *              instead of jf_process_block (the CPU path's ordering)
+ *   --batch N  hand the engine N callbacks at a time (jf_process_batch: the same blocks, the positions the
+ *              audio thread would have latched given up front) -- what an offline render should use: a
+ *              single source cannot fill a GPU one block at a time
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,14 +32,15 @@ static double now_s(void) {
 int main(int argc, char **argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: %s <hrir_dir> <in.wav> <out.wav> [--block B] [--azi A] [--ele E] "
-                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency]\n", argv[0]);
+                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N]\n", argv[0]);
         return 2;
     }
-    int block = 256, dwell = 172, rounds = 72, latency = 0;
+    int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0;
     float azi = 3, ele = 5, step = 5, radius = 0.5f;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--latency")) latency = 1;
         else if (i + 1 < argc && !strcmp(argv[i], "--block")) block = atoi(argv[++i]);
+        else if (i + 1 < argc && !strcmp(argv[i], "--batch")) batch = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--azi")) azi = (float)atof(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--ele")) ele = (float)atof(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--dwell")) dwell = atoi(argv[++i]);
@@ -62,7 +66,7 @@ int main(int argc, char **argv) {
     cfg.hrtf_len = 512;
     cfg.n_sources = 1; /* main.cu:60 */
     cfg.device = 0;
-    cfg.max_batch_blocks = 1;
+    cfg.max_batch_blocks = batch > 0 ? batch : 1;
     jf_engine *e = NULL;
     if (jf_engine_create_from_dir(&cfg, argv[1], &e) != JF_OK) {
         fprintf(stderr, "engine: %s\n", jf_last_error(NULL));
@@ -79,7 +83,31 @@ int main(int argc, char **argv) {
     size_t k = 0;
     int rc = JF_OK;
     const double t0 = now_s();
-    if (latency) rc = jf_callback(e, out); /* priming call, precision_test.cu:2110 */
+    if (batch > 0) {
+        /* the whole trajectory as latched records, then N blocks per call */
+        float *pos = (float *)malloc(sizeof(float) * JF_POS_FLOATS * total);
+        if (!pos) return 1;
+        float a = azi;
+        for (int r = 0; r <= rounds; r++) {
+            if (r > 0) {
+                a += step;
+                if (a >= 360) a -= 360;
+            }
+            float rec[JF_POS_FLOATS];
+            if (jf_position_from_spherical(ele, a, radius, rec) != JF_OK) {
+                fprintf(stderr, "position: %s\n", jf_last_error(NULL));
+                return 1;
+            }
+            for (int j = 0; j < dwell; j++, k++) memcpy(pos + JF_POS_FLOATS * k, rec, sizeof(rec));
+        }
+        for (k = 0; k < total && rc == JF_OK; k += (size_t)batch) {
+            const int nb = total - k < (size_t)batch ? (int)(total - k) : batch;
+            rc = jf_process_batch(e, nb, pos + JF_POS_FLOATS * k, out + 2 * (size_t)block * k);
+        }
+        free(pos);
+        rounds = -1; /* done: skip the per-block loop */
+    }
+    if (latency && batch <= 0) rc = jf_callback(e, out); /* priming call, precision_test.cu:2110 */
     for (int r = 0; r <= rounds && rc == JF_OK; r++) {
         if (r > 0) {
             azi += step;

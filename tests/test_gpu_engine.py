@@ -367,3 +367,10 @@ def test_directory_loader_and_offline_driver(jf, hrir, castanets, tmp_path):
         ora.set_spherical(0, ele, azi, rr)
         want.append(ora.process_block())
     assert np.abs(got - np.array(want)).max() <= 1.0 / 8388607 + TOL32
+
+    # --batch: the same trajectory handed over as latched records, 7 blocks per call (ragged last call)
+    outb = str(tmp_path / "outb.wav")
+    r = subprocess.run([exe, kemar, inp, outb, "--block", "256", "--azi", "3", "--ele", "5",
+                        "--dwell", "4", "--rounds", "5", "--batch", "7"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(outb, "rb").read() == open(outp, "rb").read()
