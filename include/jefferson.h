@@ -44,13 +44,23 @@ typedef struct jf_engine jf_engine;
  * Replaces the compile-time constants of Universal.cuh:4-13 and the
  * constructor arguments of `new GPUSoundSource[num_sources]` (main.cu:60-61).
  */
+/*
+ * jf_config.flags.  Default 0: bug-compatible with the reference's index/weight rule
+ * (SoundSource.cu:65-105: elevations truncated toward zero, so (-10, 0) interpolates as if it were
+ * [0, 10) with one negative weight; azimuths truncated to whole degrees, so the two weights on the 6.43 /
+ * 8 / 12 / ... degree rings do not sum to 1; no wrap from a ring's last azimuth to 360 = its first).
+ * JF_FLAG_CORRECTED_INTERPOLATION: true floor of the elevation, float azimuths folded into [0, 360) with the
+ * wrap, weights that sum to 1, elevations below -40 clamped to the lowest ring.  Not in the reference.
+ */
+#define JF_FLAG_CORRECTED_INTERPOLATION 1u
+
 typedef struct jf_config {
     int frames_per_buffer; /* FRAMES_PER_BUFFER (Universal.cuh:10): 128 or 256 (any multiple of 64 up to 256) */
     int hrtf_len;          /* HRTF_LEN (Universal.cuh:9): 512 -> PAD_LEN 1024 (Universal.cuh:12) */
     int n_sources;         /* num_sources (main.cu:60) */
     int device;            /* HIP device ordinal */
     int max_batch_blocks;  /* capacity of jf_process_batch / jf_batch_run (>= 1) */
-    unsigned flags;        /* reserved, 0 */
+    unsigned flags;        /* 0 = the reference's behaviour; JF_FLAG_* above */
 } jf_config;
 
 /* ---- init / teardown ------------------------------------------------- */
@@ -118,6 +128,8 @@ int jf_positions_from_spherical(size_t n, const float *ele, const float *azi, co
 /* SoundSource::interpolationCalculations (SoundSource.cu:65-105) + pick_hrtf
  * (hrtf_signals.cu:20-51), host side, for inspection/tests. */
 int jf_interpolation(float ele, float azi, int hrtf_indices[4], float omegas[6]);
+/* The same for an engine created with `flags` (JF_FLAG_CORRECTED_INTERPOLATION selects the corrected rule). */
+int jf_interpolation_ex(float ele, float azi, unsigned flags, int hrtf_indices[4], float omegas[6]);
 int jf_pick_hrtf(float ele, float azi);
 
 /* ---- per-block processing (Audio.cu:94-175) --------------------------- */

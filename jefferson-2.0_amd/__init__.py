@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("JF_LIB") or os.path.join(_HERE, "libjefferson_hip.so"
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
 
 JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+JF_FLAG_CORRECTED_INTERPOLATION = 1
 JF_MODE_FD_COMPLEX, JF_MODE_FD_BASIC = 0, 1
 NUM_HRTF = 710
 PAD_LEN = 1024
@@ -55,6 +56,7 @@ _SIGS = {
     "jf_position_from_cartesian": (C.c_int, [C.c_float, C.c_float, C.c_float, _f]),
     "jf_positions_from_spherical": (C.c_int, [C.c_size_t, _f, _f, _f, _f]),
     "jf_interpolation": (C.c_int, [C.c_float, C.c_float, _i, _f]),
+    "jf_interpolation_ex": (C.c_int, [C.c_float, C.c_float, C.c_uint, _i, _f]),
     "jf_pick_hrtf": (C.c_int, [C.c_float, C.c_float]),
     "jf_process_block": (C.c_int, [C.c_void_p, _f]),
     "jf_submit_block": (C.c_int, [C.c_void_p]),
@@ -144,10 +146,11 @@ def position_from_cartesian(x, y, z):
     return None if rc else o
 
 
-def interpolation(ele, azi):
+def interpolation(ele, azi, flags=0):
     idx = np.zeros(4, np.int32)
     om = np.zeros(6, np.float32)
-    rc = lib().jf_interpolation(ele, azi, _ip(idx), _fp(om))
+    rc = lib().jf_interpolation_ex(ele, azi, flags, _ip(idx), _fp(om)) if flags else \
+        lib().jf_interpolation(ele, azi, _ip(idx), _fp(om))
     return None if rc else (idx, om)
 
 
@@ -183,9 +186,9 @@ def wav_write_stereo24(path, interleaved, fs=44100):
 class Engine:
     """Thin object wrapper; method names follow the C ABI."""
 
-    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1):
+    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1, flags=0):
         L = lib()
-        cfg = JfConfig(B, hrtf_len, n_sources, device, max_batch_blocks, 0)
+        cfg = JfConfig(B, hrtf_len, n_sources, device, max_batch_blocks, flags)
         h = C.c_void_p()
         if hrir_dir is not None:
             rc = L.jf_engine_create_from_dir(C.byref(cfg), hrir_dir.encode(), C.byref(h))

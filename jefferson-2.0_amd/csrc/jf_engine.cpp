@@ -19,7 +19,7 @@ namespace jf {
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
 hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
-                               float *d_w, int *d_nt, int n, hipStream_t st);
+                               float *d_w, int *d_nt, int n, int corrected, hipStream_t st);
 hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
                        int S, int K, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, hipStream_t st);
@@ -119,6 +119,11 @@ int fail(jf_engine *e, int code, const std::string &msg) {
 
 bool valid_src(const jf_engine *e, int s) { return e && s >= 0 && s < e->S; }
 
+// what the kernels get as `mode`: bit 0 = FD_BASIC, bit 1 = the corrected index/weight rule
+static int kernel_mode(const jf_engine *e) {
+    return e->mode | ((e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 2 : 0);
+}
+
 EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
     if (pool.size() <= e->ev_used) {
         EventPair p;
@@ -176,7 +181,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
-    JF_HIP(e, launch_prep(ring_table(), e->mode, d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
+    JF_HIP(e, launch_prep(ring_table(), kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
     {
         const int rc = run_reverb_stage(e, p, K);
@@ -207,7 +212,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
                   : (e->S % 2 == 0 && n_items >= 8192)  ? 2
                                                          : 1;
     P.G = (e->S % G == 0) ? G : 1;
-    P.mode = e->mode;
+    P.mode = kernel_mode(e);
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
@@ -310,6 +315,7 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     if (pad != kN) return fail(nullptr, JF_ERR_ARG, "frames_per_buffer + hrtf_len - 1 must pad to 1024");
     if (cfg->n_sources <= 0) return fail(nullptr, JF_ERR_ARG, "n_sources must be positive");
     if (cfg->max_batch_blocks <= 0) return fail(nullptr, JF_ERR_ARG, "max_batch_blocks must be positive");
+    if (cfg->flags & ~JF_FLAG_CORRECTED_INTERPOLATION) return fail(nullptr, JF_ERR_ARG, "unknown bits in flags");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -560,6 +566,14 @@ int jf_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
     });
 }
 
+int jf_interpolation_ex(float ele, float azi, unsigned flags, int idx[4], float omegas[6]) {
+    return jf_guard([&]() -> int {
+    if (!idx || !omegas) return JF_ERR_ARG;
+    return (flags & JF_FLAG_CORRECTED_INTERPOLATION) ? host_interpolation_corrected(ele, azi, idx, omegas)
+                                                     : host_interpolation(ele, azi, idx, omegas);
+    });
+}
+
 int jf_pick_hrtf(float ele, float azi) { return host_pick_hrtf(ele, azi); }
 
 // ---- per-block -----------------------------------------------------------
@@ -594,7 +608,7 @@ int jf_submit_block(jf_engine *e) {
             P.K = 1;
             P.B = e->B;
             P.G = 1;
-            P.mode = e->mode;
+            P.mode = kernel_mode(e);
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
             int wgs = (e->S + 15) / 16;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
@@ -935,7 +949,8 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
         JF_HIP(e, hipMalloc(&d_n, sizeof(int) * n));
         JF_HIP(e, hipMemcpy(d_e, ele, sizeof(float) * n, hipMemcpyHostToDevice));
         JF_HIP(e, hipMemcpy(d_a, azi, sizeof(float) * n, hipMemcpyHostToDevice));
-        JF_HIP(e, launch_interp_debug(ring_table(), d_e, d_a, d_r, d_w, d_n, n, e->stream));
+        JF_HIP(e, launch_interp_debug(ring_table(), d_e, d_a, d_r, d_w, d_n, n,
+                                      (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(rows, d_r, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
         JF_HIP(e, hipMemcpy(weights, d_w, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));

@@ -112,6 +112,41 @@ int host_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
     return JF_OK;
 }
 
+// The corrected rule (include/jefferson.h JF_FLAG_CORRECTED_INTERPOLATION); twin of dev_interp_corrected.
+int host_interpolation_corrected(float ele, float azi, int idx[4], float omegas[6]) {
+    if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
+    const RingTable &rt = ring_table();
+    if (ele < -40.0f) ele = -40.0f;
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    const float q = floorf(ele / 10.0f);
+    const float phi0 = 10.0f * q;
+    const bool on_ring = ele == phi0;
+    const int r0 = (int)q + 4;
+    const int ring[2] = {r0, on_ring ? r0 : r0 + 1};
+    const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+    for (int j = 0; j < 2; j++) {
+        const int r = ring[j];
+        const float d = rt.inc[r];
+        const int n = rt.offset[r + 1] - rt.offset[r];
+        int i0 = (int)floorf(a / d);
+        if (i0 > n - 1) i0 = n - 1;
+        float wa = (a - (float)i0 * d) / d;
+        if (wa < 0.0f) wa = 0.0f;
+        if (wa > 1.0f) wa = 1.0f;
+        if (n == 1) wa = 0.0f;
+        int i1 = i0 + 1 == n ? 0 : i0 + 1;
+        if (wa == 0.0f) i1 = i0;
+        idx[2 * j] = rt.offset[r] + i0;
+        idx[2 * j + 1] = rt.offset[r] + i1;
+        omegas[2 * j] = wa;
+        omegas[2 * j + 1] = 1.0f - wa;
+    }
+    omegas[4] = omE;
+    omegas[5] = 1.0f - omE;
+    return JF_OK;
+}
+
 void host_from_spherical(float ele, float azi, float r, float out[5]) {
     ele = roundf(ele);
     azi = roundf(azi);

@@ -18,6 +18,7 @@ void table_position(int j, int *ele, int *azi);
 
 int host_pick_hrtf(float obj_ele, float obj_azi);                             // hrtf_signals.cu:20-51
 int host_interpolation(float ele, float azi, int idx[4], float omegas[6]);    // SoundSource.cu:65-105
+int host_interpolation_corrected(float ele, float azi, int idx[4], float omegas[6]);  // JF_FLAG_CORRECTED_INTERPOLATION
 void host_from_spherical(float ele, float azi, float r, float out[5]);        // SoundSource.cu:41-54
 int host_from_cartesian(float x, float y, float z, float out[5], float *r);   // SoundSource.cu:20-36
 

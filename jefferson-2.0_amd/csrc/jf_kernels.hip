@@ -787,7 +787,53 @@ JF_DEV int dev_pick_hrtf(const RingTable &rt, float obj_ele, float obj_azi) {
 }
 
 // returns number of terms (1, 2, 4) or 0 when the elevation ring does not exist
-JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[4], float w[4]) {
+// The corrected rule behind JF_FLAG_CORRECTED_INTERPOLATION (not in the reference):
+// true floor of the elevation, azimuth folded into [0, 360) with a ring's last interval wrapping to its first
+// entry, float azimuths (a ring's two weights sum to 1), elevations below the lowest ring clamped to it.
+// Same index order and weight meaning as the reference's rule.  Float32 step by step as in the oracles.
+JF_DEV bool dev_interp_corrected(const RingTable &rt, float ele, float azi, int h[4], float om[6]) {
+    if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return false;
+    if (ele < -40.0f) ele = -40.0f;
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    const float q = floorf(ele / 10.0f);
+    const float phi0 = 10.0f * q;
+    const bool on_ring = ele == phi0;
+    const int r0 = (int)q + 4;
+    const int ring[2] = {r0, on_ring ? r0 : r0 + 1};
+    const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+    for (int j = 0; j < 2; j++) {
+        const int r = ring[j];
+        const float d = rt.inc[r];
+        const int n = rt.offset[r + 1] - rt.offset[r];
+        int i0 = (int)floorf(a / d);
+        if (i0 > n - 1) i0 = n - 1;
+        float wa = (a - (float)i0 * d) / d;
+        if (wa < 0.0f) wa = 0.0f;
+        if (wa > 1.0f) wa = 1.0f;
+        if (n == 1) wa = 0.0f;
+        int i1 = i0 + 1 == n ? 0 : i0 + 1;
+        if (wa == 0.0f) i1 = i0;
+        h[2 * j] = rt.offset[r] + i0;
+        h[2 * j + 1] = rt.offset[r] + i1;
+        om[2 * j] = wa;
+        om[2 * j + 1] = 1.0f - wa;
+    }
+    om[4] = omE;
+    om[5] = 1.0f - omE;
+    return true;
+}
+
+JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float omegaB, float omegaC, float omegaD,
+                             float omegaE, float omegaF, int rows[4], float w[4]);
+
+JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[4], float w[4], bool corrected = false) {
+    if (corrected) {
+        int h[4];
+        float om[6];
+        if (!dev_interp_corrected(rt, ele, azi, h, om)) return 0;
+        return dev_flatten_terms(h[0], h[1], h[2], h[3], om[0], om[1], om[2], om[3], om[4], om[5], rows, w);
+    }
     if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return 0;
     const int phi0 = (int)(ele) / 10 * 10;
     const int phi1 = (int)(ele + 9) / 10 * 10;
@@ -812,7 +858,12 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
     const int h1 = dev_pick_azi(rt, r0, (float)th1);
     const int h2 = dev_pick_azi(rt, r1, (float)th2);
     const int h3 = dev_pick_azi(rt, r1, (float)th3);
-    // GPUSoundSource.cu:301-316
+    return dev_flatten_terms(h0, h1, h2, h3, omegaA, omegaB, omegaC, omegaD, omegaE, omegaF, rows, w);
+}
+
+// GPUSoundSource.cu:301-316: the case by index equality, flattened to <= 4 (row, weight) terms
+JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float omegaB, float omegaC, float omegaD,
+                             float omegaE, float omegaF, int rows[4], float w[4]) {
     if (h0 == h1 && h1 == h2 && h2 == h3) {
         rows[0] = h0; w[0] = 1.0f;
         rows[1] = rows[2] = rows[3] = h0;
@@ -845,7 +896,8 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
 JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi, x, y, z */, float old_ele,
                       float old_azi, ItemDesc &d) {
     const float ele = p[0], azi = p[1];
-    if (mode == 1) {
+    const bool corrected = (mode & 2) != 0;  // mode: bit 0 FD_BASIC, bit 1 the corrected index/weight rule
+    if (mode & 1) {
         // *_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): the nearest table row, weight 1, no
         // distance factor (D = 1), no crossfade
         const bool ok = (ele > -1.0e6f && ele < 1.0e6f) && (azi > -1.0e6f && azi < 1.0e6f);
@@ -863,11 +915,11 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
         d.pad = 0;
         return;
     }
-    d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new);
+    d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new, corrected);
     d.n_old = 0;
     // GPUSoundSource.cu:331-335
     if (old_azi != azi || old_ele != ele) {
-        d.n_old = dev_interp_terms(rt, old_ele, old_azi, d.rows_old, d.w_old);
+        d.n_old = dev_interp_terms(rt, old_ele, old_azi, d.rows_old, d.w_old, corrected);
         if (d.n_old == 0) d.n_new = 0;
     } else {
 #pragma unroll
@@ -919,7 +971,8 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
     float w[4] = {0.f, 0.f, 0.f, 0.f};
     int n = 0;
     const bool moved = old_azi != azi || old_ele != ele;  // GPUSoundSource.cu:331-335
-    if (mode == 1) {
+    const bool corrected = (mode & 2) != 0;
+    if (mode & 1) {
         // *_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): the nearest table row, weight 1, no
         // distance factor (D = 1), no crossfade
         const bool ok = (ele > -1.0e6f && ele < 1.0e6f) && (azi > -1.0e6f && azi < 1.0e6f);
@@ -930,9 +983,9 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
             n = ok ? 1 : 0;
         }
     } else if (!old_half) {
-        n = dev_interp_terms(rt, ele, azi, rows, w);
+        n = dev_interp_terms(rt, ele, azi, rows, w, corrected);
     } else if (moved) {
-        n = dev_interp_terms(rt, old_ele, old_azi, rows, w);
+        n = dev_interp_terms(rt, old_ele, old_azi, rows, w, corrected);
     }
     const int n_other = __shfl_xor(n, 1);
     if (!live) return;
@@ -951,7 +1004,7 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
         d.w_new[t] = w[t];
     }
     d.pad = 0;
-    if (mode == 1) {
+    if (mode & 1) {
         d.n_new = n;
         d.c_fix = 0;
         d.inv_frac = 1.0f;
@@ -976,12 +1029,12 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
 }
 
 __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const float *azi, int *rows,
-                                    float *w, int *nt, int n) {
+                                    float *w, int *nt, int n, int corrected) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     int r4[4] = {0, 0, 0, 0};
     float w4[4] = {0, 0, 0, 0};
-    nt[g] = dev_interp_terms(rt, ele[g], azi[g], r4, w4);
+    nt[g] = dev_interp_terms(rt, ele[g], azi[g], r4, w4, corrected != 0);
     for (int t = 0; t < 4; t++) {
         rows[4 * g + t] = r4[t];
         w[4 * g + t] = w4[t];
@@ -1111,9 +1164,9 @@ hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, floa
 }
 
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
-                               float *d_w, int *d_nt, int n, hipStream_t st) {
+                               float *d_w, int *d_nt, int n, int corrected, hipStream_t st) {
     hipLaunchKernelGGL(interp_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rt, d_ele, d_azi,
-                       d_rows, d_w, d_nt, n);
+                       d_rows, d_w, d_nt, n, corrected);
     return hipGetLastError();
 }
 

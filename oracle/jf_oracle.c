@@ -134,6 +134,47 @@ int jfo_interp(float ele, float azi, int hrtf_indices[4], float omegas[6]) {
     return 0;
 }
 
+/* The corrected rule the drop-in offers behind JF_FLAG_CORRECTED_INTERPOLATION (not in
+ * the reference): true floor/ceil of the elevation (no truncation toward zero below 0), azimuth folded into
+ * [0, 360) with the last interval of a ring wrapping to its first entry, azimuths kept in float so that a
+ * ring's two weights sum to 1, elevations below the lowest ring clamped to it.  Same index order and weight
+ * meaning as jfo_interp: idx = {ring0 low, ring0 high, ring1 low, ring1 high}, omegas = {A, B, C, D, E, F} with
+ * A/C the weight of the high azimuth, B/D of the low one, E of ring1, F of ring0. */
+int jfo_interp_corrected(float ele, float azi, int hrtf_indices[4], float omegas[6]) {
+    build_offsets();
+    if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return -1;
+    if (ele < -40.0f) ele = -40.0f;
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    const float q = floorf(ele / 10.0f);
+    const float phi0 = 10.0f * q;
+    const int on_ring = (ele == phi0);
+    const int r0 = (int)q + 4;
+    const int r1 = on_ring ? r0 : r0 + 1;
+    const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+    const int ring[2] = {r0, r1};
+    for (int j = 0; j < 2; j++) {
+        const int r = ring[j];
+        const float d = azimuth_inc[r];
+        const int n = azimuth_offset[r + 1] - azimuth_offset[r];
+        int i0 = (int)floorf(a / d);
+        if (i0 > n - 1) i0 = n - 1;
+        float wa = (a - (float)i0 * d) / d;
+        if (wa < 0.0f) wa = 0.0f;
+        if (wa > 1.0f) wa = 1.0f;
+        if (n == 1) wa = 0.0f;
+        int i1 = i0 + 1 == n ? 0 : i0 + 1;
+        if (wa == 0.0f) i1 = i0;
+        hrtf_indices[2 * j] = azimuth_offset[r] + i0;
+        hrtf_indices[2 * j + 1] = azimuth_offset[r] + i1;
+        omegas[2 * j] = wa;
+        omegas[2 * j + 1] = 1.0f - wa;
+    }
+    omegas[4] = omE;
+    omegas[5] = 1.0f - omE;
+    return 0;
+}
+
 /* GPUSoundSource.cu:301-316 (the CUDA path's predicate; CPUSoundSource.cpp:262
  * tests only idx0==idx2 for case 2 -- SURVEY.md App. C#6). */
 int jfo_case(const int h[4]) {
@@ -371,7 +412,7 @@ typedef struct {
 
 struct jfo_engine {
     int B, L, N, Nc, n_sources;
-    int mode; /* 0 = FD_COMPLEX (interpolated), 1 = FD_BASIC (nearest HRTF) */
+    int mode; /* bit 0: 0 = FD_COMPLEX (interpolated), 1 = FD_BASIC (nearest HRTF); bit 1: corrected index/weight rule */
     float *table; /* [710][2][Nc][2] */
     jfo_source *src;
     jfo_plan ph, pf;
@@ -545,7 +586,7 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
     int idx[4], rows[4], oidx[4], orows[4];
     float om[6], w[4], oom[6], ow[4];
     int nt = 0, ont = 0;
-    if (e->mode == 1) {
+    if (e->mode & 1) {
         /* CPU_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): nearest table row, no interpolation,
          * no distance factor, no crossfade */
         rows[0] = jfo_pick_hrtf(ele, azi);
@@ -561,9 +602,10 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
         memmove(q->x, q->x + B, sizeof(float) * (size_t)(N - B));
         return 0;
     }
-    if (jfo_interp(ele, azi, idx, om)) rc = -1;
+    int (*rule)(float, float, int *, float *) = (e->mode & 2) ? jfo_interp_corrected : jfo_interp;
+    if (rule(ele, azi, idx, om)) rc = -1;
     int xfade = (q->old_azi != azi || q->old_ele != ele);
-    if (xfade && jfo_interp(q->old_ele, q->old_azi, oidx, oom)) rc = -1;
+    if (xfade && rule(q->old_ele, q->old_azi, oidx, oom)) rc = -1;
     if (rc == 0) {
         nt = jfo_terms(idx, om, rows, w);
         if (xfade) ont = jfo_terms(oidx, oom, orows, ow);

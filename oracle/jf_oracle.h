@@ -51,6 +51,8 @@ int jfo_pick_hrtf(float obj_ele, float obj_azi);
 /* SoundSource.cu:65-105; returns -1 if the elevation ring does not exist
  * (the reference reads an uninitialised deltaTheta there). */
 int jfo_interp(float ele, float azi, int idx[4], float omegas[6]);
+/* the corrected rule behind the drop-in's JF_FLAG_CORRECTED_INTERPOLATION (not in the reference) */
+int jfo_interp_corrected(float ele, float azi, int idx[4], float omegas[6]);
 /* GPUSoundSource.cu:301-316 predicate -> 1..4 */
 int jfo_case(const int idx[4]);
 /* Flatten (idx, omegas) into <=4 (row, weight) terms in accumulation order
@@ -77,7 +79,7 @@ jfo_engine *jfo_create(int frames_per_buffer, int hrtf_len, int n_sources,
 void jfo_destroy(jfo_engine *e);
 int jfo_pad_len(const jfo_engine *e);
 /* Data::type (DataTag.cuh:16): 0 = *_FD_COMPLEX, 1 = *_FD_BASIC (CPUSoundSource.cpp:113-142) */
-void jfo_set_mode(jfo_engine *e, int mode);
+void jfo_set_mode(jfo_engine *e, int mode); /* bit 0: FD_BASIC; bit 1: corrected index/weight rule */
 /* cudaPart.cu:198-199 (buf/length); the engine copies. */
 int jfo_source_set_signal(jfo_engine *e, int s, const float *mono, int n);
 int jfo_source_set_spherical(jfo_engine *e, int s, float ele, float azi, float r);

@@ -125,6 +125,43 @@ def interp(ele, azi):
     return idx, [omA, omB, omC, omD, omE, omF]
 
 
+def interp_corrected(ele, azi):
+    """The corrected rule behind JF_FLAG_CORRECTED_INTERPOLATION (not in the reference):
+    true floor of the elevation, azimuth folded into [0, 360) with a ring's last interval wrapping to its first
+    entry, float azimuths (a ring's weights sum to 1), elevations below the lowest ring clamped to it.
+    float32 step by step, like jfo_interp_corrected."""
+    ele, azi = f32(ele), f32(azi)
+    if not (ele <= 90) or not (ele > -1e6) or not (-1e6 < azi < 1e6):
+        return None
+    if ele < -40:
+        ele = f32(-40)
+    a = f32(azi - f32(f32(360) * f32(math.floor(f32(azi / f32(360))))))
+    if not (a < 360):
+        a = f32(0)
+    q = f32(math.floor(f32(ele / f32(10))))
+    phi0 = f32(f32(10) * q)
+    on_ring = bool(ele == phi0)
+    r0 = int(q) + 4
+    r1 = r0 if on_ring else r0 + 1
+    omE = f32(0) if on_ring else f32(f32(ele - phi0) / f32(10))
+    idx, om = [], []
+    for r in (r0, r1):
+        d = AZIMUTH_INC[r]
+        n = AZIMUTH_OFFSET[r + 1] - AZIMUTH_OFFSET[r]
+        i0 = min(int(math.floor(f32(a / d))), n - 1)
+        wa = f32(f32(a - f32(f32(i0) * d)) / d)
+        wa = f32(min(max(wa, f32(0)), f32(1)))
+        if n == 1:
+            wa = f32(0)
+        i1 = 0 if i0 + 1 == n else i0 + 1
+        if wa == 0:
+            i1 = i0
+        idx += [AZIMUTH_OFFSET[r] + i0, AZIMUTH_OFFSET[r] + i1]
+        om += [wa, f32(f32(1) - wa)]
+    om += [omE, f32(f32(1) - omE)]
+    return idx, om
+
+
 def case_of(h):
     """GPUSoundSource.cu:301-316."""
     if h[0] == h[1] == h[2] == h[3]:
@@ -222,7 +259,7 @@ class Model:
         fn = (i / f32(self.B - 1.0)).astype(np.float32)  # kernels.cu:134
         self.fade_new = fn.astype(np.float64)
         self.fade_old = (f32(1.0) - fn).astype(np.float64)
-        self.mode = 0  # 0 = FD_COMPLEX, 1 = FD_BASIC (nearest HRTF, CPUSoundSource.cpp:113-142)
+        self.mode = 0  # bit 0: 0 = FD_COMPLEX, 1 = FD_BASIC (nearest HRTF, CPUSoundSource.cpp:113-142); bit 1: corrected rule
 
     def set_signal(self, s, mono):
         self.src[s].buf = np.asarray(mono, np.float32).copy()
@@ -263,7 +300,7 @@ class Model:
             q.count = int((q.count + B) % L)
         q.x[N - B:] = new
         X = np.fft.rfft(q.x) / N
-        if self.mode == 1:
+        if self.mode & 1:
             Y = X[None, :] * self.table[pick_hrtf(ele, azi)]
             Y[:, 0] = Y[:, 0].real
             Y[:, -1] = Y[:, -1].real
@@ -272,9 +309,10 @@ class Model:
             q.x[:N - B] = q.x[B:].copy()
             q.last = y.T.copy().reshape(-1)
             return q.last
-        cur = interp(ele, azi)
+        rule = interp_corrected if self.mode & 2 else interp
+        cur = rule(ele, azi)
         xfade = (q.old_azi != azi) or (q.old_ele != ele)
-        old = interp(q.old_ele, q.old_azi) if xfade else None
+        old = rule(q.old_ele, q.old_azi) if xfade else None
         if cur is None or (xfade and old is None):
             blk = np.zeros((B, 2))
         else:

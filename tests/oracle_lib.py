@@ -37,6 +37,8 @@ def lib():
         L.jfo_pick_hrtf.restype = C.c_int
         L.jfo_interp.argtypes = [C.c_float, C.c_float, _i, _f]
         L.jfo_interp.restype = C.c_int
+        L.jfo_interp_corrected.argtypes = [C.c_float, C.c_float, _i, _f]
+        L.jfo_interp_corrected.restype = C.c_int
         L.jfo_case.argtypes = [_i]
         L.jfo_case.restype = C.c_int
         L.jfo_terms.argtypes = [_i, _f, _i, _f]
@@ -97,10 +99,11 @@ def pick_hrtf(ele, azi):
     return lib().jfo_pick_hrtf(ele, azi)
 
 
-def interp(ele, azi):
+def interp(ele, azi, corrected=False):
     idx = np.zeros(4, np.int32)
     om = np.zeros(6, np.float32)
-    if lib().jfo_interp(ele, azi, iptr(idx), fptr(om)):
+    f = lib().jfo_interp_corrected if corrected else lib().jfo_interp
+    if f(ele, azi, iptr(idx), fptr(om)):
         return None
     return idx, om
 

@@ -82,6 +82,18 @@ def test_host_interpolation_matches_oracle(jf):
             assert jf.pick_hrtf(ele, azi) == oracle_lib.pick_hrtf(ele, azi)
 
 
+def test_host_corrected_interpolation_matches_oracle(jf):
+    """jf_interpolation_ex(JF_FLAG_CORRECTED_INTERPOLATION): the host twin of the kernel rule, bit for bit."""
+    for ele in np.arange(-45, 91, 2.5):
+        for azi in np.arange(-10, 371, 3.1):
+            a = jf.interpolation(float(ele), float(azi), jf.JF_FLAG_CORRECTED_INTERPOLATION)
+            b = oracle_lib.interp(float(ele), float(azi), corrected=True)
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert jf.interpolation(5.0, 3.0, 0)[0].tolist() == jf.interpolation(5.0, 3.0)[0].tolist()
+
+
 def test_host_positions_match_oracle(jf):
     rng = np.random.default_rng(5)
     for _ in range(200):

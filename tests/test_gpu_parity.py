@@ -77,6 +77,52 @@ def test_interp_kernel_exhaustive(eng256):
     assert bad == 0
 
 
+def test_corrected_rule_kernel_and_end_to_end(jf, hrir, castanets):
+    """JF_FLAG_CORRECTED_INTERPOLATION: the kernel's indices/weights bit-exact against the oracle's corrected rule,
+    then whole blocks (batch and per-block paths) against the oracle run with the same rule -- including the
+    places where the reference's rule misbehaves (negative elevations, azimuth 355..360, the 6.43-degree rings)."""
+    F = jf.JF_FLAG_CORRECTED_INTERPOLATION
+    eng = jf.Engine(256, 512, 6, hrir=hrir, max_batch_blocks=8, flags=F)
+    eles, azis = np.meshgrid(np.arange(-52, 94, 1.5), np.arange(-10, 372, 1.7), indexing="ij")
+    eles = eles.reshape(-1).astype(np.float32)
+    azis = azis.reshape(-1).astype(np.float32)
+    rows, w, nt = eng.interp_device(eles, azis)
+    bad = 0
+    for i in range(len(eles)):
+        r = oracle_lib.interp(float(eles[i]), float(azis[i]), corrected=True)
+        if r is None:
+            bad += nt[i] != 0
+            continue
+        orows, ow = oracle_lib.terms(*r)
+        n = len(orows)
+        bad += not (nt[i] == n and np.array_equal(rows[i, :n], orows) and np.array_equal(w[i, :n], ow))
+    assert bad == 0
+    ora = oracle_lib.Engine(256, 512, 6, hrir)
+    ora.set_mode(2)
+    ref = jf.Engine(256, 512, 6, hrir=hrir, max_batch_blocks=8)        # the reference's rule
+    spots = [(-5, 10), (0, 358), (45, 10), (-35, 200), (85, 20), (20, 40)]
+    for s in range(6):
+        for x in (eng, ora, ref):
+            x.set_signal(s, 0.5 * castanets[2000 * s: 2000 * s + 7000])
+    pos = np.zeros((8, 6, 5), np.float32)
+    for k in range(8):
+        for s, (e, a) in enumerate(spots):
+            pos[k, s] = jf.position_from_spherical(e, (a + 3 * k) % 360, 0.6)
+    got, want, other = eng.process_batch(pos), ora.process_batch(pos), ref.process_batch(pos)
+    assert np.abs(want).max() > 0.05
+    assert np.abs(got - want).max() <= TOL32 * 2
+    assert np.abs(got - other).max() > 1e-3        # the flag really changes the rendering at these positions
+    for k in range(3):                              # per-block (real-time kernel) path
+        for s, (e, a) in enumerate(spots):
+            for x in (eng, ora):
+                x.set_spherical(s, e, (a + 7 * k) % 360, 0.6)
+        assert np.abs(eng.process_block() - ora.process_block()).max() <= TOL32 * 2
+    for x in (eng, ref):
+        x.close()
+    with pytest.raises(jf.JfError):
+        jf.Engine(256, 512, 1, hrir=hrir, flags=8)
+
+
 @pytest.mark.parametrize("B", [256, 128])
 @pytest.mark.parametrize("name", list(SCENARIOS))
 def test_scenarios_vs_golden(jf, hrir, castanets, golden, B, name):

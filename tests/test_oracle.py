@@ -87,6 +87,38 @@ def test_interp_c_vs_numpy_exhaustive():
         assert a[0].tolist() == b[0] and a[1].tolist() == [float(x) for x in b[1]]
 
 
+def test_corrected_rule_restatements_and_properties():
+    """JF_FLAG_CORRECTED_INTERPOLATION (the corrected variant behind a flag; not in the
+    reference): C oracle == NumPy model bit for bit, and the properties the reference's rule lacks."""
+    import itertools
+    for ele, azi in itertools.product(np.arange(-45, 91, 1.5), np.arange(-10, 371, 2.3)):
+        a, b = oracle_lib.interp(float(ele), float(azi), corrected=True), model64.interp_corrected(ele, azi)
+        assert (a is None) == (b is None)
+        assert a[0].tolist() == b[0] and a[1].tolist() == [float(x) for x in b[1]]
+        om = a[1]
+        assert (om >= 0).all() and (om <= 1).all()                       # no extrapolation
+        assert om[0] + om[1] == 1 and om[2] + om[3] == 1 and om[4] + om[5] == 1
+    # negative elevations: true floor (the reference gives rings (0, 0) and a weight of -0.5 here)
+    idx, om = oracle_lib.interp(-5, 10, corrected=True)
+    assert idx.tolist() == [190, 190, 262, 262] and om[4] == 0.5
+    assert oracle_lib.interp(-5, 10)[0].tolist() == [262] * 4 and oracle_lib.interp(-5, 10)[1][4] == -0.5
+    # wrap from a ring's last azimuth to its first (the reference picks 355 degrees twice at azimuth 358)
+    idx, om = oracle_lib.interp(0, 358, corrected=True)
+    assert idx.tolist() == [331, 260, 331, 260] and abs(om[0] - 0.6) < 1e-6
+    assert oracle_lib.interp(0, 358)[0].tolist() == [331] * 4
+    # 6.43-degree ring: weights sum to 1 (reference: 0.6221 + 0.3110)
+    idx, om = oracle_lib.interp(45, 10, corrected=True)
+    assert idx.tolist() == [537, 538, 593, 594] and om[0] + om[1] == 1
+    # below the lowest ring: clamped to it; above 90 or non-finite: invalid
+    assert oracle_lib.interp(-47, 30, corrected=True)[0].tolist() == oracle_lib.interp(-40, 30, corrected=True)[0].tolist()
+    assert oracle_lib.interp(91, 0, corrected=True) is None and oracle_lib.interp(0, float("nan"), corrected=True) is None
+    # where the reference's rule is sound (ele >= 0 on a 5-degree ring, azimuth < 355) the two rules agree
+    for ele, azi in ((5, 3), (0, 0), (10, 5), (3, 23), (8, 18)):
+        r, c = oracle_lib.interp(ele, azi), oracle_lib.interp(ele, azi, corrected=True)
+        rt, ct = oracle_lib.terms(*r), oracle_lib.terms(*c)
+        assert rt[0].tolist() == ct[0].tolist() and np.abs(rt[1] - ct[1]).max() < 1e-6
+
+
 def test_geometry():
     """SoundSource.cu:20-54 incl. the handedness mismatch of the two setters (App. C#15,16)."""
     for ele, azi, r in [(0, 0, .5), (0, 90, 1), (30, 45, 2), (-40, 359, 3.5), (5.4, 2.6, .5)]:
