@@ -215,15 +215,7 @@ def main():
         # algorithmic bytes of the timed windows of THIS rank (every rank has the same mix of cases)
         # the run walks the uploaded period cyclically: price each step of the period once (its
         # predecessor block is the one before it on the circle) and count how often each was timed
-        terms = wl.n_terms_table(jf)
-        per_step = []
-        for j in range(n_pos // KB):
-            first_old = pos[(j * KB - 1) % n_pos, :, :2].astype(np.int64)
-            per_step.append(wl.algorithmic_bytes(jf, pos[j * KB:(j + 1) * KB], B, first_old=first_old, terms=terms))
-        abytes = rows = items = 0
-        for i in range(prewarm + W, prewarm + W + K):
-            a_, r_, i_ = per_step[i % (n_pos // KB)]
-            abytes, rows, items = abytes + a_, rows + r_, items + i_
+        abytes, rows, items = wl.algorithmic_bytes_cyclic(jf, pos, KB, B, prewarm + W, K)
         fused_s = prof["fused_ms"] * 1e-3
         achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         traffic = None

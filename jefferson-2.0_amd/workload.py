@@ -79,3 +79,25 @@ def algorithmic_bytes(jf, pos, B, first_old=None, terms=None):
     rows = int(n_new.sum() + n_old.sum())
     items = K * S
     return rows * TABLE_ROW_BYTES + items * (WINDOW_BYTES + 2 * B * 4), rows, items
+
+
+def algorithmic_bytes_cyclic(jf, pos, blocks_per_step, B, first_step, n_steps, terms=None):
+    """The same for a run that walks one uploaded period of positions [n_pos][S][5] again and again, one step =
+    blocks_per_step consecutive blocks (bench.py): every step of the period is priced once -- the block before
+    its first one is the one before it on the circle -- and counted as often as steps first_step ..
+    first_step + n_steps - 1 visit it.  n_pos must be a multiple of blocks_per_step."""
+    if terms is None:
+        terms = n_terms_table(jf)
+    n_pos = pos.shape[0]
+    assert n_pos % blocks_per_step == 0
+    per_step = []
+    for j in range(n_pos // blocks_per_step):
+        first_old = pos[(j * blocks_per_step - 1) % n_pos, :, :2].astype(np.int64)
+        per_step.append(algorithmic_bytes(jf, pos[j * blocks_per_step:(j + 1) * blocks_per_step], B,
+                                          first_old=first_old, terms=terms))
+    tot = [0, 0, 0]
+    for i in range(first_step, first_step + n_steps):
+        for c, v in enumerate(per_step[i % len(per_step)]):
+            tot[c] += v
+    return tuple(tot)
+

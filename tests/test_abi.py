@@ -260,3 +260,12 @@ def test_workload_helpers(jf):
     mov = wl.trajectories(jf, [2], 3, first_block=2)  # ele -26, azi 76, 77, 78: both ends case 4 -> 71 808 B
     b, rows, items = wl.algorithmic_bytes(jf, mov[1:], 256, first_old=mov[0, :, :2].astype(np.int64), terms=terms)
     assert b == 2 * 71808
+    # bench.py walks one uploaded period of the trajectory cyclically: same bytes as the unrolled trajectory
+    period = wl.trajectories(jf, [0, 5, 77], 360)                     # azimuth + 1 degree per block: 360 blocks
+    long = wl.trajectories(jf, [0, 5, 77], 360 + 3 * 360)
+    assert np.array_equal(long[360:720], period)
+    first, n = 7, 3 * 360 // 8 - 5                                      # steps of 8 blocks, well past one period
+    cyc = wl.algorithmic_bytes_cyclic(jf, period, 8, 256, first, n, terms=terms)
+    direct = wl.algorithmic_bytes(jf, long[8 * first:8 * (first + n)], 256,
+                                  first_old=long[8 * first - 1, :, :2].astype(np.int64), terms=terms)
+    assert cyc == direct
