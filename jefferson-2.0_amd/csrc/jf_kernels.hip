@@ -648,8 +648,15 @@ __global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
     const int a = lane & 3, i = lane >> 2;
 #pragma unroll 1
     for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+#if JF_UNIT_ORDER
+        // consecutive waves take consecutive BLOCKS of the same sources: their table rows and windows overlap
+        const int sg = unit / P.K;
+        const int b = unit - sg * P.K;
+        const int s0 = sg * G;
+#else
         const int b = unit / SG;
         const int s0 = (unit - b * SG) * G;
+#endif
         const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
         bool any_xfade = false;
         for (int g = 0; g < G; g++) any_xfade = any_xfade || (d0[g].n_old > 0 && d0[g].n_new > 0);
@@ -709,7 +716,11 @@ __global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
                 fr[j] = make_float2(old_t[j].x * (1.0f - fn) + fr[j].x * fn, old_t[j].y * (1.0f - fn) + fr[j].y * fn);
             }
         }
+#if JF_UNIT_ORDER
+        float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
+#else
         float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+#endif
 #pragma unroll
         for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
     }
