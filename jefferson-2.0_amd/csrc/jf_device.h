@@ -43,6 +43,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_MIN_WAVES
 #define JF_MIN_WAVES 0
 #endif
+#ifndef JF_XCD_MAP
+#define JF_XCD_MAP 0  // group kernel: 1 = adjacent units on one XCD (stationary -2 %, moving +0.5 %: off)
+#endif
 #ifndef JF_UNIT_ORDER
 #define JF_UNIT_ORDER 1  // group kernel: 1 = consecutive waves take consecutive blocks of the same sources (rows and windows overlap in cache: 2.8 %)
 #endif

@@ -646,8 +646,14 @@ __global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
     const int G = P.G, SG = P.S / G;
     const int n_units = P.K * SG;
     const int a = lane & 3, i = lane >> 2;
+#if JF_XCD_MAP
+    // workgroups go round-robin over the 8 XCDs (each with its own L2): give one XCD adjacent units
+    const int wg = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+#else
+    const int wg = blockIdx.x;
+#endif
 #pragma unroll 1
-    for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+    for (int unit = wg * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
 #if JF_UNIT_ORDER
         // consecutive waves take consecutive BLOCKS of the same sources: their table rows and windows overlap
         const int sg = unit / P.K;
