@@ -236,7 +236,7 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb k
 /* ---- debugging / parity taps ------------------------------------------ */
 
 /* Sources one wavefront processes back to back and sums in registers before writing a stereo block
- * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (4 or 8 for large batches);
+ * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (2 to 16 for large batches);
  * must divide n_sources.  The mix is the same sum in a different association. */
 int jf_debug_set_source_group(jf_engine *e, int group);
 /* Form of the reverb's multiply-accumulate stage: 0 = by call size (default); 1 = one workgroup per

@@ -203,10 +203,11 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     P.B = e->B;
     // sources summed in registers per wavefront: fewer, larger partial blocks for the mix kernel
     // sources a wavefront sums in registers before it stores a stereo block: as many as keep at least
-    // one unit per resident wavefront (4096 on MI355X); 8 instead of 4 saves 3 us of partial writes + mix
-    // per 65 536 items, 16 gains nothing more, 32 starves half the waves (profiles/r01_experiments.md)
+    // one unit per resident wavefront (4096 on MI355X): larger groups mean fewer inverse transforms in the
+    // group kernel and fewer partial blocks for the mix; 32 would starve half the waves (profiles/r01_experiments.md)
     const long long n_items = (long long)K * e->S;
     const int G = e->src_group > 0 ? e->src_group
+                  : (e->S % 16 == 0 && n_items >= 65536) ? 16
                   : (e->S % 8 == 0 && n_items >= 32768) ? 8
                   : (e->S % 4 == 0 && n_items >= 16384) ? 4
                   : (e->S % 2 == 0 && n_items >= 8192)  ? 2
