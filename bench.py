@@ -225,6 +225,18 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what actually bounds the kernel, from the committed PMC pass of this workload:
+        # VALU instructions per source-block and the share of the kernel's duration they occupy at 4 cycles each
+        valu = None
+        ppath = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(ppath) and ir is None and not args.stationary:
+            try:
+                f = json.load(open(ppath))["fused"]
+                valu = {"valu_insts_per_source_block": f["SQ_INSTS_VALU"] / (S * KB),
+                        "valu_issue_share_of_kernel_time": f["SQ_ACTIVE_INST_VALU"] / 1024 * 4 / (f["GRBM_GUI_ACTIVE"] / 8),
+                        "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc, 1024 SIMDs, 8 XCDs)"}
+            except Exception:
+                valu = None
         out = {
             "metric": "source-frames/s (sources x frames/sec) at 256-sample blocks",
             "value": value, "unit": "source-frames/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -245,8 +257,9 @@ def main():
                          "algorithmic_bytes_per_launch": abytes / prof["launches"] if prof["launches"] else None,
                          "avg_launch_ms": prof["fused_ms"] / prof["launches"] if prof["launches"] else None,
                          "table_rows_per_source_block": rows / items,
-                         "other_kernels": "prep_kernel ~13 us, mix_kernel ~10 us per launch "
-                                          "(profiles/r01_kernel_stats.csv)"},
+                         "other_kernels": "prep_kernel ~9 us, mix_kernel ~5 us per launch "
+                                          "(profiles/r01_kernel_stats.csv)",
+                         "issue_bound": valu},
         }
         if ir is not None:
             # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
