@@ -606,8 +606,15 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     const int a = lane & 3, i = lane >> 2;
 #pragma unroll 1
     for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
+#if JF_UNIT_ORDER
+        // consecutive waves take consecutive BLOCKS of the same sources: their table rows and windows overlap
+        const int sg = unit / P.K;
+        const int b = unit - sg * P.K;
+        const int s0 = sg * G;
+#else
         const int b = unit / SG;
         const int s0 = (unit - b * SG) * G;
+#endif
         float2 acc[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
@@ -616,7 +623,11 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
             const int item = b * P.S + s0 + g;
             spatialise_item<NOUT>(P, P.desc + item, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, acc);
         }
+#if JF_UNIT_ORDER
+        float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
+#else
         float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
+#endif
 #pragma unroll
         for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = acc[j];
     }
