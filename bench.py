@@ -261,6 +261,12 @@ def main():
                                           "(profiles/r01_kernel_stats.csv)",
                          "issue_bound": valu},
         }
+        if world > 1:
+            # the only exchange of the path: the sum of the per-rank stereo mixes
+            out["comm"] = {"collective": "reduce(sum, dst=0) of float32[%d][%d] per step" % (KB, 2 * B),
+                           "payload_bytes_per_rank_per_step": KB * 2 * B * 4,
+                           "overlap": "asynchronous on RCCL's stream, double-buffered: step i + 1 computes while "
+                                      "step i reduces; no collective on the data path of the kernels"}
         if ir is not None:
             # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
             # 690*129*8 B of IR spectra once per block (shared by all sources)
