@@ -220,6 +220,34 @@ def test_group_kernel_mixed_units(jf, hrir, castanets, B, G):
     assert np.abs(outs[1] - want).max() <= TOL32 * S / 4
 
 
+def test_source_shards_sum_to_the_whole(jf, hrir, castanets):
+    """sources are independent until the final sum, so a multi-GPU job is N engines over
+    contiguous slices of the sources and a sum of their mixes.  Two engines with half the sources each against one
+    engine with all of them (the RCCL reduce of bench.py does the addition across processes)."""
+    S, K, B = 32, 12, 256
+    wl = _workload()
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            pos[k, s] = jf.position_from_spherical(-35 + (9 * s) % 120, (23 * s + 2 * k) % 360, 0.5 + 0.03 * s)
+    sigs = [np.roll(castanets, 911 * s)[:20000] for s in range(S)]
+    whole = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    for s in range(S):
+        whole.set_signal(s, sigs[s])
+    want = whole.process_batch(pos)
+    whole.close()
+    total = np.zeros_like(want)
+    for rank in range(2):
+        lo, hi = wl.shard_range(S, 2, rank)
+        part = jf.Engine(B, 512, hi - lo, hrir=hrir, max_batch_blocks=K)
+        for s in range(lo, hi):
+            part.set_signal(s - lo, sigs[s])
+        total += part.process_batch(np.ascontiguousarray(pos[:, lo:hi]))
+        part.close()
+    assert np.abs(want).max() > 0.2
+    assert np.abs(total - want).max() <= TOL32 * S / 4
+
+
 def test_full_size_moving_workload_properties(jf, hrir):
     """BASELINE.json configs[2] at full width (1024 moving sources, B = 256): the oracle is too
     slow to replay it all in a test, so check (1) a sample of sources against the oracle,
