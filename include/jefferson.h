@@ -175,8 +175,13 @@ int jf_pa_callback(const void *input, void *output, unsigned long frames_per_buf
 enum { JF_MODE_FD_COMPLEX = 0, JF_MODE_FD_BASIC = 1 };
 int jf_set_mode(jf_engine *e, int mode);
 
-/* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed. */
+/* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed.
+ * Like jf_set_mode, callable from another thread than the audio thread (an atomic flag read at every block). */
 int jf_set_pause(jf_engine *e, int paused);
+
+/* The clip alert of callback_func (Audio.cu:111-113 prints "ALERT" when a mixed sample exceeds 1.0): max |sample|
+ * of the last block handed out by jf_collect_block / jf_process_block / jf_callback / jf_pa_callback. */
+float jf_last_block_peak(const jf_engine *e);
 
 /* ---- convolution reverb -------------------------------- */
 
@@ -249,6 +254,20 @@ int jf_debug_set_reverb_form(jf_engine *e, int form);
  * I/O, the workgroups' blocks added on the host in order); above that, the batch pipeline with one block.
  * Default 256; 0 disables the real-time kernel. */
 int jf_debug_set_rt_max_sources(jf_engine *e, int n);
+/* G the last batch pipeline run used (1 = fused_block_kernel, > 1 = fused_group_kernel). */
+int jf_debug_last_source_group(const jf_engine *e);
+/* Caps the persistent grid of the fused kernel at `workgroups` (0 = what the device holds): with a small cap every
+ * wavefront loops over several work units, which full-size calls do only beyond 4096 units. */
+int jf_debug_set_grid_limit(jf_engine *e, int workgroups);
+/*
+ * Stage taps the reference's own tests compare (precision_test.cu:60-75 distance factor, :225-241 and :374-404
+ * weighted spectra), through the device code of the fused kernels.  positions[n][JF_POS_FLOATS];
+ * dist[n][513][2]: D[k] of generateDistanceFactor (kernels.cu:116-125; bin 512: real part only, imaginary 0 --
+ * c2r never reads it).  If spectra != NULL: windows[n][1024] -> spectra[n][2][513][2] = Y_ear[k] =
+ * sum_t w_t X[k] H[row_t][ear][k] D[k] with X = rfft(window)/N, the filter set of positions[i].
+ */
+int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float *windows, float *dist,
+                        float *spectra);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 

@@ -80,6 +80,10 @@ _SIGS = {
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_form": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_last_block_peak": (C.c_float, [C.c_void_p]),
+    "jf_debug_last_source_group": (C.c_int, [C.c_void_p]),
+    "jf_debug_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_stage_taps": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _f, _f]),
     "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jf_debug_set_rt_max_sources": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
@@ -307,6 +311,30 @@ class Engine:
 
     def set_source_group(self, g):
         self._chk(lib().jf_debug_set_source_group(self.h, int(g)))
+
+    def last_source_group(self):
+        return lib().jf_debug_last_source_group(self.h)
+
+    def set_grid_limit(self, wgs):
+        self._chk(lib().jf_debug_set_grid_limit(self.h, int(wgs)))
+
+    def last_block_peak(self):
+        return float(lib().jf_last_block_peak(self.h))
+
+    def stage_taps(self, positions, windows=None):
+        """positions [n][5] (and windows [n][1024]) -> D [n][513] complex64 (and Y [n][2][513] complex64)."""
+        positions = np.ascontiguousarray(positions, np.float32)
+        n = positions.shape[0]
+        dist = np.zeros((n, NC, 2), np.float32)
+        spec = None
+        if windows is not None:
+            windows = np.ascontiguousarray(windows, np.float32)
+            assert windows.shape == (n, PAD_LEN)
+            spec = np.zeros((n, 2, NC, 2), np.float32)
+        self._chk(lib().jf_debug_stage_taps(self.h, n, _fp(positions), _fp(windows) if spec is not None else None,
+                                            _fp(dist), _fp(spec) if spec is not None else None))
+        d = dist.view(np.complex64)[..., 0]
+        return d if spec is None else (d, spec.view(np.complex64)[..., 0])
 
     def set_reverb_form(self, form):
         self._chk(lib().jf_debug_set_reverb_form(self.h, int(form)))

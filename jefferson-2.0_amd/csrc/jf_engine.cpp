@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -22,7 +23,11 @@ hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const fl
                                float *d_w, int *d_nt, int n, int corrected, hipStream_t st);
 hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
                        int S, int K, hipStream_t st);
-hipError_t launch_fused(const FusedParams &P, hipStream_t st);
+hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st);
+hipError_t fused_resident_workgroups(int nb, bool group, int *out);
+hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos, const float *d_win, int n,
+                              const float4 *d_htab, const float2 *d_tw, float2 *d_dist, float2 *d_spec,
+                              hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
                            hipStream_t st);
@@ -68,15 +73,21 @@ struct jf_engine {
     int traj_blocks = 0;
     int cur = 0;  // parity of the valid state/history
     int src_group = 0;  // 0 = automatic
+    int last_group = 0; // G of the last batch pipeline run
     int rv_form = 0;    // 0 = automatic
-    int mode = 0;       // Data::type: 0 = FD_COMPLEX, 1 = FD_BASIC
+    // Data::type and Data::pauseStatus are written by the UI thread and read by the audio thread at every
+    // block (Audio.cu:101,104)
+    std::atomic<int> mode{0};  // 0 = FD_COMPLEX, 1 = FD_BASIC
+    std::atomic<int> paused{0};
+    int resident_wgs[2] = {0, 0};  // persistent-grid size of the per-source / the group kernel on this device
+    int grid_limit = 0;            // > 0: tests shrink the grid so that waves loop over several units
+    float last_peak = 0.0f;        // max |sample| of the last block handed out (Audio.cu:111-113 clip alert)
 
     std::vector<float *> d_signal;  // per source
     std::vector<SrcSignal> h_sigs;
 
     std::mutex pos_mu;  // setters may come from another thread (graphics.cu:378)
     std::vector<HostPos> pos;
-    bool paused = false;
 
     float *h_pos_pinned = nullptr;  // [S][5]   pinned + mapped: the real-time kernel reads it in place
     float *h_out_pinned = nullptr;  // [kRtMaxWgs][2B] pinned + mapped: ... and writes its workgroups' stereo blocks in place
@@ -119,9 +130,27 @@ int fail(jf_engine *e, int code, const std::string &msg) {
 
 bool valid_src(const jf_engine *e, int s) { return e && s >= 0 && s < e->S; }
 
+// Every ABI entry that reaches HIP binds the engine's device for its duration: the callback runs on
+// PortAudio's thread, the setters on the UI thread, and a host with one engine per GPU switches devices
+// between calls -- a thread's current device is 0 until somebody sets it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const jf_engine *e) {
+        if (!e) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != e->cfg.device)
+            switched = hipSetDevice(e->cfg.device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // what the kernels get as `mode`: bit 0 = FD_BASIC, bit 1 = the corrected index/weight rule
 static int kernel_mode(const jf_engine *e) {
-    return e->mode | ((e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 2 : 0);
+    return e->mode.load(std::memory_order_relaxed) | ((e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 2 : 0);
 }
 
 EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
@@ -213,9 +242,12 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
                   : (e->S % 2 == 0 && n_items >= 8192)  ? 2
                                                          : 1;
     P.G = (e->S % G == 0) ? G : 1;
+    e->last_group = P.G;
     P.mode = kernel_mode(e);
+    int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
+    if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
-    JF_HIP(e, launch_fused(P, e->stream));
+    JF_HIP(e, launch_fused(P, max_wgs, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
     if (em) JF_HIP(e, hipEventRecord(em->a, e->stream));
     JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
@@ -275,6 +307,7 @@ int reset_sources(jf_engine *e, int src) {
 
 void destroy_engine(jf_engine *e) {
     if (!e) return;
+    DeviceGuard bind(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_reverb(e);
     for (float *p : e->d_signal)
@@ -330,9 +363,13 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     e->maxK = cfg->max_batch_blocks;
     const size_t S = (size_t)e->S, K = (size_t)e->maxK;
     int rc = JF_OK;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     auto body = [&]() -> int {
         JF_HIP(e, hipSetDevice(cfg->device));
         JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        JF_HIP(e, fused_resident_workgroups(B / 64, false, &e->resident_wgs[0]));
+        JF_HIP(e, fused_resident_workgroups(B / 64, true, &e->resident_wgs[1]));
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
@@ -395,10 +432,11 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     if (rc != JF_OK) {
         g_create_error = e->err;
         destroy_engine(e);
-        return rc;
+        e = nullptr;
     }
+    if (prev_dev >= 0 && prev_dev != cfg->device) (void)hipSetDevice(prev_dev);  // leave the caller's device as it was
     *out = e;
-    return JF_OK;
+    return rc;
 }
 
 }  // namespace
@@ -450,6 +488,7 @@ int jf_num_sources(const jf_engine *e) { return e ? e->S : JF_ERR_ARG; }
 
 int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     // The device copy always has length >= PAD_LEN so that the kernel wraps the loop with
@@ -531,6 +570,7 @@ int jf_source_get_position(const jf_engine *e, int src, float out[6]) {
 
 int jf_source_reset(jf_engine *e, int src) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     return reset_sources(e, src);
@@ -580,9 +620,10 @@ int jf_pick_hrtf(float ele, float azi) { return host_pick_hrtf(ele, azi); }
 // ---- per-block -----------------------------------------------------------
 int jf_submit_block(jf_engine *e) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a block is already in flight");
-    if (e->paused) {  // Audio.cu:101: nothing is consumed, output is silence
+    if (e->paused.load(std::memory_order_relaxed)) {  // Audio.cu:101: nothing is consumed, output is silence
         JF_HIP(e, hipMemsetAsync(e->d_mix, 0, sizeof(float) * 2 * e->B, e->stream));
     } else {
         snapshot_positions(e, e->h_pos_pinned);
@@ -633,6 +674,7 @@ int jf_submit_block(jf_engine *e) {
 
 int jf_collect_block(jf_engine *e, float *out) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || !out) return JF_ERR_ARG;
     if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -642,6 +684,9 @@ int jf_collect_block(jf_engine *e, float *out) {
         const float *pg = e->h_out_pinned + (size_t)g * 2 * e->B;
         for (int n = 0; n < 2 * e->B; n++) out[n] += pg[n];
     }
+    float peak = 0.0f;
+    for (int n = 0; n < 2 * e->B; n++) peak = fmaxf(peak, fabsf(out[n]));
+    e->last_peak = peak;
     e->in_flight = false;
     return JF_OK;
     });
@@ -686,7 +731,7 @@ int jf_pa_callback(const void *, void *output, unsigned long frames, const void 
 int jf_set_mode(jf_engine *e, int mode) {
     return jf_guard([&]() -> int {
     if (!e || (mode != JF_MODE_FD_COMPLEX && mode != JF_MODE_FD_BASIC)) return fail(e, JF_ERR_ARG, "unknown mode");
-    e->mode = mode;  // read at the next block, like Data::type (Audio.cu:104)
+    e->mode.store(mode, std::memory_order_relaxed);  // read at the next block, like Data::type (Audio.cu:104)
     return JF_OK;
     });
 }
@@ -694,7 +739,7 @@ int jf_set_mode(jf_engine *e, int mode) {
 int jf_set_pause(jf_engine *e, int paused) {
     return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
-    e->paused = paused != 0;
+    e->paused.store(paused != 0, std::memory_order_relaxed);
     return JF_OK;
     });
 }
@@ -702,6 +747,7 @@ int jf_set_pause(jf_engine *e, int paused) {
 // ---- convolution reverb ----------------------------------------------------
 int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || (n_ir && !ir) || n_ir > (size_t)1 << 26) return fail(e, JF_ERR_ARG, "bad impulse response");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -767,6 +813,7 @@ float jf_reverb_rms_gain(const float *signal, size_t n, const float *ir, size_t 
 
 int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || !reverb_ms) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     double r = 0;
@@ -783,6 +830,7 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms) {
 // ---- batch -----------------------------------------------------------------
 int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *positions) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || total_blocks <= 0 || !positions) return fail(e, JF_ERR_ARG, "bad trajectory");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     const size_t bytes = sizeof(float) * 5 * (size_t)e->S * (size_t)total_blocks;
@@ -800,6 +848,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
 
 int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     if (n_blocks <= 0 || n_blocks > e->maxK) return fail(e, JF_ERR_ARG, "n_blocks exceeds max_batch_blocks");
     if (first_block < 0 || first_block + n_blocks > e->traj_blocks)
@@ -811,6 +860,7 @@ int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) 
 
 int jf_synchronize(jf_engine *e) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     return JF_OK;
@@ -819,6 +869,7 @@ int jf_synchronize(jf_engine *e) {
 
 int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *out_mix) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || !positions || !out_mix || n_blocks <= 0) return fail(e, JF_ERR_ARG, "bad batch arguments");
     int rc = jf_batch_upload_positions(e, n_blocks, positions);
     if (rc) return rc;
@@ -841,6 +892,7 @@ void *jf_engine_stream(jf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int jf_profile_enable(jf_engine *e, int enable) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     e->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
@@ -851,6 +903,7 @@ int jf_profile_enable(jf_engine *e, int enable) {
 
 int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     double f = 0, p = 0, m = 0;
@@ -876,6 +929,7 @@ int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix
 // ---- debugging taps -----------------------------------------------------------
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || !device_ptr || !host) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
     JF_HIP(e, hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost));
@@ -909,6 +963,7 @@ int jf_debug_set_reverb_form(jf_engine *e, int form) {
 
 int jf_debug_read_table(jf_engine *e, float *out) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || !out) return JF_ERR_ARG;
     std::vector<float4> h((size_t)kNumHrtf * 512);
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -939,6 +994,7 @@ int jf_debug_read_table(jf_engine *e, float *out) {
 int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *azi, int *rows, float *weights,
                            int *nterms) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || n <= 0 || !ele || !azi || !rows || !weights || !nterms) return JF_ERR_ARG;
     float *d_e = nullptr, *d_a = nullptr, *d_w = nullptr;
     int *d_r = nullptr, *d_n = nullptr;
@@ -970,6 +1026,7 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
 
 int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spectra) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || n <= 0 || !windows || !spectra) return JF_ERR_ARG;
     float *d_w = nullptr;
     float2 *d_s = nullptr;
@@ -988,6 +1045,50 @@ int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spect
     return rc;
     });
 }
+
+int jf_debug_last_source_group(const jf_engine *e) { return e ? e->last_group : JF_ERR_ARG; }
+
+int jf_debug_set_grid_limit(jf_engine *e, int workgroups) {
+    return jf_guard([&]() -> int {
+    if (!e || workgroups < 0) return JF_ERR_ARG;
+    e->grid_limit = workgroups;
+    return JF_OK;
+    });
+}
+
+int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float *windows, float *dist,
+                        float *spectra) {
+    return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
+    if (!e || n <= 0 || !positions || !dist || (spectra && !windows)) return JF_ERR_ARG;
+    float *d_p = nullptr, *d_w = nullptr;
+    float2 *d_d = nullptr, *d_s = nullptr;
+    auto body = [&]() -> int {
+        JF_HIP(e, hipMalloc(&d_p, sizeof(float) * 5 * (size_t)n));
+        JF_HIP(e, hipMalloc(&d_d, sizeof(float2) * (size_t)n * kNc));
+        JF_HIP(e, hipMemcpy(d_p, positions, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice));
+        if (spectra) {
+            JF_HIP(e, hipMalloc(&d_w, sizeof(float) * (size_t)n * kN));
+            JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * 2 * kNc));
+            JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
+        }
+        JF_HIP(e, launch_stage_debug(ring_table(), kernel_mode(e), d_p, d_w, n, e->d_htab, e->d_twpack, d_d, d_s,
+                                     e->stream));
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+        JF_HIP(e, hipMemcpy(dist, d_d, sizeof(float2) * (size_t)n * kNc, hipMemcpyDeviceToHost));
+        if (spectra) JF_HIP(e, hipMemcpy(spectra, d_s, sizeof(float2) * (size_t)n * 2 * kNc, hipMemcpyDeviceToHost));
+        return JF_OK;
+    };
+    int rc = body();
+    (void)hipFree(d_p);
+    (void)hipFree(d_w);
+    (void)hipFree(d_d);
+    (void)hipFree(d_s);
+    return rc;
+    });
+}
+
+float jf_last_block_peak(const jf_engine *e) { return e ? e->last_peak : 0.0f; }
 
 // ---- WAV -----------------------------------------------------------------------
 int jf_wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate) {

@@ -8,15 +8,20 @@
 //
 //   window gather (signal ring / previous window)            a5
 //   real FFT 1024 = complex FFT 512 (radix 8x8x8 Stockham, two LDS exchanges)
-//     + split post-pass with a cross-lane mirror (ds_bpermute)        a6
-//   distance factor D[k] (double phase reduction, float sincos)        a7
+//     + split post-pass; the Hermitian partner Z[512-k] comes from lane 64 - lane through LDS (mirror8)  a6
+//   distance factor D[k]: exact 64-bit fixed-point phase k*c mod 1, float minimax sin/cos of the
+//     remainder after the nearest quarter turn (no f64, no table)        a7
 //   sum_i w_i H_i[k] from the interleaved table, * X[k] D[k], both ears  a8
-//   inverse: Z = Y_L + j Y_R, built in registers (mirror by ds_bpermute),
+//   inverse: Z = Y_L + j Y_R, built in registers (upper half mirrored through LDS, mirror8),
 //     1024-point inverse as 4 decimated 256-point transforms
 //     (radix 16x16, ONE LDS exchange) + a pruned last radix-4 done as a
-//     DPP quad reduction -- only the last B samples are ever formed     a9
+//     DPP quad reduce-scatter -- only the last B samples are ever formed  a9
 //   crossfade old/new filter sets in registers                          a10
 //   store the B stereo frames of this source                            a11
+//
+// fused_block_kernel: one stereo block per source (the reference's `intermediate`); fused_group_kernel: the NEW
+// filter sets of G consecutive sources summed as spectra and inverted once; rt_block_kernel: one launch per audio
+// block for the per-block calls.
 //
 // A second tiny kernel sums the per-source blocks in source order (a12), a
 // third computes indices/weights (a2, a3) for every item.
@@ -1178,7 +1183,77 @@ __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict_
     }
 }
 
+// parity taps of the stages the reference's own tests compare (precision_test.cu:60-75 distance factor,
+// :225-241 weighted spectra): one wave per latched position record, through the same device code as the
+// fused kernels (make_desc -> distance_factors -> filtered_bins).
+//   dist [n][513] float2: D[k] of kernels.cu:116-125 (bin 512: the real part only -- the only part that is
+//                         ever used, c2r drops Im Y[512]; its imaginary part is written as 0)
+//   spec [n][2][513] float2 (may be null): Y_ear[k] = sum_t w_t X[k] H[row_t][ear][k] D[k] for the window
+//                         win[n][1024] (X includes the 1/N of GPUSoundSource.cu:344-346), NEW filter set
+__global__ __launch_bounds__(64) void stage_debug_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
+                                                        const float *__restrict__ win, const float4 *__restrict__ htab,
+                                                        const float2 *__restrict__ twg, float2 *__restrict__ dist,
+                                                        float2 *__restrict__ spec) {
+    __shared__ float2 s_tw[kTwPack];
+    __shared__ float2 s_buf[576];
+    __shared__ ItemDesc s_desc;
+    const int lane = threadIdx.x;
+    for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
+    const float *p = pos + 5 * (size_t)blockIdx.x;
+    if (lane == 0) {
+        ItemDesc d;
+        make_desc(rt, mode, p, p[0], p[1], d);  // old == new: no crossfade
+        s_desc = d;
+    }
+    __syncthreads();
+    const ItemDesc *dp = &s_desc;
+    const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
+    float2 dq[8];
+    float d512x;
+    distance_factors(c_hi, c_lo, dp->inv_frac, lane, dq, d512x);
+    float2 *dout = dist + (size_t)blockIdx.x * kNc;
+#pragma unroll
+    for (int q = 0; q < 8; q++) dout[lane + 64 * q] = dq[q];
+    if (lane == 0) dout[512] = make_float2(d512x, 0.0f);
+    if (!spec) return;
+    float2 *yl = spec + (size_t)blockIdx.x * 2 * kNc, *yr = yl + kNc;
+    if (dp->n_new <= 0) {
+        for (int k = lane; k < kNc; k += 64) yl[k] = yr[k] = make_float2(0.f, 0.f);
+        return;
+    }
+    const float *x = win + (size_t)blockIdx.x * kN;
+    float2 z[8], X[8], xd[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) z[r] = *reinterpret_cast<const float2 *>(x + 2 * (lane + 64 * r));
+    rfft1024_wave(z, X, s_buf, s_tw, lane);
+    const float sc = 1.0f / 2048.0f;  // 1/N and the split pass's 1/2 (rfft1024_wave returns twice the spectrum)
+#pragma unroll
+    for (int q = 0; q < 8; q++) xd[q] = cmul(make_float2(X[q].x * sc, X[q].y * sc), dq[q]);
+    const float2 x0 = make_float2(X[0].x * sc * dq[0].x, X[0].y * sc * d512x);
+    xd[0] = lane == 0 ? x0 : xd[0];
+    filtered_bins_nt(dp->n_new, htab, dp->rows_new, dp->w_new, xd, lane, [&](int q, float2 zk, float2 zm) {
+        // zk = Y_L + j Y_R, zm = conj Y_L + j conj Y_R
+        if (q == 0 && lane == 0) {  // zk = (Y_L[0], Y_R[0]), zm = (Y_L[512], Y_R[512]), all real
+            yl[0] = make_float2(zk.x, 0.f);
+            yr[0] = make_float2(zk.y, 0.f);
+            yl[512] = make_float2(zm.x, 0.f);
+            yr[512] = make_float2(zm.y, 0.f);
+        } else {
+            yl[lane + 64 * q] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            yr[lane + 64 * q] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        }
+    });
+}
+
 // ---------------------------------------------------------------- launchers --
+hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos, const float *d_win, int n,
+                              const float4 *d_htab, const float2 *d_tw, float2 *d_dist, float2 *d_spec,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(stage_debug_kernel, dim3(n), dim3(64), 0, st, rt, mode, d_pos, d_win, d_htab, d_tw, d_dist,
+                       d_spec);
+    return hipGetLastError();
+}
+
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
                               hipStream_t st) {
     hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
@@ -1205,31 +1280,47 @@ hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const 
     return hipGetLastError();
 }
 
-hipError_t launch_fused(const FusedParams &P, hipStream_t st) {
-    if (P.G <= 0 || P.S % P.G) return hipErrorInvalidValue;
+// Resident workgroups of the fused kernel that a call with these parameters launches (per-source kernel for
+// G = 1, group kernel otherwise), on the CURRENT device: CUs x workgroups per CU for this build's LDS and register
+// footprint.  The engine asks once per (kernel, block size) at creation and keeps the answer with its device.
+hipError_t fused_resident_workgroups(int nb, bool group, int *out) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    hipError_t q = hipGetDevice(&dev);
+    if (q == hipSuccess) q = hipGetDeviceProperties(&prop, dev);
+    if (q != hipSuccess) return q;
+    const int threads = 64 * kWavesPerWg;
+    if (group) {
+        switch (nb) {
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<1>, threads, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<2>, threads, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<3>, threads, 0); break;
+        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<4>, threads, 0); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (nb) {
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<1>, threads, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<2>, threads, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<3>, threads, 0); break;
+        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<4>, threads, 0); break;
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (q != hipSuccess) return q;
+    if (per_cu < 1) per_cu = 1;
+    *out = prop.multiProcessorCount * per_cu;
+    return hipSuccess;
+}
+
+// Persistent grid: at most max_wgs workgroups (what the GPU holds at once, fused_resident_workgroups; an
+// over-estimate only queues the surplus workgroups -- the unit loop is a plain stride, there is no grid
+// barrier, and every wave leaves the loop once unit >= n_units).
+hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
+    if (P.G <= 0 || P.S % P.G || max_wgs < 1) return hipErrorInvalidValue;
     const int n_items = P.K * (P.S / P.G);
-    // Persistent grid: as many workgroups as the GPU holds at once (CUs x resident workgroups per CU
-    // for this build's LDS and register footprint, from the occupancy query; an over-estimate only
-    // queues the surplus workgroups -- the item loop is a plain stride, there is no grid barrier).
-    static int max_wgs_of[5] = {0, 0, 0, 0, 0};
     const int nb = P.B / 64;
     if (nb < 1 || nb > 4) return hipErrorInvalidValue;
-    if (max_wgs_of[nb] == 0) {
-        int dev = 0, cus = 256, per_cu = 1;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        hipError_t q = hipErrorUnknown;
-        switch (nb) {
-        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<1>, 64 * kWavesPerWg, 0); break;
-        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<2>, 64 * kWavesPerWg, 0); break;
-        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<3>, 64 * kWavesPerWg, 0); break;
-        default: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_block_kernel<4>, 64 * kWavesPerWg, 0); break;
-        }
-        if (q != hipSuccess || per_cu < 1) per_cu = 1;
-        max_wgs_of[nb] = cus * per_cu;
-    }
-    const int max_wgs = max_wgs_of[nb];
     int wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
     if (wgs > max_wgs) wgs = max_wgs;
     const dim3 grid(wgs), block(64 * kWavesPerWg);

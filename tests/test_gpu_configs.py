@@ -1,0 +1,349 @@
+"""The configurations BASELINE.json quotes, at their own sizes, against the oracle on a real MI355X:
+
+* configs[2] in the exact shape bench.py times (1024 moving sources x 64 blocks per launch, automatic source
+  grouping = fused_group_kernel<4> with G = 16), the whole mix against the float32 C oracle and sampled source
+  groups against the float64 model;
+* the group kernel with more work units than resident wavefronts (every wave loops);
+* configs[4]'s own multiply-accumulate kernel (block tiles, 690 partitions of 128) against a float64 convolution;
+* the reference's real HRIR length, 512 taps (Universal.cuh:9; the live loader reads the 512-tap "full" KEMAR set,
+  hrtf_signals.cu:107-153) -- the committed fixture is the 128-tap compact set, so the 512-tap table is synthetic;
+* the stage taps the reference's own tests compare (precision_test.cu:60-75 distance factor, :225-241 weighted
+  spectra), incl. radii far beyond the alias-free range.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import model64
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 2e-7   # the reference's own CPU-vs-GPU bound (precision_test.cu:2158)
+TOL32 = 4e-7
+
+
+def _workload():
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+    return wl
+
+
+def _ordered_mix(part):
+    """mix_kernel's association: 16 groups of consecutive partial blocks, each summed in order in float32,
+    then the group sums in group order.  part [K][n][2B] float32."""
+    K, n, _ = part.shape
+    per = -(-n // 16)
+    acc = None
+    for g in range(16):
+        lo, hi = g * per, min(n, (g + 1) * per)
+        gs = np.zeros((K, part.shape[2]), np.float32)
+        for s in range(lo, hi):
+            gs = gs + part[:, s]
+        acc = gs if acc is None else acc + gs
+    return acc
+
+
+def test_bench_shape_against_the_oracle(jf, hrir):
+    """Exactly what bench.py launches: S = 1024, K = 64 blocks per call, B = 256, default grouping, two
+    consecutive calls (so that windows, counters and crossfade state carry).  Every block of the mix against the
+    float32 C oracle run on all 1024 sources; 8 sampled groups of 16 sources against the float64 model."""
+    wl = _workload()
+    S, K, B, CALLS = 1024, 64, 256, 2
+    ids = np.arange(S)
+    pos = wl.trajectories(jf, ids, CALLS * K)
+    sigs = [wl.source_signal_and_start(s)[0] for s in ids]   # the 1 s signals of the bench
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    for s in ids:
+        e.set_signal(int(s), sigs[s])
+    e.upload_positions(pos)
+    mixes, parts = [], []
+    for c in range(CALLS):
+        e.batch_run(c * K, K)
+        e.synchronize()
+        G = e.last_source_group()
+        assert G == 16, "bench.py's shape must take fused_group_kernel with G = 16"
+        parts.append(e.read_device(e.partial_device_ptr(), (K, S // G, 2 * B)))
+        mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
+    e.close()
+    mix = np.concatenate(mixes)
+    part = np.concatenate(parts)                             # [2K][64 groups][2B]
+
+    # the mix is the ordered float32 sum of the group blocks
+    assert np.array_equal(mix, _ordered_mix(part))
+
+    # the whole job on the float32 C oracle (all host threads; ~1 s)
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in ids:
+        ora.set_signal(int(s), sigs[s])
+    omix, opart = ora.process_batch(pos, want_partial=True)   # opart [S][2K][2B]
+    ora.close()
+    want_groups = opart.astype(np.float64).reshape(S // 16, 16, CALLS * K, 2 * B).sum(axis=1).transpose(1, 0, 2)
+    assert np.abs(want_groups).max() > 1.0
+    # 16 sources per group block, each within TOL32 of the oracle
+    assert np.abs(part - want_groups).max() <= TOL32 * 16
+    # |mix| ~ 10: the sum of 1024 sources, float32 accumulation in two different associations
+    want_mix = opart.astype(np.float64).sum(axis=0)
+    assert np.abs(mix - want_mix).max() <= 3e-5
+    assert np.abs(mix - omix).max() <= 6e-5
+
+    # sampled groups against the float64 model (the truth for the tolerance)
+    for g in (0, 1, 13, 31, 32, 47, 62, 63):
+        src = list(range(16 * g, 16 * g + 16))
+        mod = model64.Model(B, 512, 16, hrir)
+        for j, s in enumerate(src):
+            mod.set_signal(j, sigs[s])
+        m64, _ = mod.process_batch(pos[:, src])
+        assert np.abs(part[:, g] - m64).max() <= TOL64 * 16, g
+
+
+@pytest.mark.parametrize("B,G,limit", [(256, 16, 2), (128, 8, 3), (256, 1, 2)])
+def test_waves_loop_over_several_units(jf, hrir, castanets, B, G, limit):
+    """A persistent grid smaller than the work: every wavefront takes several units one after the other
+    (re-zeroed spectral sums, LDS slots and buffers reused after the inverse) -- what a full-size call does
+    beyond 4096 units.  Against the float32 oracle and against the same call on the full grid."""
+    S, K = 64, 9
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            moving = s % 5 != 0
+            pos[k, s] = jf.position_from_spherical(-40 + (7 * s) % 121, (37 * s + (k if moving else 0)) % 360,
+                                                   0.5 + 0.04 * s)
+    sigs = [np.roll(castanets, 411 * s)[: 9000 + 100 * s] for s in range(S)]
+    outs = []
+    for lim in (0, limit):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+        e.set_source_group(G)
+        e.set_grid_limit(lim)      # `limit` workgroups of 16 waves for K * S / G units
+        for s in range(S):
+            e.set_signal(s, sigs[s])
+        outs.append(e.process_batch(pos))
+        assert e.last_source_group() == G
+        e.close()
+    assert K * S // G > 16 * limit
+    assert np.array_equal(outs[0], outs[1])
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        ora.set_signal(s, sigs[s])
+    want = ora.process_batch(pos)
+    assert np.abs(want).max() > 0.1
+    assert np.abs(outs[1] - want).max() <= TOL32 * S / 4
+
+
+# ------------------------------------------------------------------ configs[4] --
+def _ir(n, seed=99, decay=6.9):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n) * np.exp(-decay * np.arange(n) / n)
+    return (h / np.sqrt((h ** 2).sum())).astype(np.float32)
+
+
+def _wet(dry, n_total, ir, gain):
+    from scipy.signal import fftconvolve
+    reps = -(-n_total // len(dry))
+    stream = np.tile(dry.astype(np.float64), reps)[:n_total]
+    return gain * fftconvolve(stream, ir.astype(np.float64))[:n_total]
+
+
+def _reverb_positions(jf, S, K):
+    pos = np.zeros((K, S, 5), np.float32)
+    for s in range(S):
+        for b in range(K):
+            pos[b, s] = jf.position_from_spherical(-40 + (7 * s) % 121, (37 * s + b) % 360, 0.5 + 0.01 * (s % 100))
+    return pos
+
+
+def _reverb_model_blocks(hrir, B, K, ir, gain, sig, pos_s):
+    """float64: one source's stereo blocks [K][2B] with the reverb ahead of the spatialiser."""
+    mod = model64.Model(B, 512, 1, hrir)
+    mod.src[0].buf = _wet(sig, K * B, ir, gain)   # keep the float64 wet stream exactly
+    mod.src[0].count = 0
+    _, p = mod.process_batch(pos_s[:, None, :])
+    return p[0]
+
+
+@pytest.mark.parametrize("S,K,form", [(16, 32, 3), (256, 32, 0)])
+def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K, form):
+    """BASELINE.json configs[4]: B = 128, 2.0 s impulse response = 690 partitions, 32 blocks per call as
+    bench.py --reverb runs it.  (16 sources, form 3 pinned) and (256 sources, the form the engine picks by
+    itself -- the block-tiled kernel at this size): per-source blocks of sampled sources against
+    gain * float64 convolution -> float64 spatialiser model, and the mix as the ordered sum of the blocks."""
+    B = 128
+    ir = _ir(88200)
+    assert -(-len(ir) // B) == 690
+    gain = 0.5
+    pos = _reverb_positions(jf, S, 2 * K)
+    sigs = [np.roll(castanets, 997 * s)[: 30000 + 64 * s] for s in range(S)]
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    e.set_reverb_form(form)
+    e.set_source_group(1)            # per-source blocks
+    for s in range(S):
+        e.set_signal(s, sigs[s])
+    e.set_reverb(ir, gain)
+    e.upload_positions(pos)
+    parts, mixes = [], []
+    for c in range(2):               # two calls: the delay line and the wet ring carry over
+        e.batch_run(c * K, K)
+        e.synchronize()
+        parts.append(e.read_device(e.partial_device_ptr(), (K, S, 2 * B)))
+        mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
+    e.close()
+    part, mix = np.concatenate(parts), np.concatenate(mixes)
+    assert np.array_equal(mix, _ordered_mix(part))
+    tol = 2e-7 + 1e-7 * np.sqrt(690)          # float32 accumulation over 690 partitions
+    sample = range(S) if S <= 16 else (0, 3, 100, 255)
+    peak = 0.0
+    for s in sample:
+        want = _reverb_model_blocks(hrir, B, 2 * K, ir, gain, sigs[s], pos[:, s])
+        peak = max(peak, np.abs(want).max())
+        assert np.abs(part[:, s] - want).max() <= tol * max(1.0, np.abs(want).max()), s
+    assert peak > 0.01
+
+
+# ------------------------------------------------------------- 512-tap HRIRs --
+def _hrir512(seed=5):
+    """Synthetic 512-tap set shaped like a measured HRIR: a short onset delay per ear, then decaying noise."""
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal((710, 2, 512)) * np.exp(-np.arange(512) / 60.0)[None, None, :]
+    delay = rng.integers(0, 30, (710, 2))
+    for j in range(710):
+        for c in range(2):
+            h[j, c, :delay[j, c]] = 0.0
+    h *= 0.25 / np.abs(h).max()
+    return h.astype(np.float32)
+
+
+def test_512_tap_table(jf):
+    """transform_hrtfs on HRTF_LEN = 512 taps (hrtf_signals.cu:107-153): every bin of the device table against
+    the float64 transform, at the reference's own table tolerance of 1e-6 (precision_test.cu:209)."""
+    h = _hrir512()
+    e = jf.Engine(256, 512, 1, hrir=h)
+    got = e.read_table()
+    e.close()
+    want = model64.build_table(h, 1024)
+    assert np.abs(want).max() > 1.0
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    t32 = oracle_lib.build_table(h, 1024)
+    assert np.abs(got - t32).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("B", [128, 256])
+def test_512_tap_blocks_vs_oracle(jf, castanets, B):
+    """8 blocks with 512-tap HRIRs -- B + 511 <= 1024, the tightest overlap-save selection the reference
+    configures -- through per-block calls and one batch call, against the float32 oracle and the float64
+    model; positions cover all four interpolation cases and a crossfade at every other block."""
+    h = _hrir512()
+    S, K = 4, 8
+    cases = [(0, 0), (0, 3), (5, 0), (5, 3)]           # cases 1, 2, 3, 4
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            ele, azi = cases[s]
+            pos[k, s] = jf.position_from_spherical(ele, (azi + 5 * (k // 2)) % 360, 0.5 + 0.3 * s)
+    sigs = [np.roll(castanets, 5000 * s)[:40000] for s in range(S)]
+    e = jf.Engine(B, 512, S, hrir=h, max_batch_blocks=K)
+    e1 = jf.Engine(B, 512, S, hrir=h)
+    ora = oracle_lib.Engine(B, 512, S, h)
+    mod = model64.Model(B, 512, S, h)
+    for x in (e, e1, ora, mod):
+        for s in range(S):
+            x.set_signal(s, sigs[s])
+    got = e.process_batch(pos)
+    blockwise = []
+    for k in range(K):
+        for s in range(S):
+            e1.set_spherical(s, *[(cases[s][0]), (cases[s][1] + 5 * (k // 2)) % 360, 0.5 + 0.3 * s])
+        blockwise.append(e1.process_block())
+    e.close()
+    e1.close()
+    want32 = ora.process_batch(pos)
+    want64, _ = mod.process_batch(pos)
+    scale = max(1.0, np.abs(want64).max())
+    assert np.abs(want64).max() > 0.05
+    assert np.abs(got - want64).max() <= TOL64 * S * scale
+    assert np.abs(got - want32).max() <= TOL32 * S * scale
+    assert np.abs(np.array(blockwise) - want64).max() <= TOL64 * S * scale
+
+
+# ---------------------------------------------------------------- stage taps --
+def test_distance_factor_tap_radius_sweep(jf, hrir):
+    """generateDistanceFactor (kernels.cu:116-125) as the fused kernels evaluate it -- 64-bit fixed-point phase,
+    float minimax sin/cos -- bin by bin against the oracle (double cos/sin rounded to float, as the reference) and
+    the float64 model, from r = 0.05 out to |coords| = 100 (r' = 20: 13 turns of phase per bin, far beyond the
+    alias-free range; the reference still evaluates it).  Tolerance: 2.5 ulp of the factor's modulus 1/frac --
+    the reference compares its two double-evaluated factors at 1e-8 (precision_test.cu:73), which only
+    double-precision sin/cos meets; the kernel's end-to-end output holds the reference's 2e-7 (other tests)."""
+    coords = [(0.0, 0.0, 0.05), (0.5, 0.0, 0.0), (0.3, 0.4, 1.2), (0.0, 3.0, 4.0), (2.0, -1.0, 7.0),
+              (10.0, 5.0, -20.0), (60.0, 0.0, 80.0), (0.0, 100.0, 0.0), (57.7, 57.7, 57.8), (1e-3, 0.0, 0.0)]
+    pos = np.array([[0.0, 0.0, x, y, z] for x, y, z in coords], np.float32)
+    e = jf.Engine(256, 512, 1, hrir=hrir)
+    D = e.stage_taps(pos)
+    e.close()
+    for i, c in enumerate(coords):
+        d32 = oracle_lib.distance_factor(*c, 513)
+        d64 = model64.distance_factor(c, 513)
+        mod = np.abs(d64[0])                      # 1 / frac
+        ulp = mod * 2.0 ** -23
+        assert np.abs(D[i, :512] - d64[:512]).max() <= 2.5 * ulp, c
+        assert np.abs(D[i, :512] - d32[:512]).max() <= 3.0 * ulp, c
+        assert abs(D[i, 512].real - d64[512].real) <= 2.5 * ulp, c
+        assert abs(np.abs(D[i, 0]) - mod) <= ulp
+
+
+def test_weighted_spectrum_tap(jf, hrir, castanets):
+    """The weighted, delayed spectra of both ears before the inverse transform (the reference's tests compare
+    conv_bufs / intermediate at this point: precision_test.cu:225-241, 374-404) for the four interpolation cases
+    and an extrapolating one, against float64: Y_ear[k] = sum_t w_t (X[k] H[row_t][ear][k]) D[k], X = rfft(x)/N."""
+    rng = np.random.default_rng(21)
+    where = [(0, 0, 0.5), (0, 3, 0.5), (5, 0, 1.0), (5, 3, 2.0), (-15, 7, 0.8), (45, 10, 3.0), (85, 20, 0.3)]
+    pos = np.array([jf.position_from_spherical(*w) for w in where], np.float32)
+    p0 = max(0, int(np.argmax(np.abs(castanets))) - 700)             # a loud stretch of the excerpt
+    wins = np.stack([castanets[p0 + 97 * i: p0 + 97 * i + 1024] for i in range(len(where))]).astype(np.float32)
+    wins[-1] = rng.uniform(-0.5, 0.5, 1024).astype(np.float32)
+    e = jf.Engine(256, 512, 1, hrir=hrir)
+    D, Y = e.stage_taps(pos, wins)
+    e.close()
+    table = model64.build_table(hrir, 1024)
+    for i, (ele, azi, r) in enumerate(where):
+        h, om = model64.interp(np.float32(ele), np.float32(azi))
+        X = np.fft.rfft(wins[i].astype(np.float64)) / 1024
+        Dk = model64.distance_factor(tuple(pos[i, 2:5]), 513)
+        want = np.zeros((2, 513), np.complex128)
+        for row, w in model64.terms(h, om):
+            want += float(w) * (X[None, :] * table[row]) * Dk[None, :]
+        want[:, 0] = want[:, 0].real
+        want[:, -1] = want[:, -1].real     # c2r ignores Im of bins 0 and N/2
+        scale = np.abs(want).max()
+        assert scale > 1e-5
+        assert np.abs(Y[i] - want).max() <= 4e-7 * scale, where[i]   # a few float32 roundings of the largest bin
+
+
+def test_far_radii_end_to_end(jf, hrir):
+    """Radii far outside the alias-free range (|coords| up to 100: the delay wraps around the 1024-sample window
+    many times; the reference evaluates the same circular shift): output against the float64 model, relative to
+    the block's own peak because the gain 1/(1 + fsvs r'^2) is down to 2e-5 there."""
+    rng = np.random.default_rng(12)
+    sig = rng.uniform(-.5, .5, 8192).astype(np.float32)
+    for r in (6.0, 10.0, 30.0, 100.0):
+        e = jf.Engine(256, 512, 1, hrir=hrir)
+        m = model64.Model(256, 512, 1, hrir)
+        for x in (e, m):
+            x.set_signal(0, sig)
+            x.set_spherical(0, 0, 45, r)
+        got, want = [], []
+        for blk in range(6):
+            if blk == 3:
+                for x in (e, m):
+                    x.set_spherical(0, 10, 50, r)      # a crossfade out there too
+            got.append(e.process_block())
+            want.append(m.process_block())
+        e.close()
+        got, want = np.array(got), np.array(want)
+        # relative to the loudest block at this radius: a block may hold only the periodic-sinc tails of the
+        # (circularly wrapped) delayed signal, 1e-3 of the others
+        peak = np.abs(want).max()
+        assert peak > 0
+        assert np.abs(got - want).max() <= 1e-6 * peak, r
