@@ -12,14 +12,27 @@ trajectories are resident in HBM before the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 prints ONE JSON line (rank 0).  metric = source-frames per second (sources x frames/s),
-whole job.  `roofline` prices the fused kernel against HBM peak with ALGORITHMIC bytes
-(SURVEY.md 8d); `cpu_baseline` is the float32 C oracle (oracle/, kind "port") timed on
-this node's host cores on a bounded sample of the same workload.
+whole job.  With --gpus N > 1 and no WORLD_SIZE in the environment it starts its own N
+ranks (python -m torch.distributed.run) as a child process before anything touches the GPU.
+
+`roofline`: the fused kernel is bound by fp32 vector issue, not by HBM (the 5.8 MB table is
+cache-resident), so `frac` is executed fp32 flops / kernel time / 157.3 TFLOP/s; the HBM side
+is reported next to it from counters collected on THIS box (two short rocprofv3 --pmc passes of
+this script, run as child processes before the parent touches the GPU), or, if that is not
+possible, from the committed profile with its source named.  `cpu_baseline` is the float32 C
+oracle (oracle/, kind "port") timed on this node's host cores on a bounded sample of the same
+workload; the same oracle run is the checker of `verified`: the last timed step's mix is compared
+with it.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,7 +43,9 @@ sys.path.insert(0, ROOT)
 B = 256
 SOURCES_PER_GPU = 1024
 BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "64"))
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md; needs packed FMAs: 2 x 78.6)
+TOL32 = 4e-7                # HIP vs float32 oracle, per source (tests/)
 
 
 def cpu_share():
@@ -52,28 +67,132 @@ def cpu_share():
     return n
 
 
-def cpu_baseline(jf, wl, hrir, n_sources, n_blocks):
-    """The oracle (CPU restatement of the reference's path) on the first n_blocks blocks of
-    the first n_sources sources of the same workload, all host threads, parallel over sources."""
+def load_workload():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "jf_workload", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+    return wl
+
+
+def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, KB, n_blocks, gpu_mix, gpu_groups, G):
+    """The oracle (CPU restatement of the reference's path) on the n_blocks blocks that END with the last timed
+    step of the GPU run, all host threads, parallel over sources: its wall time is the CPU baseline, its output
+    the check of that step (`verified`).  The oracle starts n_blocks - KB blocks earlier with empty windows; a
+    window holds 1024 samples = 4 blocks, so the compared blocks see exactly the GPU's history.
+    gpu_mix [KB][2B]: the GPU's mix of the last step; gpu_groups: {group index: [KB][2B]} stereo blocks of
+    sampled groups of G consecutive sources (None at N > 1, where rank 0 only holds the reduced mix)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    ora = oracle_lib.Engine(B, 512, n_sources, hrir)
-    for s in range(n_sources):
-        ora.set_signal(s, wl.source_signal_and_start(s)[0])
-    pos = wl.trajectories(jf, np.arange(n_sources), n_blocks)
+    S = len(src_ids)
+    first = last_first_block + KB - n_blocks          # absolute block index since the start of the run; may be negative
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for j, sid in enumerate(src_ids):
+        sig = wl.source_signal_and_start(sid)[0]
+        ora.set_signal(j, np.roll(sig, -((first * B) % len(sig))))   # the looped stream as the GPU reads it at `first`
+    idx = [(first + b) % n_pos for b in range(n_blocks)]
+    p = np.ascontiguousarray(pos[idx])
     threads = min(oracle_lib.lib().jfo_num_threads(), cpu_share())
-    ora.process_batch(pos[:2], n_threads=threads)  # warm the thread pool
-    for s in range(n_sources):
-        ora.reset(s)
+    warm = oracle_lib.Engine(B, 512, min(S, 64), hrir)              # warm the thread pool on something else
+    warm.process_batch(np.ascontiguousarray(p[:2, :min(S, 64)]), n_threads=threads)
+    warm.close()
     t0 = time.perf_counter()
-    ora.process_batch(pos, n_threads=threads)
+    omix, opart = ora.process_batch(p, want_partial=True, n_threads=threads)
     dt = time.perf_counter() - t0
     ora.close()
-    return {"value": n_sources * n_blocks * B / dt, "unit": "source-frames/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{n_sources} sources x {n_blocks} blocks of the same moving-source workload, "
-                      f"{dt:.2f} s wall on {threads} threads = the host-CPU share of this process "
-                      f"(float32 C oracle, OpenMP over sources)"}
+    base = {"value": S * n_blocks * B / dt, "unit": "source-frames/s", "cores": threads, "kind": "port",
+            "sample": f"{S} sources x {n_blocks} blocks of the same moving-source workload (the blocks that end with "
+                      f"the last timed step), {dt:.2f} s wall on {threads} threads = the host-CPU share of this "
+                      f"process (float32 C oracle, OpenMP over sources)"}
+    # ---- check of the last timed step
+    want_mix = opart[:, -KB:].astype(np.float64).sum(axis=0)
+    err_mix = float(np.abs(gpu_mix - want_mix).max())
+    peak = float(np.abs(want_mix).max())
+    # float32 accumulation of S sources on both sides: the tests' bound for |mix| ~ 10 is 3e-5 at S = 1024
+    ok = err_mix <= 3e-6 * max(1.0, peak) * max(1.0, S / 1024.0)
+    check = {"max_abs_err_mix": err_mix, "mix_peak": peak, "blocks_checked": KB, "sources_checked": S,
+             "against": "float32 C oracle (oracle/jf_oracle.c), summed in float64"}
+    if gpu_groups:
+        worst = 0.0
+        for g, blk in gpu_groups.items():
+            want = opart[g * G:(g + 1) * G, -KB:].astype(np.float64).sum(axis=0)
+            worst = max(worst, float(np.abs(blk - want).max()))
+        check["max_abs_err_group_blocks"] = worst
+        check["groups_checked"] = sorted(gpu_groups)
+        ok = ok and worst <= TOL32 * G
+    return base, bool(ok), check
+
+
+# ------------------------------------------------------------------------------- PMC passes --
+PMC_PASSES = (("FETCH_SIZE",),
+              ("WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+               "GRBM_GUI_ACTIVE"))
+
+
+def collect_pmc(extra_args, want_kernels):
+    """Hardware counters of the fused kernel on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not
+    fit one pass; counters only, no other trace domain besides --kernel-trace) over a short child run of this
+    script.  Must run before this process touches the GPU.  Returns ({counter: mean per launch}, note)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="jf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"p{i}")
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", *extra_args]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {i} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if not any(k in row.get("Kernel_Name", "") for k in want_kernels):
+                        continue
+                    a = acc.setdefault(row["Counter_Name"], [0.0, 0])
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+            if not acc:
+                return None, f"pass {i}: no counter rows for {want_kernels}"
+            for c, (s, n) in acc.items():
+                out[c] = s / n
+    except Exception as ex:  # a profiler problem must not cost the bench line
+        return None, f"{type(ex).__name__}: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, "rocprofv3 --kernel-trace --pmc, two passes of `bench.py --pmc-child` on this box"
+
+
+def single_source_latency_us(jf, hrir):
+    """configs[1]: one source, one 256-sample block per call through jf_process_block (north_star: <= 300 us)."""
+    e = jf.Engine(256, 512, 1, hrir=hrir)
+    rng = np.random.default_rng(7)
+    e.set_signal(0, rng.uniform(-0.5, 0.5, 44100).astype(np.float32))
+    t = []
+    for i in range(400):
+        e.set_spherical(0, 5.0, float(i % 360), 0.5)  # moving: a crossfade every block
+        t0 = time.perf_counter()
+        e.process_block()
+        t.append(time.perf_counter() - t0)
+    e.close()
+    t = np.array(t[100:]) * 1e6
+    return {"median": float(np.median(t)), "p99": float(np.percentile(t, 99)), "calls": len(t),
+            "what": "jf_process_block, 1 moving source, B = 256 (configs[1]); host call to host result"}
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as a child (this process has not touched the GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -87,50 +206,63 @@ def main():
     ap.add_argument("--reverb", action="store_true",
                     help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
                          "(partitioned FDL convolution ahead of the spatialiser); not the default bench line")
+    ap.add_argument("--realtime", action="store_true",
+                    help="with --reverb: one block per call (the audio callback's shape), where the delay line "
+                         "is read from HBM: roofline of the per-block multiply-accumulate kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes")
     ap.add_argument("--cpu-sample-blocks", type=int, default=256)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # JF_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the multi-rank path
-    # on a 1-GPU box (RCCL refuses duplicate devices); the measured configuration is always nccl.
+    pmc, pmc_note = None, "not collected"
+    if world == 1 and not args.pmc_child and not args.no_pmc and not args.realtime:
+        extra = (["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
+        pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_group_kernel", "fused_block_kernel",
+                                                                                "fused_pair_kernel"))
+
     backend = os.environ.get("JF_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch = dist = None
+    if not args.pmc_child:
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        # JF_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the multi-rank path
+        # on a 1-GPU box (RCCL refuses duplicate devices); the measured configuration is always nccl.
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     from jf_load import jf
-    import importlib.util
-    spec = importlib.util.spec_from_file_location(
-        "jf_workload", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
-    wl = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(wl)
-
+    wl = load_workload()
     gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
     hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
 
     global B
     S = SOURCES_PER_GPU
     K, W, KB = args.steps, args.warmup, BLOCKS_PER_STEP
+    if args.pmc_child:
+        K, W = 6, 2
     ir = None
     if args.reverb:
-        B, S, KB = 128, 256, 32
+        B, S, KB = 128, 256, (1 if args.realtime else 32)
         rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
         ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
         ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
@@ -147,10 +279,16 @@ def main():
     # The trajectories are periodic (azimuth + 1 degree per block: 360 blocks), so a long run walks one
     # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
     # costs the same 20 B x sources x lcm(360, blocks per step) of host and device memory.
-    period = int(np.lcm(360, KB))
-    n_pos = period
+    n_pos = int(np.lcm(360, KB))
     pos = wl.trajectories(jf, src_ids, n_pos, moving=not args.stationary)
     eng.upload_positions(pos)
+
+    if args.pmc_child:  # a few launches for the counters, no torch, no timing
+        for i in range(W + K):
+            eng.batch_run((i * KB) % n_pos, KB)
+        eng.synchronize()
+        eng.close()
+        return
 
     # The mix lands in a torch tensor so that RCCL can reduce it in place.  Two buffers: the
     # (latency-bound, K * 2 KB) reduce of step i runs on RCCL's stream while the engine's stream
@@ -203,6 +341,30 @@ def main():
     prof = eng.profile_read()
     reverb_ms = eng.profile_read_reverb() if ir is not None else 0.0
     eng.profile_enable(False)
+    kernels = eng.last_kernels()
+    G = eng.last_source_group()
+
+    # what the last timed step left behind (checked against the oracle below)
+    i_last = prewarm + W + K - 1
+    last_mix = mixes[i_last & 1].cpu().numpy().copy()
+    groups = {}
+    if world == 1 and ir is None:
+        part = eng.read_device(eng.partial_device_ptr(), (KB, S // G, 2 * B))
+        for g in sorted({0, 1, (S // G) // 3, (S // G) // 2, S // G - 2, S // G - 1}):
+            groups[int(g)] = part[:, g].copy()
+
+    # prep / mix kernel times: a short untimed pass with every kernel bracketed by events
+    other = {}
+    if ir is None:
+        eng.profile_enable(2)
+        for i in range(prewarm + W + K, prewarm + W + K + 16):
+            step(i)
+        fence()
+        p2 = eng.profile_read()
+        eng.profile_enable(False)
+        other = {"prep_kernel_us": p2["prep_ms"] / max(p2["launches"], 1) * 1e3,
+                 "mix_kernel_us": p2["mix_ms"] / max(p2["launches"], 1) * 1e3,
+                 "source": "HIP events on the engine stream, 16 untimed steps after the timed region"}
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -212,31 +374,63 @@ def main():
     if rank == 0:
         frames = world * S * KB * K * B
         value = frames / dt
-        # algorithmic bytes of the timed windows of THIS rank (every rank has the same mix of cases)
-        # the run walks the uploaded period cyclically: price each step of the period once (its
-        # predecessor block is the one before it on the circle) and count how often each was timed
-        abytes, rows, items = wl.algorithmic_bytes_cyclic(jf, pos, KB, B, prewarm + W, K)
+        launches = max(prof["launches"], 1)
         fused_s = prof["fused_ms"] * 1e-3
-        achieved = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and ir is None and not args.stationary:  # measured for this workload only
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what actually bounds the kernel, from the committed PMC pass of this workload:
-        # VALU instructions per source-block and the share of the kernel's duration they occupy at 4 cycles each
-        valu = None
-        ppath = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(ppath) and ir is None and not args.stationary:
-            try:
-                f = json.load(open(ppath))["fused"]
-                valu = {"valu_insts_per_source_block": f["SQ_INSTS_VALU"] / (S * KB),
-                        "valu_issue_share_of_kernel_time": f["SQ_ACTIVE_INST_VALU"] / 1024 * 4 / (f["GRBM_GUI_ACTIVE"] / 8),
-                        "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc, 1024 SIMDs, 8 XCDs)"}
-            except Exception:
-                valu = None
+        first_step = prewarm + W
+        # the run walks the uploaded period cyclically: price each step of the period once (its predecessor block is
+        # the one before it on the circle) and count how often each was timed
+        abytes, rows, items = wl.algorithmic_bytes_cyclic(jf, pos, KB, B, first_step, K)
+        pair = any("pair" in k for k in kernels)
+        flops_ex, flops_ref = wl.flops_cyclic(jf, pos, KB, B, G, first_step, K, old_sets_spectral=pair)
+        tf = flops_ex / fused_s / 1e12 if fused_s > 0 else 0.0
+        fused_name = next((k for k in kernels if k.startswith("fused_")), kernels[-1])
+        roof = {"bound": "valu-fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / FP32_VECTOR_PEAK_TF, "traffic": None, "kernel": fused_name,
+                "avg_launch_ms": prof["fused_ms"] / launches,
+                "flops_per_launch_executed": flops_ex / launches,
+                "flops_per_launch_reference_algorithm": flops_ref / launches,
+                "flop_model": "jefferson-2.0_amd/workload.py flops_window (textbook counts; tests/test_abi.py)",
+                "table_rows_per_source_block": rows / items,
+                "other_kernels": other,
+                "why_not_hbm": "the 5.8 MB HRTF table is cache-resident: compulsory HBM bytes are ~1.3 KB per source-block"}
+        # SURVEY.md 8(d)'s algorithmic bytes (table rows re-read per item): a CACHE-level rate, not an HBM rate
+        roof["algorithmic_cache_gbps"] = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
+        roof["algorithmic_bytes_per_launch"] = abytes / launches
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads 1/2 of a wide
+            # coalesced stream -> x2; WRITE_SIZE is exact for 16-B-per-lane stores
+            traffic = pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024
+            src = pmc_note
+        else:
+            traffic, src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if ir is None and not args.stationary and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    src = f"REPLAYED from profiles/traffic_latest.json ({tj.get('measured_at', 'round 1 build')}); live " \
+                          f"collection failed: {pmc_note}"
+                except Exception:
+                    traffic = None
+        if traffic is not None:
+            roof["traffic"] = traffic
+            hbm.update({"bytes_per_launch": traffic, "achieved": traffic / (fused_s / launches) / 1e9,
+                        "frac": traffic / (fused_s / launches) / 1e9 / HBM_PEAK_GBS, "source": src})
+        else:
+            hbm.update({"bytes_per_launch": None, "source": f"unavailable: {pmc_note}"})
+        roof["hbm"] = hbm
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            iss = {"valu_insts_per_source_block": pmc["SQ_INSTS_VALU"] / (S * KB), "source": pmc_note}
+            if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
+                # 1024 SIMDs; a non-packed VALU instruction holds its SIMD's issue for 4 cycles; GRBM_GUI_ACTIVE
+                # is summed over the 8 XCDs
+                iss["valu_issue_share_of_kernel_time"] = pmc["SQ_ACTIVE_INST_VALU"] / 1024 * 4 / (pmc["GRBM_GUI_ACTIVE"] / 8)
+            if pmc.get("SQ_INSTS_VMEM_RD"):
+                iss["vmem_loads_per_source_block"] = pmc["SQ_INSTS_VMEM_RD"] / (S * KB)
+            if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY"):
+                iss["wave_time_waiting_share"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
+            roof["issue"] = iss
         out = {
             "metric": "source-frames/s (sources x frames/sec) at 256-sample blocks",
             "value": value, "unit": "source-frames/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -246,53 +440,70 @@ def main():
             "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
                                    "N=1024 overlap-save, KEMAR 710x2 table"
                                    + (" (stationary variant)" if args.stationary else ""),
-                       "sources_per_gpu": S, "block": B, "blocks_per_step": KB,
-                       "parallelism": f"sources sharded x{world}, RCCL reduce of the stereo mix"
-                       if world > 1 else "1 GPU"},
+                       "sources_per_gpu": S, "block": B, "blocks_per_step": KB, "source_group": G,
+                       "kernels": kernels,
+                       "parallelism": (f"sources sharded x{world}, "
+                                       + ("RCCL reduce" if backend == "nccl" else f"{backend} all_reduce (rehearsal, not RCCL)")
+                                       + " of the stereo mix") if world > 1 else "1 GPU"},
             "real_time_factor": (KB * K * B / 44100.0) / dt,
             "us_per_source_block": dt / (S * KB * K) * 1e6,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fused_group_kernel<4>",
-                         "algorithmic_bytes_per_launch": abytes / prof["launches"] if prof["launches"] else None,
-                         "avg_launch_ms": prof["fused_ms"] / prof["launches"] if prof["launches"] else None,
-                         "table_rows_per_source_block": rows / items,
-                         "other_kernels": "prep_kernel ~9 us, mix_kernel ~5 us per launch "
-                                          "(profiles/r01_kernel_stats.csv)",
-                         "issue_bound": valu},
+            "roofline": roof,
         }
         if world > 1:
             # the only exchange of the path: the sum of the per-rank stereo mixes
             out["comm"] = {"collective": "reduce(sum, dst=0) of float32[%d][%d] per step" % (KB, 2 * B),
+                           "backend": "RCCL" if backend == "nccl" else backend,
                            "payload_bytes_per_rank_per_step": KB * 2 * B * 4,
-                           "overlap": "asynchronous on RCCL's stream, double-buffered: step i + 1 computes while "
-                                      "step i reduces; no collective on the data path of the kernels"}
+                           "overlap": "asynchronous on the collective's stream, double-buffered: step i + 1 computes "
+                                      "while step i reduces; no collective on the data path of the kernels"}
         if ir is not None:
             # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
             # 690*129*8 B of IR spectra once per block (shared by all sources)
             P = -(-len(ir) // B)
             rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
-            t = reverb_ms / max(prof["launches"], 1) * 1e-3
+            t = reverb_ms / launches * 1e-3
+            mac_name = next((k for k in kernels if k.startswith("reverb_mac")), "reverb_mac")
             out["config"]["workload"] = ("configs[4]: 256 sources + 2 s convolution-reverb IR, partitioned "
-                                         "overlap-save (690 partitions of 128), 128-sample blocks")
-            out["reverb_roofline"] = {"bound": "hbm", "achieved": rb / t / 1e9 if t > 0 else 0.0,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None,
-                                      "kernel": "reverb_fft_kernel + reverb_mac_tiled_kernel",
-                                      "algorithmic_bytes_per_launch": rb, "avg_launch_ms": t * 1e3,
-                                      # the block-tiled form reads each delay-line slot once per tile of 16
-                                      # blocks and keeps the delay line (S*P KB) in the Infinity Cache, so the
-                                      # per-source-block figure above is what it AVOIDS reading; what one
-                                      # launch must move through HBM at least: the delay line once, the IR
-                                      # spectra once, the new slots and wet blocks written
-                                      "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4),
-                                      "multiply_accumulates_per_launch": S * KB * P * B,
-                                      "note": "frac > 1 = delay-line reuse across the blocks of a tile; the kernel "
-                                              "is bound by L2->L1 load bandwidth and packed-f32 FMA issue "
-                                              "(DESIGN.md section 7)"}
-        if world == 1 and not args.no_cpu_baseline and ir is None:
-            out["cpu_baseline"] = cpu_baseline(jf, wl, hrir, S, args.cpu_sample_blocks)
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                                         "overlap-save (690 partitions of 128), 128-sample blocks"
+                                         + (", ONE block per call (real-time shape)" if args.realtime else ""))
+            macs = S * KB * P * B
+            rv = {"kernel": "reverb_fft_kernel + " + mac_name, "avg_launch_ms": t * 1e3,
+                  "algorithmic_bytes_per_launch": rb, "multiply_accumulates_per_launch": macs}
+            if args.realtime:
+                # one block per call: every source's 690 KB of delay line is read once per block and nothing in
+                # a 181 MB stream is reused within the call -> HBM (Infinity Cache permitting) is the bound
+                rv.update({"bound": "hbm", "achieved": rb / t / 1e9 if t > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None})
+            else:
+                # block tiles: each delay-line slot is read once per tile of 16 blocks and stays in the Infinity
+                # Cache; the bound is fp32 FMA issue (8 flops per complex multiply-accumulate, packed FMAs)
+                tfr = 8.0 * macs / t / 1e12 if t > 0 else 0.0
+                rv.update({"bound": "valu-fp32", "achieved": tfr, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": tfr / FP32_VECTOR_PEAK_TF, "traffic": None,
+                           "algorithmic_cache_gbps": rb / t / 1e9 if t > 0 else 0.0,
+                           "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
+            if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                rv["traffic"] = pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024
+                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only)"
+            out["reverb_roofline"] = rv
+        if world == 1 and ir is None:
+            try:
+                out["single_source_block_latency_us"] = single_source_latency_us(jf, hrir)
+            except Exception as ex:
+                out["single_source_block_latency_us"] = {"error": str(ex)}
+        if not args.no_cpu_baseline and ir is None:
+            all_ids = np.arange(0, world * S)
+            if world == 1:
+                all_pos = pos
+            else:
+                all_pos = wl.trajectories(jf, all_ids, n_pos, moving=not args.stationary)
+            nb = max(KB + 4, min(args.cpu_sample_blocks, max(KB + 4, 262144 // len(all_ids))))
+            base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, n_pos, i_last * KB, KB, nb,
+                                                     last_mix, groups, G)
+            out["cpu_baseline"] = base
+            out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
+            out["verified"] = ok
+            out["verification"] = check
         print(json.dumps(out), flush=True)
 
     eng.close()

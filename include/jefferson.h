@@ -254,6 +254,9 @@ int jf_debug_set_reverb_form(jf_engine *e, int form);
  * I/O, the workgroups' blocks added on the host in order); above that, the batch pipeline with one block.
  * Default 256; 0 disables the real-time kernel. */
 int jf_debug_set_rt_max_sources(jf_engine *e, int n);
+/* ';'-separated names of the kernels the last processing call launched, in launch order (bench.py labels its
+ * roofline with them).  The string is owned by the engine and valid until the next call of this function. */
+const char *jf_debug_last_kernels(jf_engine *e);
 /* G the last batch pipeline run used (1 = fused_block_kernel, > 1 = fused_group_kernel). */
 int jf_debug_last_source_group(const jf_engine *e);
 /* Caps the persistent grid of the fused kernel at `workgroups` (0 = what the device holds): with a small cap every

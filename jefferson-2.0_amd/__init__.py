@@ -81,6 +81,7 @@ _SIGS = {
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_form": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_last_block_peak": (C.c_float, [C.c_void_p]),
+    "jf_debug_last_kernels": (C.c_char_p, [C.c_void_p]),
     "jf_debug_last_source_group": (C.c_int, [C.c_void_p]),
     "jf_debug_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_stage_taps": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _f, _f]),
@@ -311,6 +312,9 @@ class Engine:
 
     def set_source_group(self, g):
         self._chk(lib().jf_debug_set_source_group(self.h, int(g)))
+
+    def last_kernels(self):
+        return lib().jf_debug_last_kernels(self.h).decode().split(";")
 
     def last_source_group(self):
         return lib().jf_debug_last_source_group(self.h)

@@ -33,7 +33,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
                            hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
-hipError_t launch_reverb(const ReverbParams &P, hipStream_t st);
+hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used);
 }  // namespace jf
 
 using namespace jf;
@@ -74,6 +74,9 @@ struct jf_engine {
     int cur = 0;  // parity of the valid state/history
     int src_group = 0;  // 0 = automatic
     int last_group = 0; // G of the last batch pipeline run
+    int last_rv_form = 0;  // form of the reverb multiply-accumulate stage the last call took
+    bool last_rt = false;  // the last block went through the one-launch real-time kernel
+    std::string kernels;   // jf_debug_last_kernels
     int rv_form = 0;    // 0 = automatic
     // Data::type and Data::pauseStatus are written by the UI thread and read by the audio thread at every
     // block (Audio.cu:101,104)
@@ -190,7 +193,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     R.Wr = e->rv_Wr;
     R.head = e->rv_head;
     R.mac_form = e->rv_form;
-    JF_HIP(e, launch_reverb(R, e->stream));
+    JF_HIP(e, launch_reverb(R, e->stream, &e->last_rv_form));
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
     return JF_OK;
@@ -254,6 +257,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     if (em) JF_HIP(e, hipEventRecord(em->b, e->stream));
     if (e->profiling) e->ev_used++;
     e->cur = p ^ 1;
+    e->last_rt = false;
     return JF_OK;
 }
 
@@ -656,6 +660,7 @@ int jf_submit_block(jf_engine *e) {
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
             JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, wgs, e->stream));
             e->cur = p ^ 1;
+            e->last_rt = true;
             e->rt_wgs = wgs;
             e->in_flight = true;
             return JF_OK;
@@ -1047,6 +1052,27 @@ int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spect
 }
 
 int jf_debug_last_source_group(const jf_engine *e) { return e ? e->last_group : JF_ERR_ARG; }
+
+const char *jf_debug_last_kernels(jf_engine *e) {
+    if (!e) return "";
+    try {
+        const std::string nb = std::to_string(e->B / 64), bs = std::to_string(e->B);
+        std::string k;
+        if (!e->last_rt) k = "prep_kernel;";
+        if (e->rv_P > 0) {
+            k += "reverb_fft_kernel<" + bs + ">;";
+            const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
+            if (e->last_rv_form == 3) k += "reverb_mac_tiled_kernel<" + bs + "," + std::to_string(tile) + ">;";
+            else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
+        }
+        if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
+        else k += std::string(e->last_group > 1 ? "fused_group_kernel<" : "fused_block_kernel<") + nb + ">;mix_kernel";
+        e->kernels = k;
+        return e->kernels.c_str();
+    } catch (...) {
+        return "";
+    }
+}
 
 int jf_debug_set_grid_limit(jf_engine *e, int workgroups) {
     return jf_guard([&]() -> int {

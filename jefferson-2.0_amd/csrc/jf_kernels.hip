@@ -748,6 +748,286 @@ __global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
     }
 }
 
+// ------------------------------------------------------------- pair kernel --
+// The group kernel's work with BOTH filter sets of a unit's sources summed as spectra:
+//     sum_s [ old_s (1 - f) + new_s f ]  =  (1 - f) IFFT( sum_s Z_old,s )  +  f IFFT( sum_s Z_new,s ),
+// two inverse transforms per unit instead of G + 1, and one round of table-row loads per source for both
+// sets when they share rows (a source that moved by a degree inside one grid cell interpolates between the
+// same four rows with other weights).  Two spectral sums are 64 floats per lane -- more registers and LDS
+// than a wavefront has at four waves per SIMD -- so a unit is worked by a PAIR of wavefronts (2p, 2p + 1 of a
+// workgroup) that split the BINS of the sums, not the transforms: every FFT stays a one-wave transform.
+//   * wave `half` keeps the sums of bins lane + 64 q, q = 4 half .. 4 half + 3, of both sets (Z[k] in 16
+//     registers, Z[N-k] in the pair's LDS);
+//   * the waves alternate over the unit's sources: the owner of source g runs its front half (window,
+//     forward FFT, distance factor), leaves X D in its LDS work area (the "mailbox"), and both waves filter
+//     and accumulate their own bins of it -- each wave does G / 2 forward transforms and G half-filters;
+//   * at the end wave 0 inverts the old sum, wave 1 the new one (each fetches the other half of its sum
+//     through LDS), wave 0 hands its frames over, wave 1 cross-fades and stores the unit's stereo block.
+// Hand-offs are sequence-numbered flags in LDS (no workgroup barrier: only the two waves of a pair wait for each
+// other): pub[w] = number of hand-offs wave w has published in its work area, ack[w] = number of the partner's
+// hand-offs wave w has consumed.  A wave overwrites its work area only after the partner has consumed
+// everything it published; both waves run the same sequence of hand-offs, so the counts always match and every
+// wait is for something the partner reaches without waiting for this wave.  Sums run in source order.
+constexpr int kPairsPerWg = kWavesPerWg / 2;
+constexpr int kPairWork = 576;                                 // float2: a wave's FFT work space = its mailbox
+constexpr int kPairZm = 520;                                   // float2: [8][64] sums of Z[N-k] + lane 0's mirror slot
+constexpr int kPairLds = 2 * kPairWork + 2 * kPairZm + 2;      // + 4 flag words
+
+JF_DEV void pair_wait(const volatile int *flag, int v) {
+    while (__builtin_amdgcn_readfirstlane(*flag) < v) __builtin_amdgcn_s_sleep(1);
+}
+
+// Bins qb .. qb + 3 (hp already points at bin 64 qb + lane of row 0) of one filter set, or of two sets that
+// read the same rows with different weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.
+template <int NT, bool BOTH, class F>
+JF_DEV void filtered_half(const float4 *__restrict__ hbase, const int *rows, const float *wa, const float *wb,
+                          const float2 (&xh)[4], bool special, F &&use) {
+    const float4 *hp[NT];
+    float a[NT], b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        hp[t] = hbase + (size_t)rows[t] * 512;
+        a[t] = wa[t];
+        b[t] = BOTH ? wb[t] : 0.0f;
+    }
+    constexpr int QC = (JF_CHUNK_LOADS / NT) > 4 ? 4 : (JF_CHUNK_LOADS / NT);
+    auto ztwo = [&](int q, float2 x, float4 he, float2 &zk, float2 &zm) {
+        const float2 yl = cmul(x, make_float2(he.x, he.y));
+        const float2 yr = cmul(x, make_float2(he.z, he.w));
+        zk = make_float2(yl.x - yr.y, yl.y + yr.x);
+        zm = make_float2(yl.x + yr.y, yr.x - yl.y);
+        if (q == 0) {  // lane 0 of the lower half: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
+            const float2 z0 = make_float2(x.x * he.x, x.x * he.z);
+            const float2 z512 = make_float2(x.y * he.y, x.y * he.w);
+            zk = special ? z0 : zk;
+            zm = special ? z512 : zm;
+        }
+    };
+#pragma unroll
+    for (int qc = 0; qc < 4; qc += QC) {
+        float4 h[QC][NT];
+#pragma unroll
+        for (int q = 0; q < QC; q++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) h[q][t] = hp[t][64 * (qc + q)];
+#pragma unroll
+        for (int q = 0; q < QC; q++) {
+            float4 ha = make_float4(a[0] * h[q][0].x, a[0] * h[q][0].y, a[0] * h[q][0].z, a[0] * h[q][0].w);
+            float4 hb = make_float4(b[0] * h[q][0].x, b[0] * h[q][0].y, b[0] * h[q][0].z, b[0] * h[q][0].w);
+#pragma unroll
+            for (int t = 1; t < NT; t++) {
+                ha.x += a[t] * h[q][t].x;
+                ha.y += a[t] * h[q][t].y;
+                ha.z += a[t] * h[q][t].z;
+                ha.w += a[t] * h[q][t].w;
+                if (BOTH) {
+                    hb.x += b[t] * h[q][t].x;
+                    hb.y += b[t] * h[q][t].y;
+                    hb.z += b[t] * h[q][t].z;
+                    hb.w += b[t] * h[q][t].w;
+                }
+            }
+            float2 zka, zma, zkb = make_float2(0.f, 0.f), zmb = make_float2(0.f, 0.f);
+            ztwo(qc + q, xh[qc + q], ha, zka, zma);
+            if (BOTH) ztwo(qc + q, xh[qc + q], hb, zkb, zmb);
+            use(qc + q, zka, zma, zkb, zmb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool BOTH, class F>
+JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ hbase, const int *rows, const float *wa, const float *wb,
+                             const float2 (&xh)[4], bool special, F &&use) {
+    if (nt == 4)
+        filtered_half<4, BOTH>(hbase, rows, wa, wb, xh, special, use);
+    else if (nt == 2)
+        filtered_half<2, BOTH>(hbase, rows, wa, wb, xh, special, use);
+    else
+        filtered_half<1, BOTH>(hbase, rows, wa, wb, xh, special, use);
+}
+
+template <int NOUT>
+__global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
+    __shared__ float2 s_tw[kTwPack];
+    __shared__ float2 s_pair[kPairsPerWg * kPairLds];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    if (tid < kPairsPerWg) {
+        int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWork + 2 * kPairZm);
+        f[0] = f[1] = f[2] = f[3] = 0;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, half = wave & 1;
+    float2 *base = s_pair + pair * kPairLds;
+    float2 *buf = base + half * kPairWork;         // my FFT work space and mailbox
+    float2 *pbuf = base + (half ^ 1) * kPairWork;  // the partner's
+    float2 *zm = base + 2 * kPairWork;             // [set][kPairZm] sums of Z[N-k], both waves' bins
+    volatile int *flags = reinterpret_cast<volatile int *>(zm + 2 * kPairZm);
+    volatile int *my_pub = flags + half, *his_pub = flags + (half ^ 1);
+    volatile int *my_ack = flags + 2 + half, *his_ack = flags + 2 + (half ^ 1);
+    int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
+    auto publish = [&]() {
+        JF_WAVE_LDS_SYNC();
+        npub++;
+        if (lane == 0) *my_pub = npub;
+    };
+    auto await_partner = [&]() {  // the partner's next hand-off is in its work area
+        nseen++;
+        pair_wait(his_pub, nseen);
+        JF_WAVE_LDS_SYNC();
+    };
+    auto consumed = [&]() {  // I am done reading the partner's work area
+        JF_WAVE_LDS_SYNC();
+        if (lane == 0) *my_ack = nseen;
+    };
+    auto own_work_area = [&]() {  // the partner has consumed everything I published
+        pair_wait(his_ack, npub);
+        JF_WAVE_LDS_SYNC();
+    };
+
+    constexpr int B = 64 * NOUT;
+    const int G = P.G, SG = P.S / G;
+    const int n_units = P.K * SG;
+    const int a = lane & 3, i = lane >> 2;
+    const int qb = 4 * half;
+    const bool special = lane == 0 && half == 0;
+    const float4 *hbase = P.htab + 64 * qb + lane;
+    float2 *zmo = zm + 64 * qb + lane, *zmn = zm + kPairZm + 64 * qb + lane;  // + 64 q: my slots of the old / new sums
+#pragma unroll 1
+    for (int unit = blockIdx.x * kPairsPerWg + pair; unit < n_units; unit += gridDim.x * kPairsPerWg) {
+#if JF_UNIT_ORDER
+        const int sg = unit / P.K;
+        const int b = unit - sg * P.K;
+        const int s0 = sg * G;
+#else
+        const int b = unit / SG;
+        const int sg = unit - b * SG;
+        const int s0 = sg * G;
+#endif
+        const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
+        bool any_xfade = false;
+        for (int g = 0; g < G; g++) any_xfade = any_xfade || ((d0[g].flags & 2) != 0 && d0[g].n_new > 0);
+        own_work_area();  // also: the partner has read my slots of the last unit's sums
+        float2 zko[4], zkn[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            zko[q] = zkn[q] = make_float2(0.f, 0.f);
+            zmo[64 * q] = make_float2(0.f, 0.f);
+            zmn[64 * q] = make_float2(0.f, 0.f);
+        }
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            const ItemDesc *dp = d0 + g;
+            const bool audible = dp->n_new > 0;
+            const bool mine = (g & 1) == half;
+            if (mine) {
+                own_work_area();
+                const int item = b * P.S + s0 + g;
+                float2 xd[8];
+                if (item_front<NOUT, true>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) buf[64 * q + lane] = xd[q];
+                    publish();
+                }
+            } else if (audible) {
+                await_partner();
+            }
+            if (!audible) continue;
+            const float2 *mail = (mine ? buf : pbuf) + 64 * qb + lane;
+            float2 xh[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) xh[q] = mail[64 * q];
+            if (!mine) consumed();
+            const int nn = dp->n_new;
+            if (!any_xfade) {
+                filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
+                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
+                                            zkn[q] = cadd(zkn[q], zk);
+                                            zmn[64 * q] = cadd(zmn[64 * q], zmv);
+                                        });
+            } else if (dp->flags & 1) {
+                // both sets read the same rows (prep_kernel laid them out so): one round of loads
+                filtered_half_nt<true>(nn, hbase, dp->rows_new, dp->w_old, dp->w_new, xh, special,
+                                       [&](int q, float2 zka, float2 zma, float2 zkb, float2 zmb) {
+                                           zko[q] = cadd(zko[q], zka);
+                                           zmo[64 * q] = cadd(zmo[64 * q], zma);
+                                           zkn[q] = cadd(zkn[q], zkb);
+                                           zmn[64 * q] = cadd(zmn[64 * q], zmb);
+                                       });
+            } else {
+                filtered_half_nt<false>(dp->n_old, hbase, dp->rows_old, dp->w_old, dp->w_old, xh, special,
+                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
+                                            zko[q] = cadd(zko[q], zk);
+                                            zmo[64 * q] = cadd(zmo[64 * q], zmv);
+                                        });
+                filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
+                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
+                                            zkn[q] = cadd(zkn[q], zk);
+                                            zmn[64 * q] = cadd(zmn[64 * q], zmv);
+                                        });
+            }
+        }
+        // ---- the two inverse transforms: wave 0 takes the old sum, wave 1 the new one
+        const bool give = half == 0 || any_xfade;  // my bins of the sum the partner inverts
+        const bool take = half == 1 || any_xfade;  // I invert a sum
+        if (give) {
+            own_work_area();
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[64 * q + lane] = half == 0 ? zkn[q] : zko[q];
+            if (special) {  // lane 0's partner in the Hermitian mirror is itself (see mirror8)
+                zm[512] = zm[0];
+                zm[kPairZm + 512] = zm[kPairZm];
+            }
+            publish();
+        }
+        float2 fr[NOUT];
+        if (take) {
+            await_partner();
+            float2 v[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float2 theirs = pbuf[64 * q + lane];
+                const float2 own = half == 0 ? zko[q] : zkn[q];
+                v[q] = half == 0 ? own : theirs;
+                v[4 + q] = half == 0 ? theirs : own;
+            }
+            const float2 *rd = zm + half * kPairZm + (64 - lane);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[8 + j] = rd[64 * (7 - j)];
+            consumed();
+            if (give) own_work_area();  // the partner has fetched my bins: the work area is free for the exchange
+            ifft1024_lastq_wave<NOUT, true>(v, fr, buf, s_tw, lane);
+        }
+        if (any_xfade) {
+            if (half == 0) {
+#pragma unroll
+                for (int j = 0; j < NOUT; j++) buf[64 * j + lane] = fr[j];
+                publish();
+            } else {
+                await_partner();
+#pragma unroll
+                for (int j = 0; j < NOUT; j++) {
+                    const float2 old = pbuf[64 * j + lane];
+                    // kernels.cu:132-137
+                    const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
+                    const float fn = (float)n_out / ((float)B - 1.0f);
+                    fr[j] = make_float2(old.x * (1.0f - fn) + fr[j].x * fn, old.y * (1.0f - fn) + fr[j].y * fn);
+                }
+                consumed();
+            }
+        }
+        if (half == 1) {
+            float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
+#pragma unroll
+            for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- mixing --
 // Audio.cu:109-110: out[i] += source->intermediate[i], sources in index order.
 // Deterministic: 16 groups of consecutive sources are each summed in source order by

@@ -398,31 +398,33 @@ static void launch_mac_tiled(const ReverbParams &P, hipStream_t st) {
 // Form of stage B by the amount of work in the call: block-tiled when the tiles alone fill the GPU,
 // else source-grouped, else (real-time calls) one workgroup per (block, source).
 template <int B, int T, int KB>
-static void launch_mac_any(const ReverbParams &P, hipStream_t st) {
+static int launch_mac_any(const ReverbParams &P, hipStream_t st) {
     const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
     const long long tiles = (long long)((P.K + KB - 1) / KB) * P.S;
-    if (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) launch_mac_tiled<B, KB>(P, st);
-    else if (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) launch_mac<B, T>(P, st);
-    else launch_mac<B, 1>(P, st);
+    if (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) return launch_mac_tiled<B, KB>(P, st), 3;
+    if (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) return launch_mac<B, T>(P, st), 2;
+    return launch_mac<B, 1>(P, st), 1;
 }
 
-hipError_t launch_reverb(const ReverbParams &P, hipStream_t st) {
+hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used) {
+    int form = 0;
     const dim3 ga((P.K * P.S + 3) / 4), blk(256);
     switch (P.B) {
     case 64:
         hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        launch_mac_any<64, 4, 16>(P, st);
+        form = launch_mac_any<64, 4, 16>(P, st);
         break;
     case 128:
         hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        launch_mac_any<128, 4, 16>(P, st);
+        form = launch_mac_any<128, 4, 16>(P, st);
         break;
     case 256:
         hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        launch_mac_any<256, 2, 8>(P, st);
+        form = launch_mac_any<256, 2, 8>(P, st);
         break;
     default: return hipErrorInvalidValue;
     }
+    if (form_used) *form_used = form;
     return hipGetLastError();
 }
 

@@ -101,3 +101,85 @@ def algorithmic_bytes_cyclic(jf, pos, blocks_per_step, B, first_step, n_steps, t
             tot[c] += v
     return tuple(tot)
 
+
+
+# ---------------------------------------------------------------------------------------------------
+# Floating-point work of the path (for the fp32 vector roofline of bench.py).  Textbook counts:
+# a complex FFT of n points = 5 n log2 n flops; a complex multiply = 6, a complex add = 2.
+N = 1024
+NC = 513
+FLOPS_RFFT = 5 * 512 * 9 + 512 * 12        # real FFT 1024 = complex FFT 512 + split pass (2 complex add, 1 mul, 1 add per bin)
+FLOPS_DISTANCE = NC * 20 + NC * 6          # D[k] (two short polynomials + scaling per bin) and X[k] D[k]
+FLOPS_IFFT_FULL = 5 * 1024 * 10            # both ears in one complex 1024-point inverse (the reference: two c2r of 1024)
+FLOPS_IFFT_PRUNED = 4 * 5 * 256 * 8        # 4 decimated 256-point transforms ...
+FLOPS_XFADE_PER_FRAME = 2 * 3              # out = old (1 - f) + new f, two channels
+
+
+def flops_filter(n_rows):
+    """sum_t w_t H_t (both ears, re and im: 4 (2 n - 1) flops per bin) times X D (two complex multiplies) and the
+    two complex adds that form Z = Y_L + j Y_R and its mirror: per bin 8 n + 12."""
+    return NC * (8 * n_rows + 12)
+
+
+def flops_ifft_pruned(B):
+    """... + the last radix-4 of the inverse formed for the B frames of the block only (3 complex multiplies and
+    3 complex adds per frame)."""
+    return FLOPS_IFFT_PRUNED + B * 24
+
+
+def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=True):
+    """Floating-point operations of one launch over the trajectory window pos [K][S][5].
+
+    Returns (executed, reference): `executed` is what the shipped kernels have to do -- per source-block one
+    forward transform, the distance factor, one weighted filter per set; per UNIT of G consecutive sources one
+    pruned inverse for the sum of the new sets and, if any source of the unit crossfades, one for the sum of the
+    old sets (G = 1: one or two inverses per source-block; old_sets_spectral=False: one inverse per crossfading
+    unit's SOURCE for the old sets, the form of the round-1 group kernel), the crossfade and the G-fold sum -- and `reference`
+    is the reference's own algorithm (GPUSoundSource.cu:320-385): an unpruned inverse pair per set and source.
+    Silent items (position not interpolable) are counted like the others; the synthetic workloads have none."""
+    if terms is None:
+        terms = n_terms_table(jf)
+    ele = pos[..., 0].astype(np.int64)
+    azi = pos[..., 1].astype(np.int64)
+    K, S = ele.shape
+    prev_e = np.zeros((K, S), np.int64)
+    prev_a = np.zeros((K, S), np.int64)
+    if first_old is not None:
+        prev_e[0], prev_a[0] = first_old[:, 0], first_old[:, 1]
+    prev_e[1:], prev_a[1:] = ele[:-1], azi[:-1]
+    n_new = terms[ele + 49, azi]
+    moved = (prev_e != ele) | (prev_a != azi)
+    n_old = np.where(moved, terms[prev_e + 49, prev_a], 0)
+    items = K * S
+    front = items * (FLOPS_RFFT + FLOPS_DISTANCE)
+    filt = int((NC * (8 * n_new + 12)).sum() + (NC * (8 * n_old + 12) * moved).sum())
+    units_x = int(moved.reshape(K, S // G, G).any(axis=2).sum())     # units with a crossfade
+    units = K * (S // G)
+    old_inv = units_x if (old_sets_spectral or G == 1) else units_x * G
+    inv = (units + old_inv) * flops_ifft_pruned(B)
+    xfade = units_x * B * FLOPS_XFADE_PER_FRAME
+    gsum = items * NC * 4 * (1 + moved.mean()) if G > 1 else 0          # spectral sums over the unit's sources
+    mix = units * 2 * B                                                 # mix_kernel: one add per float of a block
+    executed = front + filt + inv + xfade + int(gsum) + mix
+    reference = (front + filt + int((1 + moved).sum()) * FLOPS_IFFT_FULL + int(moved.sum()) * B * FLOPS_XFADE_PER_FRAME
+                 + items * 2 * B)
+    return executed, reference
+
+
+def flops_cyclic(jf, pos, blocks_per_step, B, G, first_step, n_steps, terms=None, old_sets_spectral=True):
+    """flops_window over a cyclically walked period of positions (see algorithmic_bytes_cyclic)."""
+    if terms is None:
+        terms = n_terms_table(jf)
+    n_pos = pos.shape[0]
+    assert n_pos % blocks_per_step == 0
+    per_step = []
+    for j in range(n_pos // blocks_per_step):
+        first_old = pos[(j * blocks_per_step - 1) % n_pos, :, :2].astype(np.int64)
+        per_step.append(flops_window(jf, pos[j * blocks_per_step:(j + 1) * blocks_per_step], B, G,
+                                     first_old=first_old, terms=terms, old_sets_spectral=old_sets_spectral))
+    ex = ref = 0
+    for i in range(first_step, first_step + n_steps):
+        e, r = per_step[i % len(per_step)]
+        ex += e
+        ref += r
+    return ex, ref

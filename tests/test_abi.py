@@ -269,3 +269,59 @@ def test_workload_helpers(jf):
     direct = wl.algorithmic_bytes(jf, long[8 * first:8 * (first + n)], 256,
                                   first_old=long[8 * first - 1, :, :2].astype(np.int64), terms=terms)
     assert cyc == direct
+
+
+def test_flop_model(jf):
+    """The fp32 work model behind bench.py's roofline (workload.flops_window), case by case."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+    terms = wl.n_terms_table(jf)
+    B = 256
+    front = wl.FLOPS_RFFT + wl.FLOPS_DISTANCE
+    assert wl.FLOPS_RFFT == 23040 + 6144 and wl.FLOPS_IFFT_FULL == 51200
+    inv = wl.flops_ifft_pruned(B)
+    assert inv == 40960 + 6144
+    # one stationary case-4 source, 3 blocks, per-source kernel: front + 4-row filter + one pruned inverse + mix add
+    one = np.tile(jf.position_from_spherical(5, 3, 1.0), (3, 1, 1))
+    ex, ref = wl.flops_window(jf, one, B, 1, first_old=np.array([[5, 3]]), terms=terms)
+    assert ex == 3 * (front + wl.flops_filter(4) + inv + 2 * B)
+    assert ref == 3 * (front + wl.flops_filter(4) + wl.FLOPS_IFFT_FULL + 2 * B)
+    # two moving case-4 sources in one unit (G = 2): two filters per source, ONE inverse per set per unit
+    mov = wl.trajectories(jf, [2, 1026], 3, first_block=2)
+    e_, a_ = mov[..., 0].astype(int), mov[..., 1].astype(int)
+    n_new = terms[e_[1:] + 49, a_[1:]]
+    n_old = terms[e_[:-1] + 49, a_[:-1]]          # every block moves: the old set is the previous block's
+    assert n_new[:, 0].tolist() == [4, 4]         # source 2: ele -26, azimuths 77, 78 -> case 4 at both ends
+    ex2, ref2 = wl.flops_window(jf, mov[1:], B, 2, first_old=mov[0, :, :2].astype(np.int64), terms=terms)
+    filt = sum(wl.flops_filter(int(n)) for n in n_new.ravel()) + sum(wl.flops_filter(int(n)) for n in n_old.ravel())
+    per_unit = 2 * inv + B * wl.FLOPS_XFADE_PER_FRAME + 2 * B
+    assert ex2 == 4 * (front + wl.NC * 4 * 2) + filt + 2 * per_unit
+    assert ref2 == 4 * (front + 2 * wl.FLOPS_IFFT_FULL + B * wl.FLOPS_XFADE_PER_FRAME + 2 * B) + filt
+    # the round-1 group kernel inverted the old sets per source
+    ex3, _ = wl.flops_window(jf, mov[1:], B, 2, first_old=mov[0, :, :2].astype(np.int64), terms=terms,
+                             old_sets_spectral=False)
+    assert ex3 == ex2 + 2 * inv
+    # cyclic walk == unrolled trajectory
+    period = wl.trajectories(jf, [0, 5, 77, 400], 360)
+    long = wl.trajectories(jf, [0, 5, 77, 400], 4 * 360)
+    first, n = 7, 100
+    cyc = wl.flops_cyclic(jf, period, 8, B, 4, first, n, terms=terms)
+    direct = wl.flops_window(jf, long[8 * first:8 * (first + n)], B, 4,
+                             first_old=long[8 * first - 1, :, :2].astype(np.int64), terms=terms)
+    assert cyc == direct
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher spawns torch.distributed.run itself and hands back the
+    children's failure (here: no GPU) as a non-zero exit code -- it neither refuses to start nor hangs."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in err
+    assert "needs a GPU" in err          # printed by the ranks, i.e. they were started

@@ -402,3 +402,81 @@ def test_directory_loader_and_offline_driver(jf, hrir, castanets, tmp_path):
                         "--dwell", "4", "--rounds", "5", "--batch", "7"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(outb, "rb").read() == open(outp, "rb").read()
+
+
+def test_rccl_reduce_on_the_engine_stream():
+    """The RCCL side of bench.py's N > 1 path on the one GPU of this box: the `nccl` backend with world_size 1
+    (communicator init, the engine's stream wrapped as an ExternalStream, asynchronous dist.reduce ordered after
+    the kernels, double-buffered reuse).  A reduce over one rank must hand back exactly the engine's mix."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["JF_ROOT"])
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from jf_load import jf
+import importlib.util
+spec = importlib.util.spec_from_file_location("wl", os.path.join(os.environ["JF_ROOT"], "jefferson-2.0_amd", "workload.py"))
+wl = importlib.util.module_from_spec(spec); spec.loader.exec_module(wl)
+hrir = np.load(os.path.join(os.environ["JF_ROOT"], "tests", "golden", "kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
+S, KB, B, STEPS = 64, 8, 256, 6
+ids = np.arange(S)
+def engine():
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=KB)
+    for s in ids:
+        e.set_signal(int(s), wl.source_signal_and_start(s, 9000)[0])
+    e.upload_positions(wl.trajectories(jf, ids, KB * STEPS))
+    return e
+ref = engine()
+want = []
+for i in range(STEPS):
+    ref.batch_run(i * KB, KB)
+    ref.synchronize()
+    want.append(ref.read_device(ref.mix_device_ptr(), (KB, 2 * B)))
+ref.close()
+eng = engine()
+ext = torch.cuda.ExternalStream(eng.stream_ptr())
+mixes = [torch.zeros((KB, 2 * B), dtype=torch.float32, device="cuda") for _ in range(2)]
+pending = [None, None]
+got = []
+for i in range(STEPS):
+    j = i & 1
+    if pending[j] is not None:
+        with torch.cuda.stream(ext):
+            pending[j][0].wait()
+        pending[j][0].wait()
+        torch.cuda.synchronize()
+        got.append((pending[j][1], mixes[j].cpu().numpy().copy()))
+        pending[j] = None
+    eng.batch_run(i * KB, KB, mixes[j].data_ptr())
+    with torch.cuda.stream(ext):
+        pending[j] = (dist.reduce(mixes[j], dst=0, op=dist.ReduceOp.SUM, async_op=True), i)
+for j in range(2):
+    if pending[j] is not None:
+        pending[j][0].wait()
+        torch.cuda.synchronize()
+        got.append((pending[j][1], mixes[j].cpu().numpy().copy()))
+eng.synchronize()
+dist.barrier()
+torch.cuda.synchronize()
+assert sorted(i for i, _ in got) == list(range(STEPS))
+for i, m in got:
+    assert np.abs(want[i]).max() > 0.1
+    assert np.array_equal(m, want[i]), i
+eng.close()
+dist.destroy_process_group()
+print("RCCL_OK", dist.is_nccl_available())
+'''
+    env = dict(os.environ, JF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    assert "RCCL_OK True" in r.stdout.decode()
