@@ -70,7 +70,9 @@ struct ItemDesc {
     float inv_frac;  // 1 / (1 + fsvs r'^2)
     int n_new;       // 1, 2 or 4 terms; 0 = position not interpolable -> silence
     int n_old;       // 0 = no crossfade
-    int pad;
+    int flags;       // pair-kernel layout (prep_kernel with canon = 1): bit 0 = both sets read rows_new[] (w_old[] / w_new[]
+                     // are their weights on those rows, 0 where a set does not use a row; n_old == n_new), bit 1 = the
+                     // source moved (crossfade); a source that did not move carries its new set as old set too
 };
 static_assert(sizeof(ItemDesc) == 88, "ItemDesc layout");
 
@@ -107,6 +109,8 @@ struct FusedParams {
     int S, K, B;
     int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
     int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
+    int form;  // G > 1: 1 = fused_pair_kernel (descriptors in the pair-kernel layout), 0 = fused_group_kernel
+    int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
 };
 
 // Convolution reverb stage (jf_reverb.hip): uniformly partitioned overlap-save with a

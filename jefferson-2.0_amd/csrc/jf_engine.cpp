@@ -22,9 +22,9 @@ hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, floa
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
                                float *d_w, int *d_nt, int n, int corrected, hipStream_t st);
 hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
-                       int S, int K, hipStream_t st);
+                       int S, int K, int canon, hipStream_t st);
 hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st);
-hipError_t fused_resident_workgroups(int nb, bool group, int *out);
+hipError_t fused_resident_workgroups(int nb, int kind, int *out);
 hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos, const float *d_win, int n,
                               const float4 *d_htab, const float2 *d_tw, float2 *d_dist, float2 *d_spec,
                               hipStream_t st);
@@ -82,7 +82,8 @@ struct jf_engine {
     // block (Audio.cu:101,104)
     std::atomic<int> mode{0};  // 0 = FD_COMPLEX, 1 = FD_BASIC
     std::atomic<int> paused{0};
-    int resident_wgs[2] = {0, 0};  // persistent-grid size of the per-source / the group kernel on this device
+    int resident_wgs[3] = {0, 0, 0};  // persistent-grid size of the per-source / group / pair kernel on this device
+    int group_form = 1;               // G > 1: 1 = fused_pair_kernel, 0 = fused_group_kernel (A/B runs)
     int grid_limit = 0;            // > 0: tests shrink the grid so that waves loop over several units
     float last_peak = 0.0f;        // max |sample| of the last block handed out (Audio.cu:111-113 clip alert)
 
@@ -96,6 +97,7 @@ struct jf_engine {
     float *h_out_pinned = nullptr;  // [kRtMaxWgs][2B] pinned + mapped: ... and writes its workgroups' stereo blocks in place
     int rt_wgs = 0;                 // partial blocks the block in flight left there (0: one finished block)
     float *hd_pos = nullptr, *hd_out = nullptr;  // their device addresses
+    int *h_err = nullptr, *hd_err = nullptr;     // pinned + mapped error word of the fused kernels
     int rt_max_sources = 256;       // per-block calls with at most this many sources take the one-launch path
     bool in_flight = false;         // a submitted block not yet collected
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
@@ -212,14 +214,27 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
         em = next_events(e, e->ev_mix);
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
+    // sources a wavefront (pair) sums before it stores a stereo block: as many as keep the resident waves
+    // busy: larger groups mean fewer inverse transforms and fewer partial blocks for the mix
+    // (profiles/r01_experiments.md)
+    const long long n_items = (long long)K * e->S;
+    const int G = e->src_group > 0 ? e->src_group
+                  : (e->S % 16 == 0 && n_items >= 65536) ? 16
+                  : (e->S % 8 == 0 && n_items >= 32768) ? 8
+                  : (e->S % 4 == 0 && n_items >= 16384) ? 4
+                  : (e->S % 2 == 0 && n_items >= 8192)  ? 2
+                                                         : 1;
+    FusedParams P;
+    P.G = (e->S % G == 0) ? G : 1;
+    P.form = e->group_form;
+    const int canon = P.G > 1 && P.form == 1;
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
-    JF_HIP(e, launch_prep(ring_table(), kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, e->stream));
+    JF_HIP(e, launch_prep(ring_table(), kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
     {
         const int rc = run_reverb_stage(e, p, K);
         if (rc) return rc;
     }
-    FusedParams P;
     P.htab = e->d_htab;
     P.tw = e->d_twpack;
     P.desc = e->d_desc;
@@ -233,21 +248,10 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     P.S = e->S;
     P.K = K;
     P.B = e->B;
-    // sources summed in registers per wavefront: fewer, larger partial blocks for the mix kernel
-    // sources a wavefront sums in registers before it stores a stereo block: as many as keep at least
-    // one unit per resident wavefront (4096 on MI355X): larger groups mean fewer inverse transforms in the
-    // group kernel and fewer partial blocks for the mix; 32 would starve half the waves (profiles/r01_experiments.md)
-    const long long n_items = (long long)K * e->S;
-    const int G = e->src_group > 0 ? e->src_group
-                  : (e->S % 16 == 0 && n_items >= 65536) ? 16
-                  : (e->S % 8 == 0 && n_items >= 32768) ? 8
-                  : (e->S % 4 == 0 && n_items >= 16384) ? 4
-                  : (e->S % 2 == 0 && n_items >= 8192)  ? 2
-                                                         : 1;
-    P.G = (e->S % G == 0) ? G : 1;
     e->last_group = P.G;
     P.mode = kernel_mode(e);
-    int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
+    P.err = e->hd_err;
+    int max_wgs = e->resident_wgs[P.G > 1 ? (P.form == 1 ? 2 : 1) : 0];
     if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, max_wgs, e->stream));
@@ -332,6 +336,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_traj);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
+    if (e->h_err) (void)hipHostFree(e->h_err);
     for (auto *pool : {&e->ev_prep, &e->ev_fused, &e->ev_mix, &e->ev_reverb})
         for (auto &p : *pool) {
             (void)hipEventDestroy(p.a);
@@ -372,8 +377,8 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     auto body = [&]() -> int {
         JF_HIP(e, hipSetDevice(cfg->device));
         JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        JF_HIP(e, fused_resident_workgroups(B / 64, false, &e->resident_wgs[0]));
-        JF_HIP(e, fused_resident_workgroups(B / 64, true, &e->resident_wgs[1]));
+        for (int kind = 0; kind < 3; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
+        if (const char *f = getenv("JF_GROUP_FORM")) e->group_form = atoi(f) != 0;  // tuning runs only
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
@@ -391,6 +396,9 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
+        JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int), hipHostMallocMapped));
+        *e->h_err = 0;
+        JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_err, e->h_err, 0));
         e->d_signal.assign(S, nullptr);
         JF_HIP(e, hipMalloc(&e->d_zero, sizeof(float) * kN));
         JF_HIP(e, hipMemset(e->d_zero, 0, sizeof(float) * kN));
@@ -654,6 +662,8 @@ int jf_submit_block(jf_engine *e) {
             P.K = 1;
             P.B = e->B;
             P.G = 1;
+            P.form = 0;
+            P.err = e->hd_err;
             P.mode = kernel_mode(e);
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
             int wgs = (e->S + 15) / 16;
@@ -868,6 +878,7 @@ int jf_synchronize(jf_engine *e) {
     DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
+    if (*(volatile int *)e->h_err) return fail(e, JF_ERR_DEVICE, "fused_pair_kernel: a wavefront hand-off timed out");
     return JF_OK;
     });
 }
@@ -886,6 +897,7 @@ int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *
         JF_HIP(e, hipMemcpyAsync(out_mix + (size_t)b0 * blk, e->d_mix, sizeof(float) * blk * k, hipMemcpyDeviceToHost,
                                  e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
+        if (*(volatile int *)e->h_err) return fail(e, JF_ERR_DEVICE, "fused_pair_kernel: a wavefront hand-off timed out");
     }
     return JF_OK;
     });
@@ -1066,7 +1078,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
         }
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
-        else k += std::string(e->last_group > 1 ? "fused_group_kernel<" : "fused_block_kernel<") + nb + ">;mix_kernel";
+        else k += std::string(e->last_group > 1 ? (e->group_form ? "fused_pair_kernel<" : "fused_group_kernel<") : "fused_block_kernel<") + nb + ">;mix_kernel";
         e->kernels = k;
         return e->kernels.c_str();
     } catch (...) {

@@ -33,6 +33,7 @@ namespace jf {
 
 // --------------------------------------------------------------- helpers --
 #define JF_DEV __device__ __forceinline__
+typedef float __attribute__((address_space(1))) gfloat;  // float in global memory
 
 // LDS traffic below is private to one wavefront; LDS ops of a wave execute in
 // issue order, so all that is needed is to stop the compiler from moving a
@@ -474,7 +475,9 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
     const SrcSignal sg = P.sigs[s];
     const int count0 = P.st_in[s].count;
     const float *hist = P.hist_in + (size_t)s * kN;
-    const float *sigp = sg.ptr;
+    // the pointer comes out of a table in memory: tell the compiler it is global memory, or every window load is a
+    // flat load that also ties up the LDS counter
+    const gfloat *sigp = (const gfloat *)sg.ptr;
     // first NEW sample of this call has q = 0; window sample n has q = b*B + n - (N - B)
     // The engine stores every signal with length >= N (short ones tiled, empty ones as
     // zeros), so one conditional subtract wraps the loop.
@@ -501,8 +504,7 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
                 const int q = qr + 2 * lane + c;
                 int idx = base + q;  // < L + N for q >= 0
                 idx = idx >= L ? idx - L : idx;
-                const float *p = q < 0 ? hist + (kN + q) : sigp + idx;
-                xv[c] = *p;
+                xv[c] = q < 0 ? hist[kN + q] : sigp[idx];
             }
             z[r] = make_float2(xv[0], xv[1]);
         }
@@ -533,6 +535,11 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
     }
 
     if (n_new <= 0) return false;
+#ifdef JF_EXP_NOFRONT  // timing experiment (wrong results): window loads only, no transform, no distance factor
+#pragma unroll
+    for (int q = 0; q < 8; q++) xd[q] = z[q];
+    return true;
+#endif
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
@@ -753,31 +760,57 @@ __global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
 //     sum_s [ old_s (1 - f) + new_s f ]  =  (1 - f) IFFT( sum_s Z_old,s )  +  f IFFT( sum_s Z_new,s ),
 // two inverse transforms per unit instead of G + 1, and one round of table-row loads per source for both
 // sets when they share rows (a source that moved by a degree inside one grid cell interpolates between the
-// same four rows with other weights).  Two spectral sums are 64 floats per lane -- more registers and LDS
-// than a wavefront has at four waves per SIMD -- so a unit is worked by a PAIR of wavefronts (2p, 2p + 1 of a
-// workgroup) that split the BINS of the sums, not the transforms: every FFT stays a one-wave transform.
-//   * wave `half` keeps the sums of bins lane + 64 q, q = 4 half .. 4 half + 3, of both sets (Z[k] in 16
-//     registers, Z[N-k] in the pair's LDS);
+// same four rows with other weights).  Two spectral sums are 64 floats per lane -- more than a wavefront can
+// hold at four waves per SIMD -- so a unit is worked by a PAIR of wavefronts (2p, 2p + 1 of a workgroup) that
+// split the BINS of the sums, not the transforms: every FFT stays a one-wave transform.
+//   * wave `half` keeps the sums of bins lane + 64 q, q = 4 half .. 4 half + 3, of both sets: Z[k] and
+//     Z[N-k], 32 registers;
 //   * the waves alternate over the unit's sources: the owner of source g runs its front half (window,
-//     forward FFT, distance factor), leaves X D in its LDS work area (the "mailbox"), and both waves filter
-//     and accumulate their own bins of it -- each wave does G / 2 forward transforms and G half-filters;
+//     forward FFT, distance factor), keeps its own bins of X D and leaves the partner's in a mailbox in
+//     LDS; each wave filters and accumulates its bins of every source -- G / 2 forward transforms and G
+//     half-filters per wave;
 //   * at the end wave 0 inverts the old sum, wave 1 the new one (each fetches the other half of its sum
-//     through LDS), wave 0 hands its frames over, wave 1 cross-fades and stores the unit's stereo block.
-// Hand-offs are sequence-numbered flags in LDS (no workgroup barrier: only the two waves of a pair wait for each
-// other): pub[w] = number of hand-offs wave w has published in its work area, ack[w] = number of the partner's
-// hand-offs wave w has consumed.  A wave overwrites its work area only after the partner has consumed
-// everything it published; both waves run the same sequence of hand-offs, so the counts always match and every
-// wait is for something the partner reaches without waiting for this wave.  Sums run in source order.
+//     from the partner's mailbox), wave 0 hands its frames over, wave 1 cross-fades and stores the block.
+// Hand-offs are sequence-numbered flags in LDS (no workgroup barrier: only the two waves of a pair wait for
+// each other): pub[w] = number of hand-offs wave w has published, ack[w] = number of the partner's hand-offs
+// wave w has consumed.  A wave has two mailbox slots and consumes the partner's source one step late, so it
+// waits only when the partner has fallen a whole source behind.  Both waves run the same sequence of
+// hand-offs, so the counts always match, and every wait is for something the partner reaches without
+// waiting for anything this wave has not done yet.  Each wave adds its sources in a fixed order.
 constexpr int kPairsPerWg = kWavesPerWg / 2;
-constexpr int kPairWork = 576;                                 // float2: a wave's FFT work space = its mailbox
-constexpr int kPairZm = 520;                                   // float2: [8][64] sums of Z[N-k] + lane 0's mirror slot
-constexpr int kPairLds = 2 * kPairWork + 2 * kPairZm + 2;      // + 4 flag words
+constexpr int kPairWork = 576;                          // float2: a wave's FFT work space
+constexpr int kPairMail = 256;                          // float2: one mailbox slot = 4 bins x 64 lanes
+constexpr int kPairWave = kPairWork + 2 * kPairMail;    // per wave
+constexpr int kPairLds = 2 * kPairWave + 2;             // per pair, + 4 flag words
 
-JF_DEV void pair_wait(const volatile int *flag, int v) {
-    while (__builtin_amdgcn_readfirstlane(*flag) < v) __builtin_amdgcn_s_sleep(1);
+// Flag words are read and written with explicit LDS instructions on their LDS byte address (the low half of the
+// generic address): a volatile access through a generic pointer compiles to flat loads.
+JF_DEV int lds_flag_read(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+JF_DEV void lds_flag_write(unsigned addr, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// Every wait is bounded (about a tenth of a second): a hand-off that never arrives -- impossible by the protocol
+// above -- raises the host-visible error word and lets the grid drain instead of hanging the GPU.
+JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
+#ifdef JF_EXP_NOWAIT  // timing experiment (wrong results): what do the hand-off waits cost?
+    return;
+#endif
+    if (dead) return;  // after one time-out this wave no longer waits for anything
+    for (int spins = 0; lds_flag_read(flag) < v; spins++) {
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1 << 20)) {
+            *reinterpret_cast<volatile int *>(err) = 1;
+            dead = true;
+            return;
+        }
+    }
 }
 
-// Bins qb .. qb + 3 (hp already points at bin 64 qb + lane of row 0) of one filter set, or of two sets that
+// Bins qb .. qb + 3 (hbase already points at bin 64 qb + lane of row 0) of one filter set, or of two sets that
 // read the same rows with different weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.
 template <int NT, bool BOTH, class F>
 JF_DEV void filtered_half(const float4 *__restrict__ hbase, const int *rows, const float *wa, const float *wb,
@@ -847,6 +880,10 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ hbase, const int
         filtered_half<1, BOTH>(hbase, rows, wa, wb, xh, special, use);
 }
 
+#ifndef JF_PAIR_D_EARLY
+#define JF_PAIR_D_EARLY 0
+#endif
+
 template <int NOUT>
 __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     __shared__ float2 s_tw[kTwPack];
@@ -854,7 +891,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int tid = threadIdx.x;
     for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
     if (tid < kPairsPerWg) {
-        int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWork + 2 * kPairZm);
+        int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWave);
         f[0] = f[1] = f[2] = f[3] = 0;
     }
     __syncthreads();
@@ -863,29 +900,30 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wave >> 1, half = wave & 1;
     float2 *base = s_pair + pair * kPairLds;
-    float2 *buf = base + half * kPairWork;         // my FFT work space and mailbox
-    float2 *pbuf = base + (half ^ 1) * kPairWork;  // the partner's
-    float2 *zm = base + 2 * kPairWork;             // [set][kPairZm] sums of Z[N-k], both waves' bins
-    volatile int *flags = reinterpret_cast<volatile int *>(zm + 2 * kPairZm);
-    volatile int *my_pub = flags + half, *his_pub = flags + (half ^ 1);
-    volatile int *my_ack = flags + 2 + half, *his_ack = flags + 2 + (half ^ 1);
+    float2 *buf = base + half * kPairWave;  // my FFT work space
+    float2 *mail = buf + kPairWork;         // my two mailbox slots
+    const float2 *pbuf = base + (half ^ 1) * kPairWave, *pmail = pbuf + kPairWork;  // the partner's
+    const unsigned flags = (unsigned)(size_t)(base + 2 * kPairWave);  // LDS byte address of pub[2], ack[2]
+    const unsigned my_pub = flags + 4 * half, his_pub = flags + 4 * (half ^ 1);
+    const unsigned my_ack = flags + 8 + 4 * half, his_ack = flags + 8 + 4 * (half ^ 1);
     int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
+    bool dead = false;        // a wait timed out (pair_wait)
     auto publish = [&]() {
         JF_WAVE_LDS_SYNC();
         npub++;
-        if (lane == 0) *my_pub = npub;
+        if (lane == 0) lds_flag_write(my_pub, npub);
     };
-    auto await_partner = [&]() {  // the partner's next hand-off is in its work area
+    auto await_partner = [&]() {  // the partner's next hand-off is in its mailbox
         nseen++;
-        pair_wait(his_pub, nseen);
+        pair_wait(his_pub, nseen, P.err, dead);
         JF_WAVE_LDS_SYNC();
     };
-    auto consumed = [&]() {  // I am done reading the partner's work area
+    auto consumed = [&]() {  // I am done reading the partner's mailbox
         JF_WAVE_LDS_SYNC();
-        if (lane == 0) *my_ack = nseen;
+        if (lane == 0) lds_flag_write(my_ack, nseen);
     };
-    auto own_work_area = [&]() {  // the partner has consumed everything I published
-        pair_wait(his_ack, npub);
+    auto mail_free = [&](int upto) {  // the partner has consumed my hand-offs 1 .. upto
+        pair_wait(his_ack, upto, P.err, dead);
         JF_WAVE_LDS_SYNC();
     };
 
@@ -896,7 +934,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int qb = 4 * half;
     const bool special = lane == 0 && half == 0;
     const float4 *hbase = P.htab + 64 * qb + lane;
-    float2 *zmo = zm + 64 * qb + lane, *zmn = zm + kPairZm + 64 * qb + lane;  // + 64 q: my slots of the old / new sums
+    const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
 #pragma unroll 1
     for (int unit = blockIdx.x * kPairsPerWg + pair; unit < n_units; unit += gridDim.x * kPairsPerWg) {
 #if JF_UNIT_ORDER
@@ -911,107 +949,133 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
         bool any_xfade = false;
         for (int g = 0; g < G; g++) any_xfade = any_xfade || ((d0[g].flags & 2) != 0 && d0[g].n_new > 0);
-        own_work_area();  // also: the partner has read my slots of the last unit's sums
-        float2 zko[4], zkn[4];
+        mail_free(npub);  // the last unit's final hand-offs used both slots
+        // sums over the unit's sources of Z[k] and Z[N-k], k = lane + 64 (qb + q), old and new sets
+        float2 zko[4], zkn[4], zmo[4], zmn[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            zko[q] = zkn[q] = make_float2(0.f, 0.f);
-            zmo[64 * q] = make_float2(0.f, 0.f);
-            zmn[64 * q] = make_float2(0.f, 0.f);
-        }
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const ItemDesc *dp = d0 + g;
-            const bool audible = dp->n_new > 0;
-            const bool mine = (g & 1) == half;
-            if (mine) {
-                own_work_area();
-                const int item = b * P.S + s0 + g;
-                float2 xd[8];
-                if (item_front<NOUT, true>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) {
-#pragma unroll
-                    for (int q = 0; q < 8; q++) buf[64 * q + lane] = xd[q];
-                    publish();
-                }
-            } else if (audible) {
-                await_partner();
-            }
-            if (!audible) continue;
-            const float2 *mail = (mine ? buf : pbuf) + 64 * qb + lane;
-            float2 xh[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) xh[q] = mail[64 * q];
-            if (!mine) consumed();
+        for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = make_float2(0.f, 0.f);
+        auto accumulate = [&](const ItemDesc *dp, const float2 (&xh)[4]) {
+#ifdef JF_EXP_NOFILTER  // timing experiment (wrong results): fronts and hand-offs only
+            zkn[0] = cadd(zkn[0], xh[0]);
+            return;
+#endif
             const int nn = dp->n_new;
             if (!any_xfade) {
                 filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zkn[q] = cadd(zkn[q], zk);
-                                            zmn[64 * q] = cadd(zmn[64 * q], zmv);
+                                            zmn[q] = cadd(zmn[q], zmv);
                                         });
             } else if (dp->flags & 1) {
                 // both sets read the same rows (prep_kernel laid them out so): one round of loads
                 filtered_half_nt<true>(nn, hbase, dp->rows_new, dp->w_old, dp->w_new, xh, special,
                                        [&](int q, float2 zka, float2 zma, float2 zkb, float2 zmb) {
                                            zko[q] = cadd(zko[q], zka);
-                                           zmo[64 * q] = cadd(zmo[64 * q], zma);
+                                           zmo[q] = cadd(zmo[q], zma);
                                            zkn[q] = cadd(zkn[q], zkb);
-                                           zmn[64 * q] = cadd(zmn[64 * q], zmb);
+                                           zmn[q] = cadd(zmn[q], zmb);
                                        });
             } else {
                 filtered_half_nt<false>(dp->n_old, hbase, dp->rows_old, dp->w_old, dp->w_old, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zko[q] = cadd(zko[q], zk);
-                                            zmo[64 * q] = cadd(zmo[64 * q], zmv);
+                                            zmo[q] = cadd(zmo[q], zmv);
                                         });
                 filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zkn[q] = cadd(zkn[q], zk);
-                                            zmn[64 * q] = cadd(zmn[64 * q], zmv);
+                                            zmn[q] = cadd(zmn[q], zmv);
                                         });
             }
+        };
+        auto take_partner_source = [&](int jp) {  // his j-th source: my bins of its X D are in his mailbox
+            const ItemDesc *dp = d0 + 2 * jp + (half ^ 1);
+            if (dp->n_new <= 0) return;  // silent: he published nothing
+            await_partner();
+            const float2 *m = pmail + (nseen & 1) * kPairMail + lane;
+            float2 xh[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) xh[q] = m[64 * q];
+            consumed();
+            accumulate(dp, xh);
+        };
+        int jp = 0;
+#pragma unroll 1
+        for (int j = 0; j < n_own; j++) {
+            const int g = 2 * j + half;
+            const ItemDesc *dp = d0 + g;
+            const int item = b * P.S + s0 + g;
+            float2 xd[8];
+            if (item_front<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) {
+                float2 xh[4];
+                mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
+                float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    xh[q] = half ? xd[4 + q] : xd[q];
+                    m[64 * q] = half ? xd[q] : xd[4 + q];
+                }
+                publish();
+                accumulate(dp, xh);
+            }
+            // the partner's sources one step late: his hand-off has been waiting for a whole source
+            if (jp < j && jp < n_his) take_partner_source(jp++);
         }
+#pragma unroll 1
+        for (; jp < n_his; jp++) take_partner_source(jp);
+
         // ---- the two inverse transforms: wave 0 takes the old sum, wave 1 the new one
         const bool give = half == 0 || any_xfade;  // my bins of the sum the partner inverts
         const bool take = half == 1 || any_xfade;  // I invert a sum
         if (give) {
-            own_work_area();
+            mail_free(npub);  // both slots: Z[k] in the first, Z[N-k] in the second
 #pragma unroll
-            for (int q = 0; q < 4; q++) buf[64 * q + lane] = half == 0 ? zkn[q] : zko[q];
-            if (special) {  // lane 0's partner in the Hermitian mirror is itself (see mirror8)
-                zm[512] = zm[0];
-                zm[kPairZm + 512] = zm[kPairZm];
+            for (int q = 0; q < 4; q++) {
+                mail[64 * q + lane] = half == 0 ? zkn[q] : zko[q];
+                mail[kPairMail + 64 * q + lane] = half == 0 ? zmn[q] : zmo[q];
             }
-            publish();
         }
+        if (take) {  // my own Z[N-k] go through LDS as well: the inverse needs them from lane 64 - lane
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[64 * q + lane] = half == 0 ? zmo[q] : zmn[q];
+        }
+        if (give) publish();
         float2 fr[NOUT];
         if (take) {
             await_partner();
             float2 v[16];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float2 theirs = pbuf[64 * q + lane];
+                const float2 theirs = pmail[64 * q + lane];
                 const float2 own = half == 0 ? zko[q] : zkn[q];
                 v[q] = half == 0 ? own : theirs;
                 v[4 + q] = half == 0 ? theirs : own;
             }
-            const float2 *rd = zm + half * kPairZm + (64 - lane);
+            // Z[lane + 64 r], r = 8..15 = Z[N-k] of bin 7 - j on lane 64 - lane; lane 0: its own bin (8 - j) & 7
+            // (see mirror8).  Bins 0..3 are wave 0's, 4..7 wave 1's: mine in my work space, his in his mailbox.
+            const float2 *lo = half == 0 ? buf : pmail + kPairMail;
+            const float2 *hi = half == 0 ? pmail + kPairMail : buf;
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[8 + j] = rd[64 * (7 - j)];
+            for (int j = 0; j < 8; j++) {
+                const int qn = 7 - j, q0 = (8 - j) & 7;  // bin read by lanes 1..63 / by lane 0
+                const float2 *pn = (qn < 4 ? lo : hi) + 64 * (qn & 3) + (64 - lane);
+                const float2 *p0 = (q0 < 4 ? lo : hi) + 64 * (q0 & 3);
+                v[8 + j] = *(lane == 0 ? p0 : pn);
+            }
             consumed();
-            if (give) own_work_area();  // the partner has fetched my bins: the work area is free for the exchange
             ifft1024_lastq_wave<NOUT, true>(v, fr, buf, s_tw, lane);
         }
         if (any_xfade) {
             if (half == 0) {
+                mail_free(npub);
 #pragma unroll
-                for (int j = 0; j < NOUT; j++) buf[64 * j + lane] = fr[j];
+                for (int j = 0; j < NOUT; j++) mail[64 * j + lane] = fr[j];
                 publish();
             } else {
                 await_partner();
 #pragma unroll
                 for (int j = 0; j < NOUT; j++) {
-                    const float2 old = pbuf[64 * j + lane];
+                    const float2 old = pmail[64 * j + lane];
                     // kernels.cu:132-137
                     const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
                     const float fn = (float)n_out / ((float)B - 1.0f);
@@ -1225,7 +1289,7 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
         d.n_old = 0;
         d.c_fix = 0;
         d.inv_frac = 1.0f;
-        d.pad = 0;
+        d.flags = 0;
         return;
     }
     d.n_new = dev_interp_terms(rt, ele, azi, d.rows_new, d.w_new, corrected);
@@ -1255,18 +1319,18 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
     }
     d.inv_frac = 1.0f / frac;
     if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
-    d.pad = 0;
+    d.flags = 0;
 }
 
 // Two adjacent lanes per item: the even one does the new position's rule and the distance part, the odd one
 // the old position's rule (the kernel is a short dependent chain per thread at one wave per SIMD: halving
 // the chain halves its time).  Same arithmetic as make_desc, which the real-time kernel uses.
 __global__ void prep_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
-                            const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K) {
+                            const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K, int canon) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int item = tid >> 1;
     const bool old_half = tid & 1;
-    const bool live = item < S * K;  // both lanes of a pair agree; no early return before the shuffle
+    const bool live = item < S * K;  // both lanes of a pair agree; no early return before the shuffles
     const int it = live ? item : 0;
     const int b = it / S, s = it - b * S;
     const float *p = pos + (size_t)it * 5;
@@ -1300,9 +1364,18 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
     } else if (moved) {
         n = dev_interp_terms(rt, old_ele, old_azi, rows, w, corrected);
     }
+    // the other half's result (the even lane needs the old set for the pair-kernel layout)
     const int n_other = __shfl_xor(n, 1);
+    int orow[4];
+    float ow[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        orow[t] = __shfl_xor(rows[t], 1);
+        ow[t] = __shfl_xor(w[t], 1);
+    }
     if (!live) return;
     if (old_half) {
+        if (canon) return;  // the even lane writes the whole record
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             d.rows_old[t] = rows[t];
@@ -1311,33 +1384,92 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
         d.n_old = n;
         return;
     }
+    int flags = 0;
+    if (mode & 1) {
+        d.c_fix = 0;
+        d.inv_frac = 1.0f;
+    } else {
+        if (moved && n_other == 0) n = 0;  // the old position is not interpolable
+        // GPUSoundSource.cu:81-90
+        const float x = p[2], y = p[3], z = p[4];
+        float r = sqrtf(x * x + y * y + z * z);
+        r /= 5;
+        const float fsvs = (float)(44100.0 / 343.0);
+        const float frac = 1 + fsvs * (float)((double)r * (double)r);
+        {
+            // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+            double c = (double)fsvs * (double)r / 513.0;
+            c -= floor(c);
+            d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
+        }
+        d.inv_frac = 1.0f / frac;
+        if (!(frac >= 1.0f) || !(frac < 3.0e38f)) n = 0;  // NaN / inf coordinates
+    }
+    if (canon) {
+        // Layout for fused_pair_kernel.  A source that did not move carries its new set as its old set (inside a
+        // unit that crossfades it goes through both sums).  If the rows of one set are, in order, among the rows of
+        // the other -- a step inside one grid cell, onto a grid line or off one -- both sets are written on the
+        // larger set's rows, with weight 0 where a set does not use a row: the kernel then loads each row once.
+        // A term with weight 0 adds +-0, and the other terms keep their order, so each set's weighted sum is
+        // bit-identical to the sum over its own rows.
+        const bool xf = moved && !(mode & 1) && n > 0;
+        flags = xf ? 2 : 0;
+        int n_o = xf ? n_other : n;
+        if (!xf) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                orow[t] = rows[t];
+                ow[t] = w[t];
+            }
+        }
+        const bool new_is_big = n >= n_o;
+        int big_rows[4], small_rows[4];
+        float big_w[4], small_w[4], ex_w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            big_rows[t] = new_is_big ? rows[t] : orow[t];
+            big_w[t] = new_is_big ? w[t] : ow[t];
+            small_rows[t] = new_is_big ? orow[t] : rows[t];
+            small_w[t] = new_is_big ? ow[t] : w[t];
+        }
+        const int n_big = new_is_big ? n : n_o, n_small = new_is_big ? n_o : n;
+        bool share = n > 0;
+        int from = 0;
+        for (int i = 0; i < n_small && share; i++) {
+            int at = -1;
+            for (int k = from; k < n_big; k++)
+                if (at < 0 && big_rows[k] == small_rows[i]) at = k;
+            if (at < 0) {
+                share = false;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) ex_w[k] = k == at ? small_w[i] : ex_w[k];
+                from = at + 1;
+            }
+        }
+        if (share) {
+            flags |= 1;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                rows[t] = orow[t] = big_rows[t];
+                w[t] = new_is_big ? big_w[t] : ex_w[t];
+                ow[t] = new_is_big ? ex_w[t] : big_w[t];
+            }
+            n = n_o = n_big;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            d.rows_old[t] = orow[t];
+            d.w_old[t] = ow[t];
+        }
+        d.n_old = n > 0 ? n_o : 0;
+    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         d.rows_new[t] = rows[t];
         d.w_new[t] = w[t];
     }
-    d.pad = 0;
-    if (mode & 1) {
-        d.n_new = n;
-        d.c_fix = 0;
-        d.inv_frac = 1.0f;
-        return;
-    }
-    if (moved && n_other == 0) n = 0;  // the old position is not interpolable
-    // GPUSoundSource.cu:81-90
-    const float x = p[2], y = p[3], z = p[4];
-    float r = sqrtf(x * x + y * y + z * z);
-    r /= 5;
-    const float fsvs = (float)(44100.0 / 343.0);
-    const float frac = 1 + fsvs * (float)((double)r * (double)r);
-    {
-        // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-        double c = (double)fsvs * (double)r / 513.0;
-        c -= floor(c);
-        d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
-    }
-    d.inv_frac = 1.0f / frac;
-    if (!(frac >= 1.0f) || !(frac < 3.0e38f)) n = 0;  // NaN / inf coordinates
+    d.flags = flags;
     d.n_new = n;
 }
 
@@ -1554,23 +1686,33 @@ hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const fl
 }
 
 hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const SrcState *d_st, ItemDesc *d_desc,
-                       int S, int K, hipStream_t st) {
+                       int S, int K, int canon, hipStream_t st) {
     const int n = S * K;
-    hipLaunchKernelGGL(prep_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, rt, mode, d_pos, d_st, d_desc, S, K);
+    hipLaunchKernelGGL(prep_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, rt, mode, d_pos, d_st, d_desc, S, K,
+                       canon);
     return hipGetLastError();
 }
 
 // Resident workgroups of the fused kernel that a call with these parameters launches (per-source kernel for
 // G = 1, group kernel otherwise), on the CURRENT device: CUs x workgroups per CU for this build's LDS and register
 // footprint.  The engine asks once per (kernel, block size) at creation and keeps the answer with its device.
-hipError_t fused_resident_workgroups(int nb, bool group, int *out) {
+hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source, 1 group, 2 pair kernel */, int *out) {
+    const bool group = kind == 1;
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     hipError_t q = hipGetDevice(&dev);
     if (q == hipSuccess) q = hipGetDeviceProperties(&prop, dev);
     if (q != hipSuccess) return q;
     const int threads = 64 * kWavesPerWg;
-    if (group) {
+    if (kind == 2) {
+        switch (nb) {
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1>, threads, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2>, threads, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<3>, threads, 0); break;
+        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<4>, threads, 0); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else if (group) {
         switch (nb) {
         case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<1>, threads, 0); break;
         case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<2>, threads, 0); break;
@@ -1601,11 +1743,22 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
     const int n_items = P.K * (P.S / P.G);
     const int nb = P.B / 64;
     if (nb < 1 || nb > 4) return hipErrorInvalidValue;
-    int wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
+    const int per_wg = (P.G > 1 && P.form == 1) ? kPairsPerWg : kWavesPerWg;  // units a workgroup works on at a time
+    int wgs = (n_items + per_wg - 1) / per_wg;
     if (wgs > max_wgs) wgs = max_wgs;
     const dim3 grid(wgs), block(64 * kWavesPerWg);
     // groups of sources are summed as spectra (one pair of inverse transforms per group); single sources
     // keep the per-source kernel, whose blocks are the reference's per-source `intermediate`
+    if (P.G > 1 && P.form == 1) {
+        switch (P.B / 64) {
+        case 1: hipLaunchKernelGGL(fused_pair_kernel<1>, grid, block, 0, st, P); break;
+        case 2: hipLaunchKernelGGL(fused_pair_kernel<2>, grid, block, 0, st, P); break;
+        case 3: hipLaunchKernelGGL(fused_pair_kernel<3>, grid, block, 0, st, P); break;
+        case 4: hipLaunchKernelGGL(fused_pair_kernel<4>, grid, block, 0, st, P); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (P.G > 1) {
         switch (P.B / 64) {
         case 1: hipLaunchKernelGGL(fused_group_kernel<1>, grid, block, 0, st, P); break;

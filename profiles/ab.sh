@@ -1,13 +1,19 @@
 #!/bin/bash
-# A/B of fused-kernel builds on one GPU box: profiles/ab.sh tag1 tag2 ...  ("base" = the product .so)
-# extra bench flags via ABFLAGS
+# A/B of kernel builds on the GPU box: profiles/ab.sh <tag> [<tag> ...]   ("-" = the product library)
+# Each tag is a library built with `make -C jefferson-2.0_amd/csrc variant TAG=<tag> KFLAGS=...`.
+# Every run keeps its stderr and exit code; a failed variant prints FAILED, never a traceback.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
-for rep in 1 2; do
-for t in "$@"; do
-  if [ "$t" = base ]; then L=""; else L="$REPO/jefferson-2.0_amd/libjefferson_hip_$t.so"; fi
-  JF_LIB=$L timeout -k 10 120 python3 bench.py --steps 300 --warmup 200 --no-cpu-baseline $ABFLAGS 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$t rep$rep: value %.3e  step %.4f ms  fused %.4f ms  frac %.3f' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac']))"
-done; done
+ARGS=${AB_ARGS:---steps 256 --warmup 256 --no-cpu-baseline --no-pmc}
+for T in "$@"; do
+  if [ "$T" = "-" ]; then unset JF_LIB; N=product; else export JF_LIB=$REPO/jefferson-2.0_amd/libjefferson_hip_$T.so; N=$T; fi
+  for R in 1 2; do
+    timeout -k 10 300 python3 bench.py $ARGS > gpurun_out/ab_${N}_$R.json 2> gpurun_out/ab_${N}_$R.err
+    RC=$?
+    if [ $RC -ne 0 ] || [ ! -s gpurun_out/ab_${N}_$R.json ]; then
+      echo "FAILED $N rep $R rc=$RC: $(tail -n 2 gpurun_out/ab_${N}_$R.err | tr '\n' ' ')"
+    else
+      python3 profiles/bench_brief.py gpurun_out/ab_${N}_$R.json
+    fi
+  done
+done
