@@ -33,7 +33,20 @@ namespace jf {
 
 // --------------------------------------------------------------- helpers --
 #define JF_DEV __device__ __forceinline__
+// The value again, opaque to the optimiser: expressions of the result cannot be hoisted out of the enclosing loop.
+// Used on the lane index where the compiler would otherwise keep dozens of loop-invariant per-lane addresses and
+// constants alive across a whole persistent kernel -- and spill them.
+JF_DEV int opaque(int x) {
+#ifndef JF_EXP_NO_OPAQUE
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 typedef float __attribute__((address_space(1))) gfloat;  // float in global memory
+struct __attribute__((packed, aligned(4))) FloatPair {   // two consecutive samples, 4-byte aligned
+    float x, y;
+};
+typedef FloatPair __attribute__((address_space(1))) gpair;
 
 // LDS traffic below is private to one wavefront; LDS ops of a wave execute in
 // issue order, so all that is needed is to stop the compiler from moving a
@@ -486,27 +499,39 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
     const int qpos = q0 > 0 ? q0 : 0;
     const int base = (int)(((long long)count0 + qpos) % L) - qpos;  // signal index of q = 0 (mod L)
     float2 z[8];
+    // Where the window comes from is wave-uniform.  Usual case: all of it from one stretch of the looped signal --
+    // eight loads of a sample pair per lane at scalar base + 8 lane + 512 r, no per-lane index arithmetic.  Else
+    // (the first blocks of a call, whose windows reach back into the previous one; a window across the loop point of
+    // the signal) every lane works out where its samples are; all loads are in flight together either way.
+    int start0 = base + q0;  // signal index of the window's first sample (meaningful for q0 >= 0), < L + N
+    start0 = start0 >= L ? start0 - L : start0;
+    if (q0 >= 0 && start0 + kN <= L) {
+        const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int qr = q0 + 128 * r;  // first sample of this 128-sample row (wave-uniform)
-        if ((NOUT % 2 == 0) && qr < 0) {
-            // B is a multiple of 128: the window/signal boundary falls between rows
-            z[r] = *reinterpret_cast<const float2 *>(hist + (kN + qr) + 2 * lane);
-        } else if (NOUT % 2 == 0) {
-            int i0 = base + qr + 2 * lane, i1 = i0 + 1;  // < L + N
-            i0 = i0 >= L ? i0 - L : i0;
-            i1 = i1 >= L ? i1 - L : i1;
-            z[r] = make_float2(sigp[i0], sigp[i1]);
-        } else {
-            float xv[2];
+        for (int r = 0; r < 8; r++) z[r] = make_float2(p[64 * r].x, p[64 * r].y);
+    } else {
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const int q = qr + 2 * lane + c;
-                int idx = base + q;  // < L + N for q >= 0
-                idx = idx >= L ? idx - L : idx;
-                xv[c] = q < 0 ? hist[kN + q] : sigp[idx];
+        for (int r = 0; r < 8; r++) {
+            const int qr = q0 + 128 * r;  // first sample of this 128-sample row (wave-uniform)
+            if ((NOUT % 2 == 0) && qr < 0) {
+                // B is a multiple of 128: the window/signal boundary falls between rows
+                z[r] = *reinterpret_cast<const float2 *>(hist + (kN + qr) + 2 * lane);
+            } else if (NOUT % 2 == 0) {
+                int i0 = base + qr + 2 * lane, i1 = i0 + 1;  // < L + N
+                i0 = i0 >= L ? i0 - L : i0;
+                i1 = i1 >= L ? i1 - L : i1;
+                z[r] = make_float2(sigp[i0], sigp[i1]);
+            } else {
+                float xv[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int q = qr + 2 * lane + c;
+                    int idx = base + q;  // < L + N for q >= 0
+                    idx = idx >= L ? idx - L : idx;
+                    xv[c] = q < 0 ? hist[kN + q] : sigp[idx];
+                }
+                z[r] = make_float2(xv[0], xv[1]);
             }
-            z[r] = make_float2(xv[0], xv[1]);
         }
     }
     // ---- distance factor.  The 1/N of the forward transform and the 1/2 of its split pass ride on
@@ -810,18 +835,24 @@ JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
     }
 }
 
-// Bins qb .. qb + 3 (hbase already points at bin 64 qb + lane of row 0) of one filter set, or of two sets that
-// read the same rows with different weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.
+// Bins qb .. qb + 3 (lofs = 64 qb + lane) of one filter set, or of two sets that read the same rows with different
+// weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.  Row addresses stay scalar (table + row, wave-uniform)
+// with ONE per-lane offset register for all rows: loads in the saddr form, no 64-bit pointer pair per row.
 template <int NT, bool BOTH, class F>
-JF_DEV void filtered_half(const float4 *__restrict__ hbase, const int *rows, const float *wa, const float *wb,
+JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa, const float *wb,
                           const float2 (&xh)[4], bool special, F &&use) {
     const float4 *hp[NT];
     float a[NT], b[NT];
+    // opaque to the optimiser here: otherwise it folds table + lane offset into one loop-invariant 64-bit VGPR pointer
+    // and adds the row to that, one VGPR pair per row
+    unsigned boff = 16u * lofs;  // byte offset of this lane's first bin inside a row
+    asm("" : "+v"(boff));
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        hp[t] = hbase + (size_t)rows[t] * 512;
-        a[t] = wa[t];
-        b[t] = BOTH ? wb[t] : 0.0f;
+        // rows and weights are wave-uniform: pin them to scalar registers
+        hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512;
+        a[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wa[t])));
+        b[t] = BOTH ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wb[t]))) : 0.0f;
     }
     constexpr int QC = (JF_CHUNK_LOADS / NT) > 4 ? 4 : (JF_CHUNK_LOADS / NT);
     auto ztwo = [&](int q, float2 x, float4 he, float2 &zk, float2 &zm) {
@@ -842,7 +873,8 @@ JF_DEV void filtered_half(const float4 *__restrict__ hbase, const int *rows, con
 #pragma unroll
         for (int q = 0; q < QC; q++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) h[q][t] = hp[t][64 * (qc + q)];
+            for (int t = 0; t < NT; t++)
+                h[q][t] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (qc + q)) + boff);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
             float4 ha = make_float4(a[0] * h[q][0].x, a[0] * h[q][0].y, a[0] * h[q][0].z, a[0] * h[q][0].w);
@@ -870,14 +902,14 @@ JF_DEV void filtered_half(const float4 *__restrict__ hbase, const int *rows, con
 }
 
 template <bool BOTH, class F>
-JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ hbase, const int *rows, const float *wa, const float *wb,
-                             const float2 (&xh)[4], bool special, F &&use) {
+JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa,
+                             const float *wb, const float2 (&xh)[4], bool special, F &&use) {
     if (nt == 4)
-        filtered_half<4, BOTH>(hbase, rows, wa, wb, xh, special, use);
+        filtered_half<4, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
     else if (nt == 2)
-        filtered_half<2, BOTH>(hbase, rows, wa, wb, xh, special, use);
+        filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
     else
-        filtered_half<1, BOTH>(hbase, rows, wa, wb, xh, special, use);
+        filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
 }
 
 #ifndef JF_PAIR_D_EARLY
@@ -933,7 +965,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int a = lane & 3, i = lane >> 2;
     const int qb = 4 * half;
     const bool special = lane == 0 && half == 0;
-    const float4 *hbase = P.htab + 64 * qb + lane;
+    const unsigned lofs = 64u * qb + lane;
     const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
 #pragma unroll 1
     for (int unit = blockIdx.x * kPairsPerWg + pair; unit < n_units; unit += gridDim.x * kPairsPerWg) {
@@ -961,14 +993,14 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #endif
             const int nn = dp->n_new;
             if (!any_xfade) {
-                filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
+                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zkn[q] = cadd(zkn[q], zk);
                                             zmn[q] = cadd(zmn[q], zmv);
                                         });
             } else if (dp->flags & 1) {
                 // both sets read the same rows (prep_kernel laid them out so): one round of loads
-                filtered_half_nt<true>(nn, hbase, dp->rows_new, dp->w_old, dp->w_new, xh, special,
+                filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, xh, special,
                                        [&](int q, float2 zka, float2 zma, float2 zkb, float2 zmb) {
                                            zko[q] = cadd(zko[q], zka);
                                            zmo[q] = cadd(zmo[q], zma);
@@ -976,12 +1008,12 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                                            zmn[q] = cadd(zmn[q], zmb);
                                        });
             } else {
-                filtered_half_nt<false>(dp->n_old, hbase, dp->rows_old, dp->w_old, dp->w_old, xh, special,
+                filtered_half_nt<false>(dp->n_old, P.htab, lofs, dp->rows_old, dp->w_old, dp->w_old, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zko[q] = cadd(zko[q], zk);
                                             zmo[q] = cadd(zmo[q], zmv);
                                         });
-                filtered_half_nt<false>(nn, hbase, dp->rows_new, dp->w_new, dp->w_new, xh, special,
+                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
                                         [&](int q, float2 zk, float2 zmv, float2, float2) {
                                             zkn[q] = cadd(zkn[q], zk);
                                             zmn[q] = cadd(zmn[q], zmv);
@@ -1006,7 +1038,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             const ItemDesc *dp = d0 + g;
             const int item = b * P.S + s0 + g;
             float2 xd[8];
-            if (item_front<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) {
+            if (item_front<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, opaque(lane), xd)) {
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
                 float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
@@ -1063,7 +1095,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                 v[8 + j] = *(lane == 0 ? p0 : pn);
             }
             consumed();
-            ifft1024_lastq_wave<NOUT, true>(v, fr, buf, s_tw, lane);
+            ifft1024_lastq_wave<NOUT, true>(v, fr, buf, s_tw, opaque(lane));
         }
         if (any_xfade) {
             if (half == 0) {
