@@ -336,18 +336,26 @@ JF_DEV void ifft1024_lastq_wave(float2 (&v)[16], float2 (&out)[NOUT], float2 *bu
 // D[k] = exp(-2 pi i * fsvs r' k / 513) * inv_frac (kernels.cu:116-125).  The phase is
 // exact integer arithmetic: c = frac(fsvs r'/513) as a 64-bit fraction of a turn, phase(k) =
 // k*c mod 1 (top 32 bits kept, 1.5e-9 rad), split into the nearest quarter turn and a
-// remainder |f| <= 1/2 quarter turn that goes through float minimax kernels.
+// remainder |f| <= 1/2 quarter turn that goes through float minimax kernels with an exactly
+// represented argument (two floats).
 // p = the phase word.  Branch-free: the quarter only swaps sin/cos and sets sign bits.
 JF_DEV float2 distance_from_phase(unsigned p, float inv_frac) {
     const unsigned p2 = p + 0x20000000u;  // + 1/8 turn: round to the nearest quarter
     const int rem = (int)(p2 & 0x3FFFFFFFu) - 0x20000000;
-    // x = remainder in radians, |x| <= pi/4
-    const float x = (float)rem * (1.57079632679489661923f / 1073741824.0f);
+    // x + xl = remainder in radians, |x| <= pi/4, to ~1e-16: the 30-bit remainder does not fit a float (rf rounds, rl
+    // is what it drops) and neither does pi/2 / 2^30 (Kh + Kl); xl collects both residuals with exact FMAs
+    constexpr float Kh = 0x1.921fb6p-30f, Kl = -0x1.777a5cp-55f;
+    const float rf = (float)rem;
+    const float rl = (float)(rem - (int)rf);
+    const float x = rf * Kh;
+    const float xl = fmaf(rl, Kh, fmaf(rf, Kl, fmaf(rf, Kh, -x)));
     const float x2 = x * x;
-    // Cephes sinf/cosf kernels, ~1 ulp
-    const float s = x + x * x2 * (-1.6666654611e-1f + x2 * (8.3321608736e-3f + x2 * -1.9515295891e-4f));
-    const float c = 1.0f - 0.5f * x2 +
-                    x2 * x2 * (4.166664568298827e-2f + x2 * (-1.388731625493765e-3f + x2 * 2.443315711809948e-5f));
+    // Cephes sinf/cosf kernels, ~1 ulp, then the first-order correction for xl
+    const float s0 = x + x * x2 * (-1.6666654611e-1f + x2 * (8.3321608736e-3f + x2 * -1.9515295891e-4f));
+    const float c0 = 1.0f - 0.5f * x2 +
+                     x2 * x2 * (4.166664568298827e-2f + x2 * (-1.388731625493765e-3f + x2 * 2.443315711809948e-5f));
+    const float s = fmaf(xl, c0, s0);
+    const float c = fmaf(-xl, s0, c0);
     // quarter q = p2 >> 30: (cos, sin) = (c, s), (-s, c), (-c, -s), (s, -c); the result is (cos, -sin) * inv_frac
     const bool odd = (p2 & 0x40000000u) != 0;
     const float cc = odd ? s : c, ss = odd ? c : s;
@@ -357,10 +365,15 @@ JF_DEV float2 distance_from_phase(unsigned p, float inv_frac) {
                        __uint_as_float(__float_as_uint(ss * inv_frac) ^ neg_im));
 }
 
-// D of this lane's bins lane + 64 q, q = 0..7, and Re D[512].  Phase words by 64-bit accumulation (two
-// adds per bin instead of two quarter-rate 32-bit multiplies): hi32(k c mod 2^64), k = lane + 64 q.
+// D of this lane's bins lane + 64 q, q = 0..7, and Re D[512].  Phase words by 64-bit accumulation (two adds per bin
+// instead of two quarter-rate 32-bit multiplies): hi32(k c mod 2^64), k = lane + 64 q; every bin evaluated on its own.
+// JF_FAST_DISTANCE (off): D[lane + 64 q] = D[lane] E^q with the wave-uniform step E = exp(-2 pi i 64 c), whose
+// powers lanes 0..8 evaluate and broadcast through scalar registers -- 135 fewer instructions per source-block, 4.5 %
+// of the batch kernel's time, but one more rounding per factor: on a full-scale signal (|y| ~ 1.2) the output error
+// against float64 grows from 2.06e-7 to 2.90e-7, past the reference's 2e-7 (profiles/r02_experiments.md).
 JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int lane, float2 (&dq)[8], float &d512x) {
     const unsigned long long c64 = ((unsigned long long)c_hi << 32) | c_lo;
+#ifndef JF_FAST_DISTANCE
     unsigned long long ph = (unsigned long long)(unsigned)lane * c64;
     const unsigned long long step = c64 << 6;
 #pragma unroll
@@ -369,6 +382,18 @@ JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int l
         ph += step;
     }
     d512x = distance_from_phase((unsigned)((c64 << 9) >> 32), inv_frac).x;
+#else
+    const float2 d0 = distance_from_phase((unsigned)(((unsigned long long)(unsigned)lane * c64) >> 32), inv_frac);
+    const float2 e = distance_from_phase((unsigned)(((unsigned long long)(unsigned)(lane & 15) * (c64 << 6)) >> 32), 1.0f);
+    dq[0] = d0;
+#pragma unroll
+    for (int q = 1; q < 8; q++) {
+        const float ex = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.x), q));
+        const float ey = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.y), q));
+        dq[q] = cmul(d0, make_float2(ex, ey));
+    }
+    d512x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.x), 8)) * inv_frac;
+#endif
 }
 
 // ------------------------------------------------------ filter + inverse --
