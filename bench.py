@@ -227,8 +227,7 @@ def main():
     pmc, pmc_note = None, "not collected"
     if world == 1 and not args.pmc_child and not args.no_pmc and not args.realtime:
         extra = (["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
-        pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_group_kernel", "fused_block_kernel",
-                                                                                "fused_pair_kernel"))
+        pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
 
     backend = os.environ.get("JF_DIST_BACKEND", "nccl")
     torch = dist = None

@@ -109,7 +109,6 @@ struct FusedParams {
     int S, K, B;
     int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
     int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
-    int form;  // G > 1: 1 = fused_pair_kernel (descriptors in the pair-kernel layout), 0 = fused_group_kernel
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
 };
 

@@ -82,8 +82,7 @@ struct jf_engine {
     // block (Audio.cu:101,104)
     std::atomic<int> mode{0};  // 0 = FD_COMPLEX, 1 = FD_BASIC
     std::atomic<int> paused{0};
-    int resident_wgs[3] = {0, 0, 0};  // persistent-grid size of the per-source / group / pair kernel on this device
-    int group_form = 1;               // G > 1: 1 = fused_pair_kernel, 0 = fused_group_kernel (A/B runs)
+    int resident_wgs[2] = {0, 0};  // persistent-grid size of the per-source / the pair kernel on this device
     int grid_limit = 0;            // > 0: tests shrink the grid so that waves loop over several units
     float last_peak = 0.0f;        // max |sample| of the last block handed out (Audio.cu:111-113 clip alert)
 
@@ -226,8 +225,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
                                                          : 1;
     FusedParams P;
     P.G = (e->S % G == 0) ? G : 1;
-    P.form = e->group_form;
-    const int canon = P.G > 1 && P.form == 1;
+    const int canon = P.G > 1;  // descriptors in the pair-kernel layout
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
     JF_HIP(e, launch_prep(ring_table(), kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
@@ -251,7 +249,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     e->last_group = P.G;
     P.mode = kernel_mode(e);
     P.err = e->hd_err;
-    int max_wgs = e->resident_wgs[P.G > 1 ? (P.form == 1 ? 2 : 1) : 0];
+    int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
     if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, max_wgs, e->stream));
@@ -377,8 +375,7 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     auto body = [&]() -> int {
         JF_HIP(e, hipSetDevice(cfg->device));
         JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        for (int kind = 0; kind < 3; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
-        if (const char *f = getenv("JF_GROUP_FORM")) e->group_form = atoi(f) != 0;  // tuning runs only
+        for (int kind = 0; kind < 2; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
@@ -662,7 +659,6 @@ int jf_submit_block(jf_engine *e) {
             P.K = 1;
             P.B = e->B;
             P.G = 1;
-            P.form = 0;
             P.err = e->hd_err;
             P.mode = kernel_mode(e);
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
@@ -1078,7 +1074,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
         }
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
-        else k += std::string(e->last_group > 1 ? (e->group_form ? "fused_pair_kernel<" : "fused_group_kernel<") : "fused_block_kernel<") + nb + ">;mix_kernel";
+        else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb + ">;mix_kernel";
         e->kernels = k;
         return e->kernels.c_str();
     } catch (...) {

@@ -19,7 +19,7 @@
 //   crossfade old/new filter sets in registers                          a10
 //   store the B stereo frames of this source                            a11
 //
-// fused_block_kernel: one stereo block per source (the reference's `intermediate`); fused_group_kernel: the NEW
+// fused_block_kernel: one stereo block per source (the reference's `intermediate`); fused_pair_kernel: BOTH
 // filter sets of G consecutive sources summed as spectra and inverted once; rt_block_kernel: one launch per audio
 // block for the per-block calls.
 //
@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
+#include "jf_packed.h"
 
 namespace jf {
 
@@ -407,10 +408,13 @@ JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, cons
                           const float2 (&xd)[8], int lane, F &&use) {
     const float4 *hp[NT];
     float wt[NT];
+    // row addresses stay scalar (table + row, wave-uniform) with one per-lane byte offset for all rows (see filtered_half)
+    unsigned boff = 16u * (unsigned)lane;
+    asm("" : "+v"(boff));
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        hp[t] = htab + (size_t)rows[t] * 512 + lane;
-        wt[t] = w[t];
+        hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512;
+        wt[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[t])));
     }
     // JF_CHUNK_LOADS row loads (16 B per lane each) in flight per round; the weighted sum is
     // folded into Z right away so that only the loads of one round are live.
@@ -421,7 +425,8 @@ JF_DEV void filtered_bins(const float4 *__restrict__ htab, const int *rows, cons
 #pragma unroll
         for (int q = 0; q < QC; q++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) h[q][t] = hp[t][64 * (qc + q)];
+            for (int t = 0; t < NT; t++)
+                h[q][t] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (qc + q)) + boff);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
             float4 he = make_float4(wt[0] * h[q][0].x, wt[0] * h[q][0].y, wt[0] * h[q][0].z, wt[0] * h[q][0].w);
@@ -488,11 +493,12 @@ JF_DEV void filter_set(int nt, const float4 *__restrict__ htab, const int *rows,
 }
 
 // ------------------------------------------------------------ fused kernel --
+#ifndef JF_BLOCK_D_EARLY
+#define JF_BLOCK_D_EARLY 1  // per-source kernels: distance factors while the window loads are in flight
+#endif
 constexpr bool kSplit = JF_SPLIT_EXCHANGE != 0;
 constexpr int kWaveLds = kSplit ? 576 : 1088;  // float2 per wave: the inverse exchange (8704 B), or with the split
                                                // exchange the forward passes (4608 B)
-// group kernel: 576 of work space (split exchange) + this lane's 8 sums of Z[N-k] + lane 0's mirror slot
-constexpr int kGroupWork = 576, kGroupWaveLds = kGroupWork + 520;
 
 // Front half of one (block b, source s) work item: window gather (Audio.cu:121-139,
 // GPUSoundSource.cu:472-513), write-back of the window and counters at the last block of a call, forward
@@ -500,16 +506,11 @@ constexpr int kGroupWork = 576, kGroupWaveLds = kGroupWork + 520;
 // (lane 0: xd[0] = (X0 D0.re, X512 D512.re)).  D_EARLY: the distance factors are computed while the window
 // loads are in flight (16 more registers live across the FFT).  False if the item is silent (not
 // interpolable: the reference has no defined output there).
-template <int NOUT, bool D_EARLY>
-JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
-                       float2 *buf, const float2 *s_tw, int lane, float2 (&xd)[8]) {
+// First part of the front half: the loads of the window, nothing that waits for them (the caller may put other work
+// between this and item_finish).  count0 / L: the source's play position and (stored) signal length.
+template <int NOUT>
+JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z)[8], int &count0_out, int &L_out) {
     constexpr int B = 64 * NOUT;
-    // ---- descriptor (wave-uniform -> scalar loads)
-    const int n_new = dp->n_new;
-    const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
-    const float inv_frac = dp->inv_frac;
-
-    // ---- window gather
     const SrcSignal sg = P.sigs[s];
     const int count0 = P.st_in[s].count;
     const float *hist = P.hist_in + (size_t)s * kN;
@@ -523,7 +524,6 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
     const int L = sg.length;
     const int qpos = q0 > 0 ? q0 : 0;
     const int base = (int)(((long long)count0 + qpos) % L) - qpos;  // signal index of q = 0 (mod L)
-    float2 z[8];
     // Where the window comes from is wave-uniform.  Usual case: all of it from one stretch of the looped signal --
     // eight loads of a sample pair per lane at scalar base + 8 lane + 512 r, no per-lane index arithmetic.  Else
     // (the first blocks of a call, whose windows reach back into the previous one; a window across the loop point of
@@ -559,6 +559,19 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
             }
         }
     }
+    count0_out = count0;
+    L_out = L;
+}
+
+// Second part: write-back of the window and counters at the last block of a call, forward FFT, distance factor.
+template <int NOUT, bool D_EARLY>
+JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s, float2 *buf,
+                        const float2 *s_tw, int lane, float2 (&z)[8], int count0, int L, float2 (&xd)[8]) {
+    constexpr int B = 64 * NOUT;
+    // ---- descriptor (wave-uniform -> scalar loads)
+    const int n_new = dp->n_new;
+    const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
+    const float inv_frac = dp->inv_frac;
     // ---- distance factor.  The 1/N of the forward transform and the 1/2 of its split pass ride on
     // 1/frac: powers of two, exact
     float2 dq[8];
@@ -601,6 +614,15 @@ JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *po
     return true;
 }
 
+template <int NOUT, bool D_EARLY>
+JF_DEV bool item_front(const FusedParams &P, const ItemDesc *dp, const float *pos_rec, int b, int s,
+                       float2 *buf, const float2 *s_tw, int lane, float2 (&xd)[8]) {
+    float2 z[8];
+    int count0, L;
+    item_gather<NOUT>(P, b, s, lane, z, count0, L);
+    return item_finish<NOUT, D_EARLY>(P, dp, pos_rec, b, s, buf, s_tw, lane, z, count0, L, xd);
+}
+
 // One (block b, source s) work item by one wavefront: everything from the window gather to the
 // crossfaded stereo frames, which are ADDED to acc (B/64 frames per lane: frame i + 16 (NOUT a + j),
 // lane = 4 i + a).  dp: this item's descriptor (global memory in the batch kernel, LDS in the
@@ -613,7 +635,7 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
     const int n_new = dp->n_new;
     const int n_old = dp->n_old;
     float2 xd[8];
-    if (!item_front<NOUT, true>(P, dp, pos_rec, b, s, buf, s_tw, lane, xd)) return;
+    if (!item_front<NOUT, JF_BLOCK_D_EARLY != 0>(P, dp, pos_rec, b, s, buf, s_tw, opaque(lane), xd)) return;
 
     // ---- filter set(s) + inverse + crossfade (GPUSoundSource.cu:351-381)
     float2 res[NOUT];
@@ -622,7 +644,7 @@ JF_DEV void spatialise_item(const FusedParams &P, const ItemDesc *dp, const floa
         const int *rows = set ? dp->rows_new : dp->rows_old;
         const float *w = set ? dp->w_new : dp->w_old;
         float2 mine[NOUT];  // frames i + 16 (NOUT a + j) of the block
-        filter_set<NOUT, kSplit>(set ? n_new : n_old, P.htab, rows, w, xd, mine, buf, s_tw, lane);
+        filter_set<NOUT, kSplit>(set ? n_new : n_old, P.htab, rows, w, xd, mine, buf, s_tw, opaque(lane));
 #pragma unroll
         for (int j = 0; j < NOUT; j++) {
             float2 r1 = mine[j];
@@ -695,116 +717,6 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     }
 }
 
-// The same work with the NEW filter sets of a unit's sources summed as spectra: the inverse transform is
-// linear and the crossfade ramp f = n / (B - 1) is the same for every source, so
-//     sum_s [ old_s (1 - f) + new_s f ]  =  (1 - f) sum_s old_s  +  f IFFT( sum_s Z_new,s ).
-// A unit of G crossfading sources then costs G + 1 inverse transforms instead of 2 G, and a unit in which
-// nothing crossfades exactly one (the inverse is 45 % of a per-source item's instructions).  The sum of
-// Z[k] and Z[N-k] over the sources (32 VGPRs) runs in source order; the old sets stay per source in the
-// time domain -- a second spectral sum would need 32 more registers than a 4-waves-per-SIMD kernel has.
-// A source that does not crossfade inside a unit that does (old_s = new_s) goes through both paths.
-template <int NOUT>
-__global__ JF_FUSED_BOUNDS void fused_group_kernel(const FusedParams P) {
-    __shared__ float2 s_tw[kTwPack];
-    __shared__ float2 s_buf[kWavesPerWg * kGroupWaveLds];
-    const int tid = threadIdx.x;
-    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *buf = s_buf + wave * kGroupWaveLds;  // FFT work space (split exchange)
-    float2 *zm_sum = buf + kGroupWork + lane;    // + 64 q: this lane's sums of Z[N-k]
-    constexpr int B = 64 * NOUT;
-    const int G = P.G, SG = P.S / G;
-    const int n_units = P.K * SG;
-    const int a = lane & 3, i = lane >> 2;
-#if JF_XCD_MAP
-    // workgroups go round-robin over the 8 XCDs (each with its own L2): give one XCD adjacent units
-    const int wg = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-#else
-    const int wg = blockIdx.x;
-#endif
-#pragma unroll 1
-    for (int unit = wg * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
-#if JF_UNIT_ORDER
-        // consecutive waves take consecutive BLOCKS of the same sources: their table rows and windows overlap
-        const int sg = unit / P.K;
-        const int b = unit - sg * P.K;
-        const int s0 = sg * G;
-#else
-        const int b = unit / SG;
-        const int s0 = (unit - b * SG) * G;
-#endif
-        const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
-        bool any_xfade = false;
-        for (int g = 0; g < G; g++) any_xfade = any_xfade || (d0[g].n_old > 0 && d0[g].n_new > 0);
-        // sums over the sources of the new sets' Z[k] (registers) and Z[N-k] (this lane's LDS slots: the
-        // registers are needed elsewhere), and of the old sets' frames
-        float2 zk_sum[16], old_t[NOUT];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            zk_sum[q] = make_float2(0.f, 0.f);
-            zm_sum[64 * q] = make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < NOUT; j++) old_t[j] = make_float2(0.f, 0.f);
-#pragma unroll 1
-        for (int g = 0; g < G; g++) {
-            const ItemDesc *dp = d0 + g;
-            const int item = b * P.S + s0 + g;
-            float2 xd[8];
-            if (!item_front<NOUT, true>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, xd)) continue;
-            filtered_bins_nt(dp->n_new, P.htab, dp->rows_new, dp->w_new, xd, lane, [&](int q, float2 zk, float2 zm) {
-                zk_sum[q] = cadd(zk_sum[q], zk);
-                zm_sum[64 * q] = cadd(zm_sum[64 * q], zm);
-            });
-            if (any_xfade) {
-                // GPUSoundSource.cu:331-381: the old set on the same window and the same D
-                const bool x = dp->n_old > 0;
-                int rows[4];
-                float w[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {  // wave-uniform values, not pointers: scalar selects
-                    rows[t] = x ? dp->rows_old[t] : dp->rows_new[t];
-                    w[t] = x ? dp->w_old[t] : dp->w_new[t];
-                }
-                float2 mine[NOUT];
-                filter_set<NOUT, true>(x ? dp->n_old : dp->n_new, P.htab, rows, w, xd, mine, buf, s_tw, lane);
-#pragma unroll
-                for (int j = 0; j < NOUT; j++) old_t[j] = cadd(old_t[j], mine[j]);
-            }
-        }
-        // inverse of the summed spectrum: the mirror (see mirror8) reads the Z[N-k] sums where they are
-        if (lane == 0) zm_sum[512] = zm_sum[0];
-        JF_WAVE_LDS_SYNC();
-        {
-            const float2 *rd = buf + kGroupWork + (64 - lane);
-#pragma unroll
-            for (int j = 0; j < 8; j++) zk_sum[8 + j] = rd[64 * (7 - j)];
-        }
-        JF_WAVE_LDS_SYNC();
-        float2 fr[NOUT];
-        ifft1024_lastq_wave<NOUT, true>(zk_sum, fr, buf, s_tw, lane);
-        if (any_xfade) {
-#pragma unroll
-            for (int j = 0; j < NOUT; j++) {
-                // kernels.cu:132-137
-                const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
-                const float fn = (float)n_out / ((float)B - 1.0f);
-                fr[j] = make_float2(old_t[j].x * (1.0f - fn) + fr[j].x * fn, old_t[j].y * (1.0f - fn) + fr[j].y * fn);
-            }
-        }
-#if JF_UNIT_ORDER
-        float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
-#else
-        float2 *out = reinterpret_cast<float2 *>(P.partial) + (size_t)unit * B;
-#endif
-#pragma unroll
-        for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
-    }
-}
-
 // ------------------------------------------------------------- pair kernel --
 // The group kernel's work with BOTH filter sets of a unit's sources summed as spectra:
 //     sum_s [ old_s (1 - f) + new_s f ]  =  (1 - f) IFFT( sum_s Z_old,s )  +  f IFFT( sum_s Z_new,s ),
@@ -867,27 +779,31 @@ template <int NT, bool BOTH, class F>
 JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa, const float *wb,
                           const float2 (&xh)[4], bool special, F &&use) {
     const float4 *hp[NT];
-    float a[NT], b[NT];
+    c2 a[NT], b[NT];  // (w, w): a weight as a scalar-register pair feeds both halves of a packed operation
+    unsigned boff = 16u * lofs;  // byte offset of this lane's first bin inside a row
     // opaque to the optimiser here: otherwise it folds table + lane offset into one loop-invariant 64-bit VGPR pointer
     // and adds the row to that, one VGPR pair per row
-    unsigned boff = 16u * lofs;  // byte offset of this lane's first bin inside a row
     asm("" : "+v"(boff));
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // rows and weights are wave-uniform: pin them to scalar registers
         hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512;
-        a[t] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wa[t])));
-        b[t] = BOTH ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wb[t]))) : 0.0f;
+        const float fa = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wa[t])));
+        const float fb = BOTH ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wb[t]))) : 0.0f;
+        a[t] = c2{fa, fa};
+        b[t] = c2{fb, fb};
     }
     constexpr int QC = (JF_CHUNK_LOADS / NT) > 4 ? 4 : (JF_CHUNK_LOADS / NT);
-    auto ztwo = [&](int q, float2 x, float4 he, float2 &zk, float2 &zm) {
-        const float2 yl = cmul(x, make_float2(he.x, he.y));
-        const float2 yr = cmul(x, make_float2(he.z, he.w));
-        zk = make_float2(yl.x - yr.y, yl.y + yr.x);
-        zm = make_float2(yl.x + yr.y, yr.x - yl.y);
+    // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  Y_ear = x * he_ear as two packed
+    // instructions each; Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R one packed add each.
+    auto ztwo = [&](int q, float2 x, c2 heL, c2 heR, c2 &zk, c2 &zm) {
+        const c2 xc = c2_of(x);
+        const c2 yl = pcmul(xc, heL), yr = pcmul(xc, heR);
+        zk = padd_i(yl, yr);
+        zm = pcadd_ic(yl, yr);
         if (q == 0) {  // lane 0 of the lower half: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
-            const float2 z0 = make_float2(x.x * he.x, x.x * he.z);
-            const float2 z512 = make_float2(x.y * he.y, x.y * he.w);
+            const c2 z0 = c2{x.x * heL.x, x.x * heR.x};
+            const c2 z512 = c2{x.y * heL.y, x.y * heR.y};
             zk = special ? z0 : zk;
             zm = special ? z512 : zm;
         }
@@ -902,24 +818,24 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
                 h[q][t] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (qc + q)) + boff);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
-            float4 ha = make_float4(a[0] * h[q][0].x, a[0] * h[q][0].y, a[0] * h[q][0].z, a[0] * h[q][0].w);
-            float4 hb = make_float4(b[0] * h[q][0].x, b[0] * h[q][0].y, b[0] * h[q][0].z, b[0] * h[q][0].w);
+            c2 haL = pmul_s(c2{h[q][0].x, h[q][0].y}, a[0]), haR = pmul_s(c2{h[q][0].z, h[q][0].w}, a[0]);
+            c2 hbL = c2{0.f, 0.f}, hbR = c2{0.f, 0.f};
+            if (BOTH) {
+                hbL = pmul_s(c2{h[q][0].x, h[q][0].y}, b[0]);
+                hbR = pmul_s(c2{h[q][0].z, h[q][0].w}, b[0]);
+            }
 #pragma unroll
             for (int t = 1; t < NT; t++) {
-                ha.x += a[t] * h[q][t].x;
-                ha.y += a[t] * h[q][t].y;
-                ha.z += a[t] * h[q][t].z;
-                ha.w += a[t] * h[q][t].w;
+                haL = pfma_s(c2{h[q][t].x, h[q][t].y}, a[t], haL);
+                haR = pfma_s(c2{h[q][t].z, h[q][t].w}, a[t], haR);
                 if (BOTH) {
-                    hb.x += b[t] * h[q][t].x;
-                    hb.y += b[t] * h[q][t].y;
-                    hb.z += b[t] * h[q][t].z;
-                    hb.w += b[t] * h[q][t].w;
+                    hbL = pfma_s(c2{h[q][t].x, h[q][t].y}, b[t], hbL);
+                    hbR = pfma_s(c2{h[q][t].z, h[q][t].w}, b[t], hbR);
                 }
             }
-            float2 zka, zma, zkb = make_float2(0.f, 0.f), zmb = make_float2(0.f, 0.f);
-            ztwo(qc + q, xh[qc + q], ha, zka, zma);
-            if (BOTH) ztwo(qc + q, xh[qc + q], hb, zkb, zmb);
+            c2 zka, zma, zkb = c2{0.f, 0.f}, zmb = c2{0.f, 0.f};
+            ztwo(qc + q, xh[qc + q], haL, haR, zka, zma);
+            if (BOTH) ztwo(qc + q, xh[qc + q], hbL, hbR, zkb, zmb);
             use(qc + q, zka, zma, zkb, zmb);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -939,6 +855,10 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
 
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
+#endif
+#ifndef JF_PAIR_OVERLAP
+#define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
+                           // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
 #endif
 
 template <int NOUT>
@@ -1008,40 +928,40 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         for (int g = 0; g < G; g++) any_xfade = any_xfade || ((d0[g].flags & 2) != 0 && d0[g].n_new > 0);
         mail_free(npub);  // the last unit's final hand-offs used both slots
         // sums over the unit's sources of Z[k] and Z[N-k], k = lane + 64 (qb + q), old and new sets
-        float2 zko[4], zkn[4], zmo[4], zmn[4];
+        c2 zko[4], zkn[4], zmo[4], zmn[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = make_float2(0.f, 0.f);
+        for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = c2{0.f, 0.f};
         auto accumulate = [&](const ItemDesc *dp, const float2 (&xh)[4]) {
 #ifdef JF_EXP_NOFILTER  // timing experiment (wrong results): fronts and hand-offs only
-            zkn[0] = cadd(zkn[0], xh[0]);
+            zkn[0] += c2_of(xh[0]);
             return;
 #endif
             const int nn = dp->n_new;
             if (!any_xfade) {
                 filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
-                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
-                                            zkn[q] = cadd(zkn[q], zk);
-                                            zmn[q] = cadd(zmn[q], zmv);
+                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
+                                            zkn[q] += zk;
+                                            zmn[q] += zmv;
                                         });
             } else if (dp->flags & 1) {
                 // both sets read the same rows (prep_kernel laid them out so): one round of loads
                 filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, xh, special,
-                                       [&](int q, float2 zka, float2 zma, float2 zkb, float2 zmb) {
-                                           zko[q] = cadd(zko[q], zka);
-                                           zmo[q] = cadd(zmo[q], zma);
-                                           zkn[q] = cadd(zkn[q], zkb);
-                                           zmn[q] = cadd(zmn[q], zmb);
+                                       [&](int q, c2 zka, c2 zma, c2 zkb, c2 zmb) {
+                                           zko[q] += zka;
+                                           zmo[q] += zma;
+                                           zkn[q] += zkb;
+                                           zmn[q] += zmb;
                                        });
             } else {
                 filtered_half_nt<false>(dp->n_old, P.htab, lofs, dp->rows_old, dp->w_old, dp->w_old, xh, special,
-                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
-                                            zko[q] = cadd(zko[q], zk);
-                                            zmo[q] = cadd(zmo[q], zmv);
+                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
+                                            zko[q] += zk;
+                                            zmo[q] += zmv;
                                         });
                 filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
-                                        [&](int q, float2 zk, float2 zmv, float2, float2) {
-                                            zkn[q] = cadd(zkn[q], zk);
-                                            zmn[q] = cadd(zmn[q], zmv);
+                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
+                                            zkn[q] += zk;
+                                            zmn[q] += zmv;
                                         });
             }
         };
@@ -1062,8 +982,17 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             const int g = 2 * j + half;
             const ItemDesc *dp = d0 + g;
             const int item = b * P.S + s0 + g;
+            // the loads of my source's window first; the partner's previous source is filtered while they are in
+            // flight (his hand-off has been waiting for a whole source), then my source's transform and filter
+            float2 z[8];
+            int count0, L;
+            item_gather<NOUT>(P, b, s0 + g, opaque(lane), z, count0, L);
+#if JF_PAIR_OVERLAP
+            if (jp < j && jp < n_his) take_partner_source(jp++);
+#endif
             float2 xd[8];
-            if (item_front<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, opaque(lane), xd)) {
+            if (item_finish<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, opaque(lane), z,
+                                                        count0, L, xd)) {
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
                 float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
@@ -1075,8 +1004,9 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                 publish();
                 accumulate(dp, xh);
             }
-            // the partner's sources one step late: his hand-off has been waiting for a whole source
+#if !JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
+#endif
         }
 #pragma unroll 1
         for (; jp < n_his; jp++) take_partner_source(jp);
@@ -1088,13 +1018,13 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             mail_free(npub);  // both slots: Z[k] in the first, Z[N-k] in the second
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                mail[64 * q + lane] = half == 0 ? zkn[q] : zko[q];
-                mail[kPairMail + 64 * q + lane] = half == 0 ? zmn[q] : zmo[q];
+                mail[64 * q + lane] = f2_of(half == 0 ? zkn[q] : zko[q]);
+                mail[kPairMail + 64 * q + lane] = f2_of(half == 0 ? zmn[q] : zmo[q]);
             }
         }
         if (take) {  // my own Z[N-k] go through LDS as well: the inverse needs them from lane 64 - lane
 #pragma unroll
-            for (int q = 0; q < 4; q++) buf[64 * q + lane] = half == 0 ? zmo[q] : zmn[q];
+            for (int q = 0; q < 4; q++) buf[64 * q + lane] = f2_of(half == 0 ? zmo[q] : zmn[q]);
         }
         if (give) publish();
         float2 fr[NOUT];
@@ -1104,7 +1034,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const float2 theirs = pmail[64 * q + lane];
-                const float2 own = half == 0 ? zko[q] : zkn[q];
+                const float2 own = f2_of(half == 0 ? zko[q] : zkn[q]);
                 v[q] = half == 0 ? own : theirs;
                 v[4 + q] = half == 0 ? theirs : own;
             }
@@ -1573,11 +1503,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
 #pragma unroll 1
     for (int s = blockIdx.x * kRtWaves + wave; s < P.S; s += gridDim.x * kRtWaves) {
         const float *p = pos + 5 * s;
-        if (lane == 0) {
-            ItemDesc d;
-            make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, d);
-            s_desc[wave] = d;
-        }
+        if (lane == 0) make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, s_desc[wave]);
         JF_WAVE_LDS_SYNC();
         spatialise_item<NOUT>(P, &s_desc[wave], p, 0, s, buf, s_tw, lane, acc);
         JF_WAVE_LDS_SYNC();
@@ -1669,11 +1595,7 @@ __global__ __launch_bounds__(64) void stage_debug_kernel(const RingTable rt, int
     const int lane = threadIdx.x;
     for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
     const float *p = pos + 5 * (size_t)blockIdx.x;
-    if (lane == 0) {
-        ItemDesc d;
-        make_desc(rt, mode, p, p[0], p[1], d);  // old == new: no crossfade
-        s_desc = d;
-    }
+    if (lane == 0) make_desc(rt, mode, p, p[0], p[1], s_desc);  // old == new: no crossfade
     __syncthreads();
     const ItemDesc *dp = &s_desc;
     const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
@@ -1751,30 +1673,21 @@ hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const 
 }
 
 // Resident workgroups of the fused kernel that a call with these parameters launches (per-source kernel for
-// G = 1, group kernel otherwise), on the CURRENT device: CUs x workgroups per CU for this build's LDS and register
+// G = 1, pair kernel otherwise), on the CURRENT device: CUs x workgroups per CU for this build's LDS and register
 // footprint.  The engine asks once per (kernel, block size) at creation and keeps the answer with its device.
-hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source, 1 group, 2 pair kernel */, int *out) {
-    const bool group = kind == 1;
+hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source kernel, 1 pair kernel */, int *out) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     hipError_t q = hipGetDevice(&dev);
     if (q == hipSuccess) q = hipGetDeviceProperties(&prop, dev);
     if (q != hipSuccess) return q;
     const int threads = 64 * kWavesPerWg;
-    if (kind == 2) {
+    if (kind == 1) {
         switch (nb) {
         case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1>, threads, 0); break;
         case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2>, threads, 0); break;
         case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<3>, threads, 0); break;
         case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<4>, threads, 0); break;
-        default: return hipErrorInvalidValue;
-        }
-    } else if (group) {
-        switch (nb) {
-        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<1>, threads, 0); break;
-        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<2>, threads, 0); break;
-        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<3>, threads, 0); break;
-        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_group_kernel<4>, threads, 0); break;
         default: return hipErrorInvalidValue;
         }
     } else {
@@ -1800,28 +1713,18 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
     const int n_items = P.K * (P.S / P.G);
     const int nb = P.B / 64;
     if (nb < 1 || nb > 4) return hipErrorInvalidValue;
-    const int per_wg = (P.G > 1 && P.form == 1) ? kPairsPerWg : kWavesPerWg;  // units a workgroup works on at a time
+    const int per_wg = P.G > 1 ? kPairsPerWg : kWavesPerWg;  // units a workgroup works on at a time
     int wgs = (n_items + per_wg - 1) / per_wg;
     if (wgs > max_wgs) wgs = max_wgs;
     const dim3 grid(wgs), block(64 * kWavesPerWg);
-    // groups of sources are summed as spectra (one pair of inverse transforms per group); single sources
+    // groups of sources are summed as spectra by wave pairs (two inverse transforms per group); single sources
     // keep the per-source kernel, whose blocks are the reference's per-source `intermediate`
-    if (P.G > 1 && P.form == 1) {
+    if (P.G > 1) {
         switch (P.B / 64) {
         case 1: hipLaunchKernelGGL(fused_pair_kernel<1>, grid, block, 0, st, P); break;
         case 2: hipLaunchKernelGGL(fused_pair_kernel<2>, grid, block, 0, st, P); break;
         case 3: hipLaunchKernelGGL(fused_pair_kernel<3>, grid, block, 0, st, P); break;
         case 4: hipLaunchKernelGGL(fused_pair_kernel<4>, grid, block, 0, st, P); break;
-        default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
-    if (P.G > 1) {
-        switch (P.B / 64) {
-        case 1: hipLaunchKernelGGL(fused_group_kernel<1>, grid, block, 0, st, P); break;
-        case 2: hipLaunchKernelGGL(fused_group_kernel<2>, grid, block, 0, st, P); break;
-        case 3: hipLaunchKernelGGL(fused_group_kernel<3>, grid, block, 0, st, P); break;
-        case 4: hipLaunchKernelGGL(fused_group_kernel<4>, grid, block, 0, st, P); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -56,6 +56,17 @@ JF_PK2(pmul_bhi, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]")                   // a 
 JF_PK3(pfma_blo, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]")          // acc + a * b.lo
 JF_PK3(pfma_bhi, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]")             // acc + a * b.hi
 
+// ---- a pair times / plus-times a wave-uniform scalar held as a scalar-register pair (w, w)
+JF_DEV c2 pmul_s(c2 a, c2 w) {
+    c2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(w));
+    return r;
+}
+JF_DEV c2 pfma_s(c2 a, c2 w, c2 acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(w));
+    return acc;
+}
+
 // ---- complex products: first a packed multiply by a.re, then a packed FMA by a.im
 // a * w
 JF_DEV c2 pcmul(c2 a, c2 w) {

@@ -1,7 +1,7 @@
 """The configurations BASELINE.json quotes, at their own sizes, against the oracle on a real MI355X:
 
 * configs[2] in the exact shape bench.py times (1024 moving sources x 64 blocks per launch, automatic source
-  grouping = fused_group_kernel<4> with G = 16), the whole mix against the float32 C oracle and sampled source
+  grouping = fused_pair_kernel<4> with G = 16), the whole mix against the float32 C oracle and sampled source
   groups against the float64 model;
 * the group kernel with more work units than resident wavefronts (every wave loops);
 * configs[4]'s own multiply-accumulate kernel (block tiles, 690 partitions of 128) against a float64 convolution;
@@ -66,7 +66,7 @@ def test_bench_shape_against_the_oracle(jf, hrir):
         e.batch_run(c * K, K)
         e.synchronize()
         G = e.last_source_group()
-        assert G == 16, "bench.py's shape must take fused_group_kernel with G = 16"
+        assert G == 16, "bench.py's shape must take fused_pair_kernel with G = 16"
         parts.append(e.read_device(e.partial_device_ptr(), (K, S // G, 2 * B)))
         mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
     e.close()

@@ -178,7 +178,7 @@ def test_invalid_batch_positions_are_silence_not_faults(jf, hrir, castanets):
 
 @pytest.mark.parametrize("B,G", [(64, 4), (128, 8), (192, 2), (256, 8), (256, 16)])
 def test_group_kernel_mixed_units(jf, hrir, castanets, B, G):
-    """fused_group_kernel on units that mix everything: sources that crossfade, sources that do not (inside a
+    """fused_pair_kernel on units that mix everything: sources that crossfade, sources that do not (inside a
     unit that does, and in units where nothing moves), silent sources (position not interpolable), ragged
     signal lengths, the FD_BASIC mode, carried state across two calls -- against the per-source kernel
     (G = 1) and the float32 oracle."""
@@ -297,7 +297,7 @@ def test_full_size_moving_workload_properties(jf, hrir):
     assert np.array_equal(half, (0.5 * mix).astype(np.float32))
 
     # (4) the default grouping: G = 4 or 8 consecutive sources per wavefront, their NEW filter sets summed as
-    # spectra and inverted once (fused_group_kernel; the inverse transform is linear and the crossfade ramp
+    # spectra and inverted once (fused_pair_kernel; the inverse transform is linear and the crossfade ramp
     # is common to all sources).  Same sum, other roundings: the per-group blocks against the sums of the
     # per-source blocks, and the mix against the per-source mix.
     for G in (4, 8):
