@@ -1,0 +1,172 @@
+/* jf_ctest.c -- plain-C checks of the boundary, linked only against the C ABI (jefferson.h, jefferson_group.h).
+ *
+ *   jf_ctest pa      drives jf_pa_callback with PortAudio's argument list (paCallback, Audio.cu:164-175) for 200
+ *                    blocks -- positions changed and the stream paused/resumed from the "UI side" in between -- and
+ *                    compares every block with jf_callback on a twin engine fed the same calls
+ *   jf_ctest group N one job over N GPUs (jefferson_group.h: one engine per GPU, RCCL reduce of the mixes) against
+ *                    one engine holding all sources: per-block calls (host sum) and batch calls (ncclReduce)
+ *
+ * Synthetic HRIRs and signals (no files).  Exit code 0 = all comparisons hold; prints one line per check.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/jefferson.h"
+#include "../../include/jefferson_group.h"
+
+static unsigned long long rng_state = 88172645463325252ULL;
+static float frand(void) { /* xorshift64*, uniform in [-0.5, 0.5) */
+    rng_state ^= rng_state >> 12;
+    rng_state ^= rng_state << 25;
+    rng_state ^= rng_state >> 27;
+    return (float)((rng_state * 2685821657736338717ULL) >> 40) / 16777216.0f - 0.5f;
+}
+
+static float *make_hrir(int taps) {
+    float *h = (float *)malloc(sizeof(float) * JF_NUM_HRTF * 2 * (size_t)taps);
+    for (int j = 0; j < JF_NUM_HRTF * 2; j++)
+        for (int n = 0; n < taps; n++) h[(size_t)j * taps + n] = 0.3f * frand() * expf(-(float)n / 24.0f);
+    return h;
+}
+
+static float *make_signal(size_t n) {
+    float *s = (float *)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; i++) s[i] = frand();
+    return s;
+}
+
+static double max_abs_diff(const float *a, const float *b, size_t n, double *peak) {
+    double d = 0, p = 0;
+    for (size_t i = 0; i < n; i++) {
+        const double e = fabs((double)a[i] - (double)b[i]);
+        if (e > d) d = e;
+        if (fabs((double)b[i]) > p) p = fabs((double)b[i]);
+    }
+    if (peak) *peak = p;
+    return d;
+}
+
+#define CHECK(call)                                                                       \
+    do {                                                                                  \
+        int rc_ = (call);                                                                 \
+        if (rc_ != JF_OK) {                                                               \
+            fprintf(stderr, "%s -> %d (%s / %s)\n", #call, rc_, jf_last_error(NULL), jf_group_last_error(NULL)); \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+static int test_pa(void) {
+    enum { B = 256, S = 3, BLOCKS = 200, TAPS = 128 };
+    float *hrir = make_hrir(TAPS);
+    jf_config cfg = {B, 512, S, 0, 1, 0};
+    jf_engine *pa = NULL, *ref = NULL;
+    CHECK(jf_engine_create(&cfg, hrir, TAPS, &pa));
+    CHECK(jf_engine_create(&cfg, hrir, TAPS, &ref));
+    for (int s = 0; s < S; s++) {
+        float *sig = make_signal(30000 + 777 * (size_t)s);
+        CHECK(jf_source_set_signal(pa, s, sig, 30000 + 777 * (size_t)s));
+        CHECK(jf_source_set_signal(ref, s, sig, 30000 + 777 * (size_t)s));
+        free(sig);
+    }
+    float out_pa[2 * B], out_ref[2 * B];
+    double worst = 0, peak = 0, pk = 0;
+    int silent_blocks = 0;
+    for (int k = 0; k < BLOCKS; k++) {
+        /* the UI side: positions every 7th block, pause for blocks 50..59 (Data::pauseStatus, Audio.cu:101) */
+        if (k % 7 == 0)
+            for (int s = 0; s < S; s++) {
+                const float azi = (float)((37 * s + 5 * k) % 360), ele = (float)(-20 + 10 * s);
+                CHECK(jf_source_set_spherical(pa, s, ele, azi, 0.5f + 0.2f * s));
+                CHECK(jf_source_set_spherical(ref, s, ele, azi, 0.5f + 0.2f * s));
+            }
+        if (k == 50 || k == 60) {
+            CHECK(jf_set_pause(pa, k == 50));
+            CHECK(jf_set_pause(ref, k == 50));
+        }
+        memset(out_pa, 0x7f, sizeof(out_pa)); /* must be fully overwritten */
+        /* PortAudio's call: (input, output, framesPerBuffer, timeInfo, statusFlags, userData) */
+        if (jf_pa_callback(NULL, out_pa, B, NULL, 0, pa) != 0) {
+            fprintf(stderr, "jf_pa_callback did not return paContinue\n");
+            return 1;
+        }
+        CHECK(jf_callback(ref, out_ref));
+        const double d = max_abs_diff(out_pa, out_ref, 2 * B, &pk);
+        if (d > worst) worst = d;
+        if (pk > peak) peak = pk;
+        if (pk == 0) silent_blocks++;
+        if (fabs((double)jf_last_block_peak(pa) - pk) > 0) {
+            fprintf(stderr, "jf_last_block_peak %g != %g at block %d\n", jf_last_block_peak(pa), pk, k);
+            return 1;
+        }
+    }
+    /* a stream opened with another buffer size gets silence, not garbage */
+    memset(out_pa, 0x7f, sizeof(out_pa));
+    (void)jf_pa_callback(NULL, out_pa, B / 2, NULL, 0, pa);
+    int bad = 0;
+    for (int i = 0; i < B; i++) bad += out_pa[i] != 0.0f;
+    printf("pa: %d blocks, max |jf_pa_callback - jf_callback| = %g, peak %g, %d silent blocks (1 primed + 10 paused), "
+           "wrong-size call -> %s\n", BLOCKS, worst, peak, silent_blocks, bad ? "GARBAGE" : "silence");
+    jf_engine_destroy(pa);
+    jf_engine_destroy(ref);
+    free(hrir);
+    return (worst == 0 && peak > 0.01 && silent_blocks == 11 && !bad) ? 0 : 1;
+}
+
+static int test_group(int n_gpus) {
+    enum { B = 128, S = 40, K = 6, RUNS = 3, TAPS = 128 };
+    float *hrir = make_hrir(TAPS);
+    jf_config cfg = {B, 512, S, 0, K, 0};
+    jf_engine *one = NULL;
+    jf_group *grp = NULL;
+    CHECK(jf_engine_create(&cfg, hrir, TAPS, &one));
+    CHECK(jf_group_create(&cfg, n_gpus, NULL, hrir, TAPS, &grp));
+    for (int s = 0; s < S; s++) {
+        const size_t n = 9000 + 131 * (size_t)s;
+        float *sig = make_signal(n);
+        CHECK(jf_source_set_signal(one, s, sig, n));
+        CHECK(jf_group_source_set_signal(grp, s, sig, n));
+        free(sig);
+    }
+    float *pos = (float *)malloc(sizeof(float) * JF_POS_FLOATS * S * K * RUNS);
+    for (int k = 0; k < K * RUNS; k++)
+        for (int s = 0; s < S; s++)
+            CHECK(jf_position_from_spherical((float)(-40 + (7 * s) % 121), (float)((37 * s + k) % 360), 0.5f + 0.05f * s,
+                                             pos + ((size_t)k * S + s) * JF_POS_FLOATS));
+    float *a = (float *)malloc(sizeof(float) * 2 * B * K * RUNS), *b = (float *)malloc(sizeof(float) * 2 * B * K * RUNS);
+    CHECK(jf_process_batch(one, K * RUNS, pos, a));
+    CHECK(jf_group_process_batch(grp, K * RUNS, pos, b));
+    double peak = 0;
+    const double d_batch = max_abs_diff(b, a, (size_t)2 * B * K * RUNS, &peak);
+    /* per-block calls on top of the carried state */
+    double d_block = 0;
+    for (int k = 0; k < 4; k++) {
+        for (int s = 0; s < S; s++) {
+            CHECK(jf_source_set_spherical(one, s, 10.0f, (float)((20 * s + 9 * k) % 360), 1.0f));
+            CHECK(jf_group_source_set_spherical(grp, s, 10.0f, (float)((20 * s + 9 * k) % 360), 1.0f));
+        }
+        CHECK(jf_process_block(one, a));
+        CHECK(jf_group_process_block(grp, b));
+        const double d = max_abs_diff(b, a, 2 * B, NULL);
+        if (d > d_block) d_block = d;
+    }
+    /* one GPU: the same sums in the same order -> identical; several: one more association of float32 adds */
+    const double tol = n_gpus == 1 ? 0.0 : 4e-7 * S;
+    printf("group: %d GPU(s), %d sources: batch max diff %g, per-block max diff %g (tolerance %g), peak %g\n",
+           jf_group_num_gpus(grp), S, d_batch, d_block, tol, peak);
+    jf_group_destroy(grp);
+    jf_engine_destroy(one);
+    free(pos);
+    free(a);
+    free(b);
+    free(hrir);
+    return (d_batch <= tol && d_block <= tol && peak > 0.05) ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "pa")) return test_pa();
+    if (argc >= 2 && !strcmp(argv[1], "group")) return test_group(argc >= 3 ? atoi(argv[2]) : 1);
+    fprintf(stderr, "usage: jf_ctest pa | group [n_gpus]\n");
+    return 64;
+}

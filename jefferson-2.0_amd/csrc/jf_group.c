@@ -1,0 +1,265 @@
+/* jf_group.c -- include/jefferson_group.h: one job over the GPUs of a node from a single C host process.
+ * Plain C over the C ABI of jefferson.h, the HIP runtime API and RCCL.  One jf_engine per GPU, sources in contiguous
+ * shards, no data-path collective; the only exchange is the sum of the per-GPU stereo mixes (Audio.cu:109-110). */
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/jefferson_group.h"
+
+struct jf_group {
+    int n;         /* GPUs */
+    int S, B, maxK;
+    int *dev;      /* [n] HIP device ordinals */
+    int *lo;       /* [n + 1] first global source of each shard */
+    jf_engine **eng;
+    ncclComm_t *comm;
+    float **d_red; /* [n] device buffers [maxK][2B]: each engine's mix, reduced in place into d_red[0] */
+    float *blk;    /* [2B] host scratch of jf_group_process_block */
+    int traj_blocks;
+    int run_blocks; /* > 0: a batch run is in flight (not yet fetched) */
+    char err[256];
+};
+
+static _Thread_local char g_create_err[256];
+
+static int fail(jf_group *g, int code, const char *what, const char *detail) {
+    char *dst = g ? g->err : g_create_err;
+    snprintf(dst, 256, "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+    return code;
+}
+
+#define JG_HIP(g, call)                                                              \
+    do {                                                                             \
+        hipError_t s_ = (call);                                                      \
+        if (s_ != hipSuccess) return fail((g), JF_ERR_DEVICE, #call, hipGetErrorString(s_)); \
+    } while (0)
+#define JG_NCCL(g, call)                                                              \
+    do {                                                                              \
+        ncclResult_t s_ = (call);                                                     \
+        if (s_ != ncclSuccess) return fail((g), JF_ERR_DEVICE, #call, ncclGetErrorString(s_)); \
+    } while (0)
+#define JG_ENG(g, i, call)                                                       \
+    do {                                                                         \
+        int rc_ = (call);                                                        \
+        if (rc_ != JF_OK) return fail((g), rc_, #call, jf_last_error((g)->eng[i])); \
+    } while (0)
+
+int jf_shard_range(int n_total, int n_parts, int part, int *lo, int *hi) {
+    if (n_total < 0 || n_parts < 1 || part < 0 || part >= n_parts || !lo || !hi) return JF_ERR_ARG;
+    const int base = n_total / n_parts, rem = n_total % n_parts;
+    *lo = part * base + (part < rem ? part : rem);
+    *hi = *lo + base + (part < rem ? 1 : 0);
+    return JF_OK;
+}
+
+/* shard that holds global source `src` */
+static int shard_of(const jf_group *g, int src) {
+    for (int i = 0; i < g->n; i++)
+        if (src >= g->lo[i] && src < g->lo[i + 1]) return i;
+    return -1;
+}
+
+void jf_group_destroy(jf_group *g) {
+    if (!g) return;
+    for (int i = 0; i < g->n; i++) {
+        if (g->eng && g->eng[i]) (void)jf_synchronize(g->eng[i]);
+        if (g->comm && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+        if (g->d_red && g->d_red[i]) {
+            (void)hipSetDevice(g->dev[i]);
+            (void)hipFree(g->d_red[i]);
+        }
+        if (g->eng && g->eng[i]) jf_engine_destroy(g->eng[i]);
+    }
+    free(g->dev);
+    free(g->lo);
+    free(g->eng);
+    free(g->comm);
+    free(g->d_red);
+    free(g->blk);
+    free(g);
+}
+
+int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out) {
+    if (!cfg || !hrir || !out) return fail(NULL, JF_ERR_ARG, "null argument", NULL);
+    *out = NULL;
+    if (n_gpus < 1 || n_gpus > cfg->n_sources) return fail(NULL, JF_ERR_ARG, "need 1 <= n_gpus <= n_sources", NULL);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NULL, JF_ERR_DEVICE, "no HIP device available (this library has no CPU path)", NULL);
+    jf_group *g = (jf_group *)calloc(1, sizeof(*g));
+    if (!g) return fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
+    g->n = n_gpus;
+    g->S = cfg->n_sources;
+    g->B = cfg->frames_per_buffer;
+    g->maxK = cfg->max_batch_blocks;
+    g->dev = (int *)calloc(n_gpus, sizeof(int));
+    g->lo = (int *)calloc(n_gpus + 1, sizeof(int));
+    g->eng = (jf_engine **)calloc(n_gpus, sizeof(*g->eng));
+    g->comm = (ncclComm_t *)calloc(n_gpus, sizeof(*g->comm));
+    g->d_red = (float **)calloc(n_gpus, sizeof(*g->d_red));
+    g->blk = (float *)calloc(2 * (size_t)(g->B > 0 ? g->B : 1), sizeof(float));
+    int rc = JF_OK;
+    if (!g->dev || !g->lo || !g->eng || !g->comm || !g->d_red || !g->blk) rc = fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
+    for (int i = 0; rc == JF_OK && i < n_gpus; i++) {
+        g->dev[i] = devices ? devices[i] : i;
+        if (g->dev[i] < 0 || g->dev[i] >= ndev) rc = fail(NULL, JF_ERR_ARG, "device ordinal out of range", NULL);
+        for (int k = 0; rc == JF_OK && k < i; k++)
+            if (g->dev[k] == g->dev[i]) rc = fail(NULL, JF_ERR_ARG, "a device is listed twice (RCCL needs distinct devices)", NULL);
+    }
+    for (int i = 0; rc == JF_OK && i < n_gpus; i++) {
+        int lo, hi;
+        jf_shard_range(g->S, n_gpus, i, &lo, &hi);
+        g->lo[i] = lo;
+        g->lo[i + 1] = hi;
+        jf_config c = *cfg;
+        c.n_sources = hi - lo;
+        c.device = g->dev[i];
+        rc = jf_engine_create(&c, hrir, taps, &g->eng[i]);
+        if (rc != JF_OK) {
+            fail(NULL, rc, "jf_engine_create", jf_last_error(NULL));
+            break;
+        }
+        if (hipSetDevice(g->dev[i]) != hipSuccess ||
+            hipMalloc((void **)&g->d_red[i], sizeof(float) * 2 * (size_t)g->B * (size_t)g->maxK) != hipSuccess)
+            rc = fail(NULL, JF_ERR_DEVICE, "hipMalloc of the reduce buffer failed", NULL);
+    }
+    if (rc == JF_OK) {
+        ncclResult_t s = ncclCommInitAll(g->comm, n_gpus, g->dev);
+        if (s != ncclSuccess) rc = fail(NULL, JF_ERR_DEVICE, "ncclCommInitAll", ncclGetErrorString(s));
+    }
+    if (rc != JF_OK) {
+        jf_group_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return JF_OK;
+}
+
+const char *jf_group_last_error(const jf_group *g) { return g ? g->err : g_create_err; }
+int jf_group_num_gpus(const jf_group *g) { return g ? g->n : JF_ERR_ARG; }
+int jf_group_num_sources(const jf_group *g) { return g ? g->S : JF_ERR_ARG; }
+jf_engine *jf_group_engine(jf_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->eng[i] : NULL; }
+int jf_group_first_source(const jf_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->lo[i] : JF_ERR_ARG; }
+
+int jf_group_source_set_signal(jf_group *g, int src, const float *mono, size_t n) {
+    const int i = g ? shard_of(g, src) : -1;
+    if (i < 0) return fail(g, JF_ERR_ARG, "bad source index", NULL);
+    JG_ENG(g, i, jf_source_set_signal(g->eng[i], src - g->lo[i], mono, n));
+    return JF_OK;
+}
+
+int jf_group_source_set_spherical(jf_group *g, int src, float ele, float azi, float r) {
+    const int i = g ? shard_of(g, src) : -1;
+    if (i < 0) return fail(g, JF_ERR_ARG, "bad source index", NULL);
+    JG_ENG(g, i, jf_source_set_spherical(g->eng[i], src - g->lo[i], ele, azi, r));
+    return JF_OK;
+}
+
+int jf_group_source_set_cartesian(jf_group *g, int src, float x, float y, float z) {
+    const int i = g ? shard_of(g, src) : -1;
+    if (i < 0) return fail(g, JF_ERR_ARG, "bad source index", NULL);
+    JG_ENG(g, i, jf_source_set_cartesian(g->eng[i], src - g->lo[i], x, y, z));
+    return JF_OK;
+}
+
+int jf_group_process_block(jf_group *g, float *out) {
+    if (!g || !out) return fail(g, JF_ERR_ARG, "null argument", NULL);
+    if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    /* every GPU gets its block before any is waited for */
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_submit_block(g->eng[i]));
+    memset(out, 0, sizeof(float) * 2 * (size_t)g->B);
+    for (int i = 0; i < g->n; i++) {
+        JG_ENG(g, i, jf_collect_block(g->eng[i], i == 0 ? out : g->blk));
+        if (i > 0)
+            for (int k = 0; k < 2 * g->B; k++) out[k] += g->blk[k]; /* Audio.cu:109-110, shard by shard */
+    }
+    return JF_OK;
+}
+
+int jf_group_batch_upload_positions(jf_group *g, int total_blocks, const float *positions) {
+    if (!g || total_blocks <= 0 || !positions) return fail(g, JF_ERR_ARG, "bad trajectory", NULL);
+    if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    if (g->n == 1) { /* the whole trajectory as it stands */
+        JG_ENG(g, 0, jf_batch_upload_positions(g->eng[0], total_blocks, positions));
+        g->traj_blocks = total_blocks;
+        return JF_OK;
+    }
+    for (int i = 0; i < g->n; i++) {
+        const size_t ns = (size_t)(g->lo[i + 1] - g->lo[i]);
+        float *p = (float *)malloc(sizeof(float) * JF_POS_FLOATS * ns * (size_t)total_blocks);
+        if (!p) return fail(g, JF_ERR_NOMEM, "out of host memory", NULL);
+        for (int b = 0; b < total_blocks; b++)
+            memcpy(p + (size_t)b * ns * JF_POS_FLOATS, positions + ((size_t)b * g->S + g->lo[i]) * JF_POS_FLOATS,
+                   sizeof(float) * JF_POS_FLOATS * ns);
+        const int rc = jf_batch_upload_positions(g->eng[i], total_blocks, p);
+        free(p);
+        if (rc != JF_OK) return fail(g, rc, "jf_batch_upload_positions", jf_last_error(g->eng[i]));
+    }
+    g->traj_blocks = total_blocks;
+    return JF_OK;
+}
+
+int jf_group_batch_run(jf_group *g, int first_block, int n_blocks) {
+    if (!g) return JF_ERR_ARG;
+    if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    if (n_blocks <= 0 || n_blocks > g->maxK) return fail(g, JF_ERR_ARG, "n_blocks exceeds max_batch_blocks", NULL);
+    if (first_block < 0 || first_block + n_blocks > g->traj_blocks)
+        return fail(g, JF_ERR_ARG, "window outside the uploaded trajectory", NULL);
+    /* every engine's kernels, each on its own stream, its mix into its reduce buffer */
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_batch_run(g->eng[i], first_block, n_blocks, g->d_red[i]));
+    /* the one exchange of the path: sum of the mixes to the first GPU, behind the kernels on the same streams */
+    const size_t count = (size_t)n_blocks * 2 * (size_t)g->B;
+    JG_NCCL(g, ncclGroupStart());
+    for (int i = 0; i < g->n; i++) {
+        ncclResult_t s = ncclReduce(g->d_red[i], g->d_red[i], count, ncclFloat, ncclSum, 0, g->comm[i],
+                                    (hipStream_t)jf_engine_stream(g->eng[i]));
+        if (s != ncclSuccess) {
+            (void)ncclGroupEnd();
+            return fail(g, JF_ERR_DEVICE, "ncclReduce", ncclGetErrorString(s));
+        }
+    }
+    JG_NCCL(g, ncclGroupEnd());
+    g->run_blocks = n_blocks;
+    return JF_OK;
+}
+
+int jf_group_batch_fetch(jf_group *g, float *out_mix) {
+    if (!g || !out_mix) return fail(g, JF_ERR_ARG, "null argument", NULL);
+    if (!g->run_blocks) return fail(g, JF_ERR_STATE, "no batch run in flight", NULL);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    JG_HIP(g, hipSetDevice(g->dev[0]));
+    hipStream_t st = (hipStream_t)jf_engine_stream(g->eng[0]);
+    hipError_t s = hipMemcpyAsync(out_mix, g->d_red[0], sizeof(float) * 2 * (size_t)g->B * (size_t)g->run_blocks,
+                                  hipMemcpyDeviceToHost, st);
+    if (s == hipSuccess) s = hipStreamSynchronize(st);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    g->run_blocks = 0;
+    JG_HIP(g, s);
+    /* the other GPUs' part of the reduce ends with the root's; their kernels' own errors surface here */
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_synchronize(g->eng[i]));
+    return JF_OK;
+}
+
+int jf_group_process_batch(jf_group *g, int n_blocks, const float *positions, float *out_mix) {
+    if (!g || !positions || !out_mix || n_blocks <= 0) return fail(g, JF_ERR_ARG, "bad batch arguments", NULL);
+    int rc = jf_group_batch_upload_positions(g, n_blocks, positions);
+    if (rc != JF_OK) return rc;
+    for (int b0 = 0; b0 < n_blocks; b0 += g->maxK) {
+        const int k = n_blocks - b0 < g->maxK ? n_blocks - b0 : g->maxK;
+        rc = jf_group_batch_run(g, b0, k);
+        if (rc != JF_OK) return rc;
+        rc = jf_group_batch_fetch(g, out_mix + (size_t)b0 * 2 * g->B);
+        if (rc != JF_OK) return rc;
+    }
+    return JF_OK;
+}
+
+int jf_group_synchronize(jf_group *g) {
+    if (!g) return JF_ERR_ARG;
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_synchronize(g->eng[i]));
+    return JF_OK;
+}

@@ -325,3 +325,54 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode != 0
     assert "launch with torch.distributed.run" not in err
     assert "needs a GPU" in err          # printed by the ranks, i.e. they were started
+
+
+# ---------------------------------------------------------------- jefferson_group.h (one job over a node's GPUs) --
+def _group(jf):
+    import importlib
+    return importlib.import_module("jefferson_amd.group")
+
+
+def test_group_library_exports_and_header(jf):
+    """libjefferson_group.so loads next to libjefferson_hip.so and exports every entry point its header declares."""
+    import ctypes
+    import re
+    grp = _group(jf)
+    L = ctypes.CDLL(grp.LIB_PATH)
+    text = open(grp.HEADER_PATH).read()
+    declared = set(re.findall(r"\b(jf_(?:group_\w+|shard_range))\s*\(", text))
+    assert declared == set(grp.exported_symbols())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert "Audio.cu:109-110" in text      # the interface it replaces is cited
+
+
+def test_group_shard_range_is_the_bench_partition(jf):
+    """jf_shard_range (C) == workload.shard_range (bench.py / tests): contiguous, covering, sizes within one."""
+    import importlib.util
+    grp = _group(jf)
+    spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferson-2.0_amd", "workload.py"))
+    wl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wl)
+    for n_total in (1, 5, 8, 1000, 1024, 8192, 8191):
+        for parts in (1, 2, 3, 7, 8):
+            got = [grp.shard_range(n_total, parts, r) for r in range(parts)]
+            assert got == [wl.shard_range(n_total, parts, r) for r in range(parts)]
+            assert got[0][0] == 0 and got[-1][1] == n_total
+            assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1
+    assert grp.shard_range(10, 0, 0) is None and grp.shard_range(10, 2, 2) is None and grp.shard_range(10, 2, -1) is None
+
+
+def test_group_without_gpu_fails_loudly(jf, hrir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    grp = _group(jf)
+    with pytest.raises(jf.JfError) as ei:
+        grp.Group(256, 512, 4, hrir, n_gpus=1)
+    assert ei.value.code == jf.JF_ERR_DEVICE
+    with pytest.raises(jf.JfError) as ei:
+        grp.Group(256, 512, 2, hrir, n_gpus=3)      # more GPUs than sources
+    assert ei.value.code == jf.JF_ERR_ARG

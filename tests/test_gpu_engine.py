@@ -480,3 +480,62 @@ print("RCCL_OK", dist.is_nccl_available())
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
     assert "RCCL_OK True" in r.stdout.decode()
+
+
+def test_group_of_one_gpu_equals_the_engine(jf, hrir, castanets):
+    """include/jefferson_group.h on the one GPU of this box: a communicator of size 1 (ncclCommInitAll, ncclReduce on
+    the engine's stream behind its kernels).  Batch calls in several runs, the device-resident form and per-block
+    calls must hand back exactly what a single engine produces."""
+    import importlib
+    grp = importlib.import_module("jefferson_amd.group")
+    S, K, B = 24, 20, 256
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            pos[k, s] = jf.position_from_spherical(-35 + (9 * s) % 120, (23 * s + 2 * k) % 360, 0.5 + 0.03 * s)
+    sigs = [np.roll(castanets, 911 * s)[:20000 + 10 * s] for s in range(S)]
+    eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=8)
+    g = grp.Group(B, 512, S, hrir, n_gpus=1, max_batch_blocks=8)
+    assert g.num_gpus() == 1 and g.first_source(0) == 0
+    for s in range(S):
+        eng.set_signal(s, sigs[s])
+        g.set_signal(s, sigs[s])
+    want = eng.process_batch(pos)          # 20 blocks = runs of 8, 8, 4
+    got = g.process_batch(pos)
+    assert np.abs(want).max() > 0.2
+    assert np.array_equal(got, want)
+    # device-resident form, state carried on from the batch above
+    more = np.ascontiguousarray(pos[::-1])
+    eng.upload_positions(more)
+    g.upload_positions(more)
+    for first, n in ((0, 8), (8, 5)):
+        eng.batch_run(first, n)
+        eng.synchronize()
+        w = eng.read_device(eng.mix_device_ptr(), (n, 2 * B))
+        assert g.batch_run(first, n) == jf.JF_OK
+        assert g.batch_run(first, n) == jf.JF_ERR_STATE      # one run in flight
+        rc, out = g.batch_fetch(n)
+        assert rc == jf.JF_OK and np.array_equal(out, w)
+    assert g.batch_fetch(1)[0] == jf.JF_ERR_STATE
+    # per-block calls (host sum over the shards)
+    for k in range(3):
+        for s in range(S):
+            assert g.set_spherical(s, 10, (30 * s + 5 * k) % 360, 1.0) == jf.JF_OK
+            assert eng.set_spherical(s, 10, (30 * s + 5 * k) % 360, 1.0) == jf.JF_OK
+        assert np.array_equal(g.process_block(), eng.process_block())
+    assert g.set_spherical(S, 0, 0, 1.0) == jf.JF_ERR_ARG
+    g.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("args", [["pa"], ["group", "1"]])
+def test_plain_c_boundary_checks(args):
+    """jf_ctest.c (plain C, linked against the C ABI only): `pa` drives jf_pa_callback with PortAudio's argument list
+    for 200 blocks -- positions and pause changed in between -- against jf_callback on a twin engine (paCallback,
+    Audio.cu:164-175); `group 1` runs jefferson_group.h over one GPU (RCCL communicator of size 1) against one engine."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "jefferson-2.0_amd", "jf_ctest")
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, (r.stdout.decode(), r.stderr.decode())
+    assert b"max" in r.stdout
