@@ -76,13 +76,14 @@ def load_workload():
     return wl
 
 
-def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, KB, n_blocks, gpu_mix, gpu_groups, G):
+def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, KB, n_blocks, gpu_mix, gpu_groups, G, order):
     """The oracle (CPU restatement of the reference's path) on the n_blocks blocks that END with the last timed
     step of the GPU run, all host threads, parallel over sources: its wall time is the CPU baseline, its output
     the check of that step (`verified`).  The oracle starts n_blocks - KB blocks earlier with empty windows; a
     window holds 1024 samples = 4 blocks, so the compared blocks see exactly the GPU's history.
     gpu_mix [KB][2B]: the GPU's mix of the last step; gpu_groups: {group index: [KB][2B]} stereo blocks of
-    sampled groups of G consecutive sources (None at N > 1, where rank 0 only holds the reduced mix)."""
+    sampled groups of G sources, group g = sources order[G g .. G g + G - 1] (the engine's processing order; None at
+    N > 1, where rank 0 only holds the reduced mix)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     S = len(src_ids)
@@ -116,7 +117,7 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
     if gpu_groups:
         worst = 0.0
         for g, blk in gpu_groups.items():
-            want = opart[g * G:(g + 1) * G, -KB:].astype(np.float64).sum(axis=0)
+            want = opart[order[g * G:(g + 1) * G], -KB:].astype(np.float64).sum(axis=0)
             worst = max(worst, float(np.abs(blk - want).max()))
         check["max_abs_err_group_blocks"] = worst
         check["groups_checked"] = sorted(gpu_groups)
@@ -225,8 +226,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     pmc, pmc_note = None, "not collected"
-    if world == 1 and not args.pmc_child and not args.no_pmc and not args.realtime:
-        extra = (["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
+    if world == 1 and not args.pmc_child and not args.no_pmc:
+        extra = ((["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
+                 + (["--realtime"] if args.realtime else []))
         pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
 
     backend = os.environ.get("JF_DIST_BACKEND", "nccl")
@@ -258,7 +260,7 @@ def main():
     S = SOURCES_PER_GPU
     K, W, KB = args.steps, args.warmup, BLOCKS_PER_STEP
     if args.pmc_child:
-        K, W = 6, 2
+        K, W = (40, 10) if args.realtime else (6, 2)
     ir = None
     if args.reverb:
         B, S, KB = 128, 256, (1 if args.realtime else 32)
@@ -342,6 +344,7 @@ def main():
     eng.profile_enable(False)
     kernels = eng.last_kernels()
     G = eng.last_source_group()
+    order = eng.source_order()
 
     # what the last timed step left behind (checked against the oracle below)
     i_last = prewarm + W + K - 1
@@ -440,6 +443,8 @@ def main():
                                    "N=1024 overlap-save, KEMAR 710x2 table"
                                    + (" (stationary variant)" if args.stationary else ""),
                        "sources_per_gpu": S, "block": B, "blocks_per_step": KB, "source_group": G,
+                       "source_order": "by table row of the first position" if not np.array_equal(order, np.arange(S))
+                       else "as given",
                        "kernels": kernels,
                        "parallelism": (f"sources sharded x{world}, "
                                        + ("RCCL reduce" if backend == "nccl" else f"{backend} all_reduce (rehearsal, not RCCL)")
@@ -483,7 +488,8 @@ def main():
                            "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 rv["traffic"] = pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024
-                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only)"
+                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only; FETCH_SIZE counts Infinity-Cache hits too: " \
+                                       "the 177 MB delay line fits the 256 MB cache)"
             out["reverb_roofline"] = rv
         if world == 1 and ir is None:
             try:
@@ -498,7 +504,7 @@ def main():
                 all_pos = wl.trajectories(jf, all_ids, n_pos, moving=not args.stationary)
             nb = max(KB + 4, min(args.cpu_sample_blocks, max(KB + 4, 262144 // len(all_ids))))
             base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, n_pos, i_last * KB, KB, nb,
-                                                     last_mix, groups, G)
+                                                     last_mix, groups, G, order)
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
             out["verified"] = ok

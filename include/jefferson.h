@@ -240,10 +240,15 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb k
 
 /* ---- debugging / parity taps ------------------------------------------ */
 
-/* Sources one wavefront processes back to back and sums in registers before writing a stereo block
- * (the reference's per-source `intermediate` corresponds to 1).  0 = automatic (2 to 16 for large batches);
- * must divide n_sources.  The mix is the same sum in a different association. */
+/* Sources one unit of work sums (as spectra) before it writes a stereo block (the reference's per-source
+ * `intermediate` corresponds to 1).  0 = automatic (2 to 16 for large batches, and the sources are taken in the order
+ * jf_debug_source_order reports); a value > 0 must divide n_sources and groups CONSECUTIVE sources.  The mix is the
+ * same sum in a different association. */
 int jf_debug_set_source_group(jf_engine *e, int group);
+/* order[n_sources]: unit u of the batch pipeline sums sources order[G u] .. order[G u + G - 1].  With automatic
+ * grouping jf_batch_upload_positions orders the sources by the table row nearest to their first position (units that
+ * run side by side then read neighbouring rows of the table); otherwise the identity. */
+int jf_debug_source_order(const jf_engine *e, int *order);
 /* Form of the reverb's multiply-accumulate stage: 0 = by call size (default); 1 = one workgroup per
  * (block, source) -- what real-time calls use; 2 = groups of sources share each IR partition spectrum;
  * 3 = tiles of consecutive blocks share a sliding window of input spectra (large batch calls).  The

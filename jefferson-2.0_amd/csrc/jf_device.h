@@ -37,6 +37,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_CHUNK_LOADS
 #define JF_CHUNK_LOADS 8  // table-row loads (16 B per lane each) a wave keeps in flight per round
 #endif
+#ifndef JF_STAGE_LOADS
+#define JF_STAGE_LOADS 4  // pair kernel: table-row loads per stage of a half-filter; two stages are in flight
+#endif
 #ifndef JF_SPLIT_EXCHANGE
 #define JF_SPLIT_EXCHANGE 0  // 1: halve the per-wave LDS exchange buffer (re and im separately)
 #endif
@@ -109,6 +112,7 @@ struct FusedParams {
     int S, K, B;
     int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
     int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
+    const int *order;  // [S] pair kernel: unit u works on sources order[G u .. G u + G - 1] (identity unless the engine sorted)
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
 };
 

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -70,6 +71,9 @@ struct jf_engine {
     float *d_mix = nullptr;
     float *d_pos_rt = nullptr;  // [S][5]
     float *d_traj = nullptr;    // [total][S][5]
+    int *d_order = nullptr;     // [S] processing order of the pair kernel (a permutation of the sources)
+    std::vector<int> order;     // host copy
+    bool sorted_order = false;  // d_order is not the identity
     int traj_blocks = 0;
     int cur = 0;  // parity of the valid state/history
     int src_group = 0;  // 0 = automatic
@@ -249,6 +253,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     e->last_group = P.G;
     P.mode = kernel_mode(e);
     P.err = e->hd_err;
+    P.order = e->d_order;
     int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
     if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
@@ -332,6 +337,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_mix);
     (void)hipFree(e->d_pos_rt);
     (void)hipFree(e->d_traj);
+    (void)hipFree(e->d_order);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
     if (e->h_err) (void)hipHostFree(e->h_err);
@@ -389,6 +395,10 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
+        JF_HIP(e, hipMalloc(&e->d_order, sizeof(int) * S));
+        e->order.resize(S);
+        for (size_t s = 0; s < S; s++) e->order[s] = (int)s;
+        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * S, hipMemcpyHostToDevice));
         JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5, hipHostMallocMapped));
         JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
@@ -660,6 +670,7 @@ int jf_submit_block(jf_engine *e) {
             P.B = e->B;
             P.G = 1;
             P.err = e->hd_err;
+            P.order = e->d_order;
             P.mode = kernel_mode(e);
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
             int wgs = (e->S + 15) / 16;
@@ -853,6 +864,23 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     }
     e->traj_blocks = total_blocks;
     JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
+    // Processing order of the pair kernel: a unit sums G sources that are next to each other in this order.  With
+    // automatic grouping the sources are ordered by the table row nearest to their first position, so that the units a
+    // compute unit works on at a time read neighbouring rows of the 5.8 MB table (the L2 of an XCD holds 4 MB); the mix is
+    // the same sum in another association.  jf_debug_set_source_group pins consecutive sources (identity order).
+    const bool want_sorted = e->src_group == 0 && e->S > 1;
+    if (want_sorted || e->sorted_order) {
+        std::vector<std::pair<int, int>> key((size_t)e->S);
+        for (int s = 0; s < e->S; s++) {
+            const float *p = positions + 5 * (size_t)s;
+            const bool ok = p[0] > -1.0e6f && p[0] < 1.0e6f && p[1] > -1.0e6f && p[1] < 1.0e6f;
+            key[s] = {want_sorted && ok ? host_pick_hrtf(p[0], p[1]) : 0, s};
+        }
+        std::stable_sort(key.begin(), key.end());
+        for (int s = 0; s < e->S; s++) e->order[s] = key[s].second;
+        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * e->S, hipMemcpyHostToDevice));
+        e->sorted_order = want_sorted;
+    }
     return JF_OK;
     });
 }
@@ -960,10 +988,23 @@ int jf_debug_set_rt_max_sources(jf_engine *e, int n) {
 
 int jf_debug_set_source_group(jf_engine *e, int group) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e || group < 0 || (group > 0 && e->S % group)) return JF_ERR_ARG;
     e->src_group = group;
+    if (group > 0 && e->sorted_order) {  // a pinned group size means consecutive sources
+        JF_HIP(e, hipStreamSynchronize(e->stream));
+        for (int s = 0; s < e->S; s++) e->order[s] = s;
+        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * e->S, hipMemcpyHostToDevice));
+        e->sorted_order = false;
+    }
     return JF_OK;
     });
+}
+
+int jf_debug_source_order(const jf_engine *e, int *order) {
+    if (!e || !order) return JF_ERR_ARG;
+    for (int s = 0; s < e->S; s++) order[s] = e->order[s];
+    return JF_OK;
 }
 
 int jf_debug_set_reverb_form(jf_engine *e, int form) {

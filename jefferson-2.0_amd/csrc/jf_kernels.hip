@@ -48,6 +48,33 @@ struct __attribute__((packed, aligned(4))) FloatPair {   // two consecutive samp
     float x, y;
 };
 typedef FloatPair __attribute__((address_space(1))) gpair;
+// Read-only tables of a launch (descriptors, signal table, play positions, processing order) are read through the
+// constant address space: a wave-uniform load from it is a scalar load into scalar registers.  Through a generic
+// pointer the compiler must assume that the kernel's own stores may alias, and issues a vector load instead -- a
+// vector register per dword and a full memory latency in front of whatever needs the value.
+#define JF_CONST_AS __attribute__((address_space(4)))
+template <class T>
+JF_DEV const T JF_CONST_AS *as_const(const T *p) {
+    return (const T JF_CONST_AS *)p;
+}
+// an item's descriptor, copied out of global memory by scalar loads
+JF_DEV ItemDesc load_desc(const ItemDesc *p) {
+    const ItemDesc JF_CONST_AS *c = as_const(p);
+    ItemDesc d;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        d.rows_new[t] = c->rows_new[t];
+        d.w_new[t] = c->w_new[t];
+        d.rows_old[t] = c->rows_old[t];
+        d.w_old[t] = c->w_old[t];
+    }
+    d.c_fix = c->c_fix;
+    d.inv_frac = c->inv_frac;
+    d.n_new = c->n_new;
+    d.n_old = c->n_old;
+    d.flags = c->flags;
+    return d;
+}
 
 // LDS traffic below is private to one wavefront; LDS ops of a wave execute in
 // issue order, so all that is needed is to stop the compiler from moving a
@@ -511,8 +538,11 @@ constexpr int kWaveLds = kSplit ? 576 : 1088;  // float2 per wave: the inverse e
 template <int NOUT>
 JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z)[8], int &count0_out, int &L_out) {
     constexpr int B = 64 * NOUT;
-    const SrcSignal sg = P.sigs[s];
-    const int count0 = P.st_in[s].count;
+    const SrcSignal JF_CONST_AS *sgc = as_const(P.sigs + s);
+    SrcSignal sg;
+    sg.ptr = sgc->ptr;
+    sg.length = sgc->length;
+    const int count0 = as_const(P.st_in + s)->count;
     const float *hist = P.hist_in + (size_t)s * kN;
     // the pointer comes out of a table in memory: tell the compiler it is global memory, or every window load is a
     // flat load that also ties up the LDS counter
@@ -533,7 +563,12 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     if (q0 >= 0 && start0 + kN <= L) {
         const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
 #pragma unroll
+#ifdef JF_EXP_NOWINLOAD  // timing experiment (wrong results): no window loads on the usual path
+        for (int r = 0; r < 8; r++) z[r] = make_float2((float)(start0 + r), (float)lane);
+        (void)p;
+#else
         for (int r = 0; r < 8; r++) z[r] = make_float2(p[64 * r].x, p[64 * r].y);
+#endif
     } else {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -793,7 +828,6 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
         a[t] = c2{fa, fa};
         b[t] = c2{fb, fb};
     }
-    constexpr int QC = (JF_CHUNK_LOADS / NT) > 4 ? 4 : (JF_CHUNK_LOADS / NT);
     // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  Y_ear = x * he_ear as two packed
     // instructions each; Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R one packed add each.
     auto ztwo = [&](int q, float2 x, c2 heL, c2 heR, c2 &zk, c2 &zm) {
@@ -808,35 +842,53 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
             zm = special ? z512 : zm;
         }
     };
-#pragma unroll
-    for (int qc = 0; qc < 4; qc += QC) {
-        float4 h[QC][NT];
+    // The four bins in stages of JF_STAGE_LOADS row loads (16 B per lane each), two stages in flight: while one
+    // stage's rows are weighted and multiplied, the next stage's loads are already under way -- the load latency is
+    // paid once per call, not once per stage (the loads are L2 hits; it is their latency, not their bandwidth, that
+    // the kernel waits for: profiles/r02_experiments.md).
+    constexpr int QC = (JF_STAGE_LOADS / NT) > 4 ? 4 : ((JF_STAGE_LOADS / NT) < 1 ? 1 : (JF_STAGE_LOADS / NT));
+    constexpr int NS = 4 / QC;
+    float4 h[2][QC][NT];
+    auto load_stage = [&](int st) {
 #pragma unroll
         for (int q = 0; q < QC; q++)
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                h[q][t] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (qc + q)) + boff);
+#ifdef JF_EXP_NOROWLOAD  // timing experiment (wrong results): the filter arithmetic without its table loads
+                h[st & 1][q][t] = make_float4(xh[q].x, xh[q].y, (float)boff, (float)t);
+#else
+                h[st & 1][q][t] =
+                    *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff);
+#endif
+    };
+    load_stage(0);
+#pragma unroll
+    for (int st = 0; st < NS; st++) {
+        if (st + 1 < NS) load_stage(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
-            c2 haL = pmul_s(c2{h[q][0].x, h[q][0].y}, a[0]), haR = pmul_s(c2{h[q][0].z, h[q][0].w}, a[0]);
+            const float4(&hq)[NT] = h[st & 1][q];
+            c2 haL = pmul_s(c2{hq[0].x, hq[0].y}, a[0]), haR = pmul_s(c2{hq[0].z, hq[0].w}, a[0]);
             c2 hbL = c2{0.f, 0.f}, hbR = c2{0.f, 0.f};
             if (BOTH) {
-                hbL = pmul_s(c2{h[q][0].x, h[q][0].y}, b[0]);
-                hbR = pmul_s(c2{h[q][0].z, h[q][0].w}, b[0]);
+                hbL = pmul_s(c2{hq[0].x, hq[0].y}, b[0]);
+                hbR = pmul_s(c2{hq[0].z, hq[0].w}, b[0]);
             }
 #pragma unroll
             for (int t = 1; t < NT; t++) {
-                haL = pfma_s(c2{h[q][t].x, h[q][t].y}, a[t], haL);
-                haR = pfma_s(c2{h[q][t].z, h[q][t].w}, a[t], haR);
+                haL = pfma_s(c2{hq[t].x, hq[t].y}, a[t], haL);
+                haR = pfma_s(c2{hq[t].z, hq[t].w}, a[t], haR);
                 if (BOTH) {
-                    hbL = pfma_s(c2{h[q][t].x, h[q][t].y}, b[t], hbL);
-                    hbR = pfma_s(c2{h[q][t].z, h[q][t].w}, b[t], hbR);
+                    hbL = pfma_s(c2{hq[t].x, hq[t].y}, b[t], hbL);
+                    hbR = pfma_s(c2{hq[t].z, hq[t].w}, b[t], hbR);
                 }
             }
             c2 zka, zma, zkb = c2{0.f, 0.f}, zmb = c2{0.f, 0.f};
-            ztwo(qc + q, xh[qc + q], haL, haR, zka, zma);
-            if (BOTH) ztwo(qc + q, xh[qc + q], hbL, hbR, zkb, zmb);
-            use(qc + q, zka, zma, zkb, zmb);
+            const int qq = QC * st + q;
+            ztwo(qq, xh[qq], haL, haR, zka, zma);
+            if (BOTH) ztwo(qq, xh[qq], hbL, hbR, zkb, zmb);
+            use(qq, zka, zma, zkb, zmb);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -923,9 +975,15 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         const int sg = unit - b * SG;
         const int s0 = sg * G;
 #endif
-        const ItemDesc *d0 = P.desc + (size_t)b * P.S + s0;
+        // the unit's sources: slots s0 .. s0 + G - 1 of the engine's processing order (jf_engine.cpp: sources that read
+        // the same table rows next to each other)
+        const ItemDesc *db = P.desc + (size_t)b * P.S;
+        const int JF_CONST_AS *ord = as_const(P.order + s0);
         bool any_xfade = false;
-        for (int g = 0; g < G; g++) any_xfade = any_xfade || ((d0[g].flags & 2) != 0 && d0[g].n_new > 0);
+        for (int g = 0; g < G; g++) {
+            const ItemDesc JF_CONST_AS *d = as_const(db + ord[g]);
+            any_xfade = any_xfade || ((d->flags & 2) != 0 && d->n_new > 0);
+        }
         mail_free(npub);  // the last unit's final hand-offs used both slots
         // sums over the unit's sources of Z[k] and Z[N-k], k = lane + 64 (qb + q), old and new sets
         c2 zko[4], zkn[4], zmo[4], zmn[4];
@@ -966,7 +1024,8 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             }
         };
         auto take_partner_source = [&](int jp) {  // his j-th source: my bins of its X D are in his mailbox
-            const ItemDesc *dp = d0 + 2 * jp + (half ^ 1);
+            const ItemDesc dl = load_desc(db + ord[2 * jp + (half ^ 1)]);
+            const ItemDesc *dp = &dl;
             if (dp->n_new <= 0) return;  // silent: he published nothing
             await_partner();
             const float2 *m = pmail + (nseen & 1) * kPairMail + lane;
@@ -979,19 +1038,20 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         int jp = 0;
 #pragma unroll 1
         for (int j = 0; j < n_own; j++) {
-            const int g = 2 * j + half;
-            const ItemDesc *dp = d0 + g;
-            const int item = b * P.S + s0 + g;
+            const int src = ord[2 * j + half];
+            const ItemDesc dl = load_desc(db + src);
+            const ItemDesc *dp = &dl;
+            const int item = b * P.S + src;
             // the loads of my source's window first; the partner's previous source is filtered while they are in
             // flight (his hand-off has been waiting for a whole source), then my source's transform and filter
             float2 z[8];
             int count0, L;
-            item_gather<NOUT>(P, b, s0 + g, opaque(lane), z, count0, L);
+            item_gather<NOUT>(P, b, src, opaque(lane), z, count0, L);
 #if JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
 #endif
             float2 xd[8];
-            if (item_finish<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, opaque(lane), z,
+            if (item_finish<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, src, buf, s_tw, opaque(lane), z,
                                                         count0, L, xd)) {
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago

@@ -61,6 +61,8 @@ def test_bench_shape_against_the_oracle(jf, hrir):
     for s in ids:
         e.set_signal(int(s), sigs[s])
     e.upload_positions(pos)
+    order = e.source_order()     # automatic grouping: units take the sources in this order (sorted by table row)
+    assert sorted(order.tolist()) == list(range(S)) and not np.array_equal(order, np.arange(S))
     mixes, parts = [], []
     for c in range(CALLS):
         e.batch_run(c * K, K)
@@ -82,7 +84,7 @@ def test_bench_shape_against_the_oracle(jf, hrir):
         ora.set_signal(int(s), sigs[s])
     omix, opart = ora.process_batch(pos, want_partial=True)   # opart [S][2K][2B]
     ora.close()
-    want_groups = opart.astype(np.float64).reshape(S // 16, 16, CALLS * K, 2 * B).sum(axis=1).transpose(1, 0, 2)
+    want_groups = opart[order].astype(np.float64).reshape(S // 16, 16, CALLS * K, 2 * B).sum(axis=1).transpose(1, 0, 2)
     assert np.abs(want_groups).max() > 1.0
     # 16 sources per group block, each within TOL32 of the oracle
     assert np.abs(part - want_groups).max() <= TOL32 * 16
@@ -93,7 +95,7 @@ def test_bench_shape_against_the_oracle(jf, hrir):
 
     # sampled groups against the float64 model (the truth for the tolerance)
     for g in (0, 1, 13, 31, 32, 47, 62, 63):
-        src = list(range(16 * g, 16 * g + 16))
+        src = order[16 * g: 16 * g + 16].tolist()
         mod = model64.Model(B, 512, 16, hrir)
         for j, s in enumerate(src):
             mod.set_signal(j, sigs[s])
