@@ -740,7 +740,8 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
             const int item = b * P.S + s0 + g;
-            spatialise_item<NOUT>(P, P.desc + item, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, acc);
+            const ItemDesc dl = load_desc(P.desc + item);  // scalar loads
+            spatialise_item<NOUT>(P, &dl, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, acc);
         }
 #if JF_UNIT_ORDER
         float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
