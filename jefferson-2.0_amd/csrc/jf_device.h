@@ -52,6 +52,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_UNIT_ORDER
 #define JF_UNIT_ORDER 1  // group kernel: 1 = consecutive waves take consecutive blocks of the same sources (rows and windows overlap in cache: 2.8 %)
 #endif
+#ifndef JF_UNIT_ZIGZAG
+#define JF_UNIT_ZIGZAG 1  // pair kernel: every other round of units in reverse order (balances expensive and cheap units)
+#endif
 constexpr int kWavesPerWg = JF_WAVES_PER_WG;
 
 // Twiddle pack: every table the FFT passes need, laid out so that a wave reads consecutive

@@ -217,15 +217,15 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
         em = next_events(e, e->ev_mix);
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
-    // sources a wavefront (pair) sums before it stores a stereo block: as many as keep the resident waves
-    // busy: larger groups mean fewer inverse transforms and fewer partial blocks for the mix
-    // (profiles/r01_experiments.md)
+    // sources a pair of wavefronts sums before it stores a stereo block: as many as leave one unit for every
+    // resident pair (2048 on MI355X): larger groups mean fewer inverse transforms and fewer partial blocks for the
+    // mix; 32 at full size measures the same as 16 (profiles/r02_experiments.md)
     const long long n_items = (long long)K * e->S;
     const int G = e->src_group > 0 ? e->src_group
-                  : (e->S % 16 == 0 && n_items >= 65536) ? 16
-                  : (e->S % 8 == 0 && n_items >= 32768) ? 8
-                  : (e->S % 4 == 0 && n_items >= 16384) ? 4
-                  : (e->S % 2 == 0 && n_items >= 8192)  ? 2
+                  : (e->S % 16 == 0 && n_items >= 32768) ? 16
+                  : (e->S % 8 == 0 && n_items >= 16384) ? 8
+                  : (e->S % 4 == 0 && n_items >= 8192) ? 4
+                  : (e->S % 2 == 0 && n_items >= 4096)  ? 2
                                                          : 1;
     FusedParams P;
     P.G = (e->S % G == 0) ? G : 1;

@@ -965,8 +965,18 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const bool special = lane == 0 && half == 0;
     const unsigned lofs = 64u * qb + lane;
     const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
+    // Rounds of units over the persistent pairs, every other round in reverse (JF_UNIT_ZIGZAG): the first blocks of a
+    // call gather their windows the slow way, and a pair whose unit came from the expensive end of one round takes
+    // the cheap end of the next.
+    const int n_pairs = gridDim.x * kPairsPerWg, my_pair = blockIdx.x * kPairsPerWg + pair;
 #pragma unroll 1
-    for (int unit = blockIdx.x * kPairsPerWg + pair; unit < n_units; unit += gridDim.x * kPairsPerWg) {
+    for (int round = 0; round * n_pairs < n_units; round++) {
+#if JF_UNIT_ZIGZAG
+        const int unit = (round & 1) ? (round + 1) * n_pairs - 1 - my_pair : round * n_pairs + my_pair;
+#else
+        const int unit = round * n_pairs + my_pair;
+#endif
+        if (unit >= n_units) continue;
 #if JF_UNIT_ORDER
         const int sg = unit / P.K;
         const int b = unit - sg * P.K;
