@@ -811,9 +811,11 @@ JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
 // Bins qb .. qb + 3 (lofs = 64 qb + lane) of one filter set, or of two sets that read the same rows with different
 // weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.  Row addresses stay scalar (table + row, wave-uniform)
 // with ONE per-lane offset register for all rows: loads in the saddr form, no 64-bit pointer pair per row.
-template <int NT, bool BOTH, class F>
+// fetch(xh) delivers the source's X D for these bins; it is called AFTER the first two stages of row loads have been
+// requested, so whatever it waits for (the partner's hand-off flag, the mailbox read) overlaps with their latency.
+template <int NT, bool BOTH, class X, class F>
 JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa, const float *wb,
-                          const float2 (&xh)[4], bool special, F &&use) {
+                          X &&fetch, bool special, F &&use) {
     const float4 *hp[NT];
     c2 a[NT], b[NT];  // (w, w): a weight as a scalar-register pair feeds both halves of a packed operation
     unsigned boff = 16u * lofs;  // byte offset of this lane's first bin inside a row
@@ -863,9 +865,13 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
 #endif
     };
     load_stage(0);
+    if (NS > 1) load_stage(1);
+    __builtin_amdgcn_sched_barrier(0);
+    float2 xh[4];
+    fetch(xh);
 #pragma unroll
     for (int st = 0; st < NS; st++) {
-        if (st + 1 < NS) load_stage(st + 1);
+        if (st >= 1 && st + 1 < NS) load_stage(st + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
@@ -895,15 +901,15 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
     }
 }
 
-template <bool BOTH, class F>
+template <bool BOTH, class X, class F>
 JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa,
-                             const float *wb, const float2 (&xh)[4], bool special, F &&use) {
+                             const float *wb, X &&fetch, bool special, F &&use) {
     if (nt == 4)
-        filtered_half<4, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
+        filtered_half<4, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
     else if (nt == 2)
-        filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
+        filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
     else
-        filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, xh, special, use);
+        filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
 }
 
 #ifndef JF_PAIR_D_EARLY
@@ -1000,21 +1006,24 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         c2 zko[4], zkn[4], zmo[4], zmn[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = c2{0.f, 0.f};
-        auto accumulate = [&](const ItemDesc *dp, const float2 (&xh)[4]) {
+        // fetch(xh): see filtered_half.  A source with two filters (its sets do not share rows) fetches once.
+        auto accumulate = [&](const ItemDesc *dp, auto &&fetch) {
 #ifdef JF_EXP_NOFILTER  // timing experiment (wrong results): fronts and hand-offs only
-            zkn[0] += c2_of(xh[0]);
+            float2 xq[4];
+            fetch(xq);
+            zkn[0] += c2_of(xq[0]);
             return;
 #endif
             const int nn = dp->n_new;
+            auto add_new = [&](int q, c2 zk, c2 zmv, c2, c2) {
+                zkn[q] += zk;
+                zmn[q] += zmv;
+            };
             if (!any_xfade) {
-                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
-                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
-                                            zkn[q] += zk;
-                                            zmn[q] += zmv;
-                                        });
+                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, fetch, special, add_new);
             } else if (dp->flags & 1) {
                 // both sets read the same rows (prep_kernel laid them out so): one round of loads
-                filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, xh, special,
+                filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, fetch, special,
                                        [&](int q, c2 zka, c2 zma, c2 zkb, c2 zmb) {
                                            zko[q] += zka;
                                            zmo[q] += zma;
@@ -1022,29 +1031,36 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                                            zmn[q] += zmb;
                                        });
             } else {
-                filtered_half_nt<false>(dp->n_old, P.htab, lofs, dp->rows_old, dp->w_old, dp->w_old, xh, special,
-                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
+                float2 keep[4];
+                filtered_half_nt<false>(dp->n_old, P.htab, lofs, dp->rows_old, dp->w_old, dp->w_old,
+                                        [&](float2 (&xh)[4]) {
+                                            fetch(xh);
+#pragma unroll
+                                            for (int q = 0; q < 4; q++) keep[q] = xh[q];
+                                        },
+                                        special, [&](int q, c2 zk, c2 zmv, c2, c2) {
                                             zko[q] += zk;
                                             zmo[q] += zmv;
                                         });
-                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, xh, special,
-                                        [&](int q, c2 zk, c2 zmv, c2, c2) {
-                                            zkn[q] += zk;
-                                            zmn[q] += zmv;
-                                        });
+                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new,
+                                        [&](float2 (&xh)[4]) {
+#pragma unroll
+                                            for (int q = 0; q < 4; q++) xh[q] = keep[q];
+                                        },
+                                        special, add_new);
             }
         };
         auto take_partner_source = [&](int jp) {  // his j-th source: my bins of its X D are in his mailbox
             const ItemDesc dl = load_desc(db + ord[2 * jp + (half ^ 1)]);
             const ItemDesc *dp = &dl;
             if (dp->n_new <= 0) return;  // silent: he published nothing
-            await_partner();
-            const float2 *m = pmail + (nseen & 1) * kPairMail + lane;
-            float2 xh[4];
+            accumulate(dp, [&](float2 (&xh)[4]) {
+                await_partner();
+                const float2 *m = pmail + (nseen & 1) * kPairMail + lane;
 #pragma unroll
-            for (int q = 0; q < 4; q++) xh[q] = m[64 * q];
-            consumed();
-            accumulate(dp, xh);
+                for (int q = 0; q < 4; q++) xh[q] = m[64 * q];
+                consumed();
+            });
         };
         int jp = 0;
 #pragma unroll 1
@@ -1064,6 +1080,8 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             float2 xd[8];
             if (item_finish<NOUT, JF_PAIR_D_EARLY != 0>(P, dp, P.pos + (size_t)item * 5, b, src, buf, s_tw, opaque(lane), z,
                                                         count0, L, xd)) {
+                // (requesting my filter's first row loads before this hand-off would hold X D, 16 registers, across
+                // them: it spills)
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
                 float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
@@ -1073,7 +1091,10 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                     m[64 * q] = half ? xd[q] : xd[4 + q];
                 }
                 publish();
-                accumulate(dp, xh);
+                accumulate(dp, [&](float2 (&x)[4]) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) x[q] = xh[q];
+                });
             }
 #if !JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
