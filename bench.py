@@ -391,6 +391,9 @@ def main():
                 "avg_launch_ms": prof["fused_ms"] / launches,
                 "flops_per_launch_executed": flops_ex / launches,
                 "flops_per_launch_reference_algorithm": flops_ref / launches,
+                # the same output priced with the reference's own algorithm (an unpruned inverse pair per filter set and
+                # source, GPUSoundSource.cu:320-385): comparable across kernels that skip different amounts of that work
+                "frac_reference_algorithm": (flops_ref / fused_s / 1e12 / FP32_VECTOR_PEAK_TF) if fused_s > 0 else 0.0,
                 "flop_model": "jefferson-2.0_amd/workload.py flops_window (textbook counts; tests/test_abi.py)",
                 "table_rows_per_source_block": rows / items,
                 "other_kernels": other,

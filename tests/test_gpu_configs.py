@@ -349,3 +349,35 @@ def test_far_radii_end_to_end(jf, hrir):
         peak = np.abs(want).max()
         assert peak > 0
         assert np.abs(got - want).max() <= 1e-6 * peak, r
+
+
+@pytest.mark.parametrize("B,G", [(256, 3), (128, 5), (64, 15)])
+def test_pair_kernel_odd_group_sizes(jf, hrir, castanets, B, G):
+    """Odd G: the two waves of a pair own different numbers of sources (wave 0: ceil(G/2), wave 1: floor(G/2)) and the
+    drain loop at the end of a unit runs -- against the per-source kernel and the float32 oracle, with a silent source
+    on each wave's side."""
+    S, K = 30, 7
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            moving = s % 4 != 1
+            pos[k, s] = jf.position_from_spherical(-40 + (11 * s) % 121, (29 * s + (2 * k if moving else 0)) % 360, 0.5 + 0.06 * s)
+    pos[:, 6, 0] = -70.0      # no such elevation ring: silence (an even slot of its unit for every G here ...)
+    pos[:, 7, 0] = -70.0      # ... and an odd one
+    sigs = [np.roll(castanets, 517 * s)[: 7000 + 211 * s] for s in range(S)]
+    outs = {}
+    for g in (1, G):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+        e.set_source_group(g)
+        for s in range(S):
+            e.set_signal(s, sigs[s])
+        outs[g] = np.concatenate([e.process_batch(pos[:4]), e.process_batch(pos[4:])])
+        assert e.last_source_group() == g
+        e.close()
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        ora.set_signal(s, sigs[s])
+    want = ora.process_batch(pos)
+    assert np.abs(want).max() > 0.1
+    assert np.abs(outs[G] - outs[1]).max() <= TOL32 * S / 4
+    assert np.abs(outs[G] - want).max() <= TOL32 * S / 4
