@@ -96,9 +96,13 @@ struct SrcSignal {
 };
 
 // hrtf_signals.cu:7-12 tables, filled on the host by the reference's own loop.
+constexpr int kPickAzi = 401;  // integer azimuths 0 .. 400 of the nearest-azimuth table
 struct RingTable {
     int offset[kNumElev + 1];
     float inc[kNumElev];
+    // [kNumElev][kPickAzi] device table (null: search): the table row nearest to integer azimuth a on ring e -- what
+    // pick_hrtf's search over a ring (hrtf_signals.cu:20-51) returns for (elevation of e, a); built by that search
+    const short *pick;
 };
 
 struct FusedParams {

@@ -71,6 +71,8 @@ struct jf_engine {
     float *d_mix = nullptr;
     float *d_pos_rt = nullptr;  // [S][5]
     float *d_traj = nullptr;    // [total][S][5]
+    short *d_pick = nullptr;    // nearest-azimuth table of the index/weight kernels (RingTable::pick)
+    RingTable rt{};             // ring_table() + this engine's device table
     int *d_order = nullptr;     // [S] processing order of the pair kernel (a permutation of the sources)
     std::vector<int> order;     // host copy
     bool sorted_order = false;  // d_order is not the identity
@@ -231,7 +233,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     P.G = (e->S % G == 0) ? G : 1;
     const int canon = P.G > 1;  // descriptors in the pair-kernel layout
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
-    JF_HIP(e, launch_prep(ring_table(), kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
+    JF_HIP(e, launch_prep(e->rt, kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
     {
         const int rc = run_reverb_stage(e, p, K);
@@ -338,6 +340,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_pos_rt);
     (void)hipFree(e->d_traj);
     (void)hipFree(e->d_order);
+    (void)hipFree(e->d_pick);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
     if (e->h_err) (void)hipHostFree(e->h_err);
@@ -395,6 +398,17 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
+        {
+            // nearest table row per (ring, integer azimuth), by the search itself (host_pick_hrtf = hrtf_signals.cu:20-51)
+            static const int elev[kNumElev] = {-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90};
+            std::vector<short> pick((size_t)kNumElev * kPickAzi);
+            for (int r = 0; r < kNumElev; r++)
+                for (int a = 0; a < kPickAzi; a++) pick[(size_t)r * kPickAzi + a] = (short)host_pick_hrtf((float)elev[r], (float)a);
+            JF_HIP(e, hipMalloc(&e->d_pick, sizeof(short) * pick.size()));
+            JF_HIP(e, hipMemcpy(e->d_pick, pick.data(), sizeof(short) * pick.size(), hipMemcpyHostToDevice));
+            e->rt = ring_table();
+            e->rt.pick = e->d_pick;
+        }
         JF_HIP(e, hipMalloc(&e->d_order, sizeof(int) * S));
         e->order.resize(S);
         for (size_t s = 0; s < S; s++) e->order[s] = (int)s;
@@ -675,7 +689,7 @@ int jf_submit_block(jf_engine *e) {
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
             int wgs = (e->S + 15) / 16;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
-            JF_HIP(e, launch_rt_block(P, ring_table(), e->hd_pos, e->hd_out, wgs, e->stream));
+            JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, wgs, e->stream));
             e->cur = p ^ 1;
             e->last_rt = true;
             e->rt_wgs = wgs;
@@ -1060,7 +1074,7 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
         JF_HIP(e, hipMalloc(&d_n, sizeof(int) * n));
         JF_HIP(e, hipMemcpy(d_e, ele, sizeof(float) * n, hipMemcpyHostToDevice));
         JF_HIP(e, hipMemcpy(d_a, azi, sizeof(float) * n, hipMemcpyHostToDevice));
-        JF_HIP(e, launch_interp_debug(ring_table(), d_e, d_a, d_r, d_w, d_n, n,
+        JF_HIP(e, launch_interp_debug(e->rt, d_e, d_a, d_r, d_w, d_n, n,
                                       (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(rows, d_r, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
@@ -1147,7 +1161,7 @@ int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float
             JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * 2 * kNc));
             JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
         }
-        JF_HIP(e, launch_stage_debug(ring_table(), kernel_mode(e), d_p, d_w, n, e->d_htab, e->d_twpack, d_d, d_s,
+        JF_HIP(e, launch_stage_debug(e->rt, kernel_mode(e), d_p, d_w, n, e->d_htab, e->d_twpack, d_d, d_s,
                                      e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(dist, d_d, sizeof(float2) * (size_t)n * kNc, hipMemcpyDeviceToHost));

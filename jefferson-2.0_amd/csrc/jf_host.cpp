@@ -41,6 +41,7 @@ struct Rings {
             }
             rt.offset[e + 1] = j;
         }
+        rt.pick = nullptr;
     }
 };
 const Rings &rings() {

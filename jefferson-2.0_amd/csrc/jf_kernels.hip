@@ -1226,6 +1226,12 @@ JF_DEV int dev_pick_azi(const RingTable &rt, int ring, float obj_azi) {
     return rt.offset[ring] + best;
 }
 
+// the same for an integer azimuth: one look-up in the table that search filled (jf_engine.cpp), the search itself outside it
+JF_DEV int dev_pick_int(const RingTable &rt, int ring, int th) {
+    if (rt.pick != nullptr && (unsigned)th < (unsigned)kPickAzi) return rt.pick[ring * kPickAzi + th];
+    return dev_pick_azi(rt, ring, (float)th);
+}
+
 // hrtf_signals.cu:20-51 in full: nearest elevation ring, then nearest azimuth on it
 JF_DEV int dev_pick_hrtf(const RingTable &rt, float obj_ele, float obj_azi) {
     obj_ele = roundf(obj_ele / 10) * 10;
@@ -1295,11 +1301,9 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
     const int phi1 = (int)(ele + 9) / 10 * 10;
     const float omegaE = (ele - phi0) / 10.0f;
     const float omegaF = (phi1 - ele) / 10.0f;
-    int r0 = -1, r1 = -1;
-    for (int e = 0; e < kNumElev; e++) {
-        if (phi0 == d_elev_pos[e]) r0 = e;
-        if (phi1 == d_elev_pos[e]) r1 = e;
-    }
+    // the rings with these elevations (multiples of 10 by construction; -40 .. 90 exist)
+    const int r0 = (phi0 >= -40 && phi0 <= 90) ? (phi0 + 40) / 10 : -1;
+    const int r1 = (phi1 >= -40 && phi1 <= 90) ? (phi1 + 40) / 10 : -1;
     if (r0 < 0 || r1 < 0) return 0;
     const float dt1 = rt.inc[r0], dt2 = rt.inc[r1];
     const int th0 = (int)((int)(azi / dt1) * dt1);
@@ -1310,10 +1314,10 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
     const float omegaB = (th1 - azi) / dt1;
     const float omegaC = (azi - th2) / dt2;
     const float omegaD = (th3 - azi) / dt2;
-    const int h0 = dev_pick_azi(rt, r0, (float)th0);
-    const int h1 = dev_pick_azi(rt, r0, (float)th1);
-    const int h2 = dev_pick_azi(rt, r1, (float)th2);
-    const int h3 = dev_pick_azi(rt, r1, (float)th3);
+    const int h0 = dev_pick_int(rt, r0, th0);
+    const int h1 = dev_pick_int(rt, r0, th1);
+    const int h2 = dev_pick_int(rt, r1, th2);
+    const int h3 = dev_pick_int(rt, r1, th3);
     return dev_flatten_terms(h0, h1, h2, h3, omegaA, omegaB, omegaC, omegaD, omegaE, omegaF, rows, w);
 }
 
