@@ -92,8 +92,10 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
     for j, sid in enumerate(src_ids):
         sig = wl.source_signal_and_start(sid)[0]
         ora.set_signal(j, np.roll(sig, -((first * B) % len(sig))))   # the looped stream as the GPU reads it at `first`
-    idx = [(first + b) % n_pos for b in range(n_blocks)]
-    p = np.ascontiguousarray(pos[idx])
+    if n_pos is None:   # pos holds exactly the blocks first .. first + n_blocks - 1
+        p = np.ascontiguousarray(pos)
+    else:
+        p = np.ascontiguousarray(pos[[(first + b) % n_pos for b in range(n_blocks)]])
     threads = min(oracle_lib.lib().jfo_num_threads(), cpu_share())
     warm = oracle_lib.Engine(B, 512, min(S, 64), hrir)              # warm the thread pool on something else
     warm.process_batch(np.ascontiguousarray(p[:2, :min(S, 64)]), n_threads=threads)
@@ -459,7 +461,8 @@ def main():
         }
         if world > 1:
             # the only exchange of the path: the sum of the per-rank stereo mixes
-            out["comm"] = {"collective": "reduce(sum, dst=0) of float32[%d][%d] per step" % (KB, 2 * B),
+            out["comm"] = {"collective": ("reduce(sum, dst=0)" if backend == "nccl" else "all_reduce(sum)")
+                                         + " of float32[%d][%d] per step" % (KB, 2 * B),
                            "backend": "RCCL" if backend == "nccl" else backend,
                            "payload_bytes_per_rank_per_step": KB * 2 * B * 4,
                            "overlap": "asynchronous on the collective's stream, double-buffered: step i + 1 computes "
@@ -502,12 +505,16 @@ def main():
                 out["single_source_block_latency_us"] = {"error": str(ex)}
         if not args.no_cpu_baseline and ir is None:
             all_ids = np.arange(0, world * S)
-            if world == 1:
-                all_pos = pos
-            else:
-                all_pos = wl.trajectories(jf, all_ids, n_pos, moving=not args.stationary)
             nb = max(KB + 4, min(args.cpu_sample_blocks, max(KB + 4, 262144 // len(all_ids))))
-            base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, n_pos, i_last * KB, KB, nb,
+            if world == 1:
+                all_pos, all_n = pos, n_pos
+            else:
+                # the other ranks' sources too, but only the blocks the oracle replays (the trajectory is periodic in
+                # the block index: absolute indices work as they are)
+                first = i_last * KB + KB - nb
+                all_pos = wl.trajectories(jf, all_ids, nb, moving=not args.stationary, first_block=first)
+                all_n = None
+            base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, all_n, i_last * KB, KB, nb,
                                                      last_mix, groups, G, order)
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
