@@ -64,6 +64,8 @@ static int shard_of(const jf_group *g, int src) {
 
 void jf_group_destroy(jf_group *g) {
     if (!g) return;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     for (int i = 0; i < g->n; i++) {
         if (g->eng && g->eng[i]) (void)jf_synchronize(g->eng[i]);
         if (g->comm && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
@@ -80,6 +82,7 @@ void jf_group_destroy(jf_group *g) {
     free(g->d_red);
     free(g->blk);
     free(g);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
 }
 
 int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out) {
@@ -91,6 +94,8 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
         return fail(NULL, JF_ERR_DEVICE, "no HIP device available (this library has no CPU path)", NULL);
     jf_group *g = (jf_group *)calloc(1, sizeof(*g));
     if (!g) return fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev); /* the caller's current device is left as it was */
     g->n = n_gpus;
     g->S = cfg->n_sources;
     g->B = cfg->frames_per_buffer;
@@ -132,8 +137,10 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
     }
     if (rc != JF_OK) {
         jf_group_destroy(g);
+        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
         return rc;
     }
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     *out = g;
     return JF_OK;
 }
