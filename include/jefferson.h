@@ -276,6 +276,8 @@ int jf_debug_set_grid_limit(jf_engine *e, int workgroups);
  */
 int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float *windows, float *dist,
                         float *spectra);
+/* Timing experiments (kernels built with -DJF_EXP_STAMPS): n 64-bit time stamps the last launch left (n <= 8192). */
+int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 

@@ -79,6 +79,7 @@ _SIGS = {
     "jf_reverb_rms_gain": (C.c_float, [_f, C.c_size_t, _f, C.c_size_t]),
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "jf_debug_source_order": (C.c_int, [C.c_void_p, _i]),
     "jf_debug_set_reverb_form": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_last_block_peak": (C.c_float, [C.c_void_p]),
@@ -316,6 +317,11 @@ class Engine:
 
     def last_kernels(self):
         return lib().jf_debug_last_kernels(self.h).decode().split(";")
+
+    def read_stamps(self, n):
+        out = np.zeros(n, np.uint64)
+        self._chk(lib().jf_debug_read_stamps(self.h, out.ctypes.data_as(C.POINTER(C.c_ulonglong)), n))
+        return out
 
     def source_order(self):
         o = np.zeros(self.S, np.int32)

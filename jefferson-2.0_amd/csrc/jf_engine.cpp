@@ -417,8 +417,9 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
-        JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int), hipHostMallocMapped));
-        *e->h_err = 0;
+        // the error word, followed by 64 KB that timing experiments of the kernels may fill (JF_EXP_STAMPS)
+        JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int) * 4 + 65536, hipHostMallocMapped));
+        memset(e->h_err, 0, sizeof(int) * 4 + 65536);
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_err, e->h_err, 0));
         e->d_signal.assign(S, nullptr);
         JF_HIP(e, hipMalloc(&e->d_zero, sizeof(float) * kN));
@@ -1178,6 +1179,16 @@ int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float
 }
 
 float jf_last_block_peak(const jf_engine *e) { return e ? e->last_peak : 0.0f; }
+
+int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n) {
+    return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
+    if (!e || !out || n < 0 || n > 8192) return JF_ERR_ARG;
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    memcpy(out, (const char *)e->h_err + 16, sizeof(unsigned long long) * (size_t)n);
+    return JF_OK;
+    });
+}
 
 // ---- WAV -----------------------------------------------------------------------
 int jf_wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate) {

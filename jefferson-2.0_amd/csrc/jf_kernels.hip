@@ -560,7 +560,12 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     // the signal) every lane works out where its samples are; all loads are in flight together either way.
     int start0 = base + q0;  // signal index of the window's first sample (meaningful for q0 >= 0), < L + N
     start0 = start0 >= L ? start0 - L : start0;
+#ifdef JF_EXP_FASTGATHER  // timing experiment (wrong results): every window takes the one-stretch path
+    start0 = (q0 >= 0 && start0 + kN <= L) ? start0 : 0;
+    if (true) {
+#else
     if (q0 >= 0 && start0 + kN <= L) {
+#endif
         const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
 #pragma unroll
 #ifdef JF_EXP_NOWINLOAD  // timing experiment (wrong results): no window loads on the usual path
@@ -915,6 +920,9 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
+#ifndef JF_PAIR_ROTATE_PRIO
+#define JF_PAIR_ROTATE_PRIO 1  // 1: progress-ordered wave priorities (0: the hardware's oldest-first: -5.5 %)
+#endif
 #ifndef JF_PAIR_OVERLAP
 #define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
                            // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
@@ -935,6 +943,12 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wave >> 1, half = wave & 1;
+#ifdef JF_EXP_STAMPS  // timing experiment: when does every wave start and finish (100 MHz real-time counter)
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(P.err) + 16);
+    const int wid = blockIdx.x * kPairsPerWg + pair;  // pair index: 4 stamps per pair, written by its wave 1
+    const bool stamper = lane == 0 && half == 1 && wid < 2048;
+    if (stamper) stamps[4 * wid] = __builtin_amdgcn_s_memrealtime();
+#endif
     float2 *base = s_pair + pair * kPairLds;
     float2 *buf = base + half * kPairWave;  // my FFT work space
     float2 *mail = buf + kPairWork;         // my two mailbox slots
@@ -943,6 +957,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const unsigned my_pub = flags + 4 * half, his_pub = flags + 4 * (half ^ 1);
     const unsigned my_ack = flags + 8 + 4 * half, his_ack = flags + 8 + 4 * (half ^ 1);
     int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
+    int steps_done = 0;       // sources I have run the front half of
     bool dead = false;        // a wait timed out (pair_wait)
     auto publish = [&]() {
         JF_WAVE_LDS_SYNC();
@@ -1065,6 +1080,18 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         int jp = 0;
 #pragma unroll 1
         for (int j = 0; j < n_own; j++) {
+#if JF_PAIR_ROTATE_PRIO
+            // The issue arbiter of a SIMD serves its oldest wave first: left alone, waves 0..7 of a workgroup run their
+            // first unit in 54 us and waves 8..15 in 70-100 us (profiles/stamps.py), and the SIMDs are half empty while
+            // the late ones finish.  A wave lowers its priority with every source it has done (mod 4): whoever is
+            // behind is served first, and the waves of a SIMD advance together.
+            switch (3 - (steps_done++ & 3)) {  // s_setprio takes an immediate
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
             const int src = ord[2 * j + half];
             const ItemDesc dl = load_desc(db + src);
             const ItemDesc *dp = &dl;
@@ -1168,7 +1195,13 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #pragma unroll
             for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
         }
+#ifdef JF_EXP_STAMPS
+        if (stamper && round < 2) stamps[4 * wid + 1 + round] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
+#ifdef JF_EXP_STAMPS
+    if (stamper) stamps[4 * wid + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------- mixing --
