@@ -52,6 +52,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_UNIT_ORDER
 #define JF_UNIT_ORDER 1  // group kernel: 1 = consecutive waves take consecutive blocks of the same sources (rows and windows overlap in cache: 2.8 %)
 #endif
+#ifndef JF_PAIR_ROTATE_PRIO
+#define JF_PAIR_ROTATE_PRIO 1  // persistent kernels: 1 = progress-ordered wave priorities (0: the hardware's oldest-first: -5.5 %)
+#endif
 #ifndef JF_UNIT_ZIGZAG
 #define JF_UNIT_ZIGZAG 1  // pair kernel: every other round of units in reverse order (balances expensive and cheap units)
 #endif

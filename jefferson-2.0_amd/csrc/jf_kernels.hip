@@ -728,6 +728,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
     const int G = P.G, SG = P.S / G;
     const int n_units = P.K * SG;
     const int a = lane & 3, i = lane >> 2;
+    [[maybe_unused]] int steps_done = 0;
 #pragma unroll 1
     for (int unit = blockIdx.x * kWavesPerWg + wave; unit < n_units; unit += gridDim.x * kWavesPerWg) {
 #if JF_UNIT_ORDER
@@ -744,6 +745,14 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
         for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
+#if JF_PAIR_ROTATE_PRIO
+            switch (3 - (steps_done++ & 3)) {  // progress-ordered priorities, see fused_pair_kernel
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
             const int item = b * P.S + s0 + g;
             const ItemDesc dl = load_desc(P.desc + item);  // scalar loads
             spatialise_item<NOUT>(P, &dl, P.pos + (size_t)item * 5, b, s0 + g, buf, s_tw, lane, acc);
@@ -920,9 +929,6 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
-#ifndef JF_PAIR_ROTATE_PRIO
-#define JF_PAIR_ROTATE_PRIO 1  // 1: progress-ordered wave priorities (0: the hardware's oldest-first: -5.5 %)
-#endif
 #ifndef JF_PAIR_OVERLAP
 #define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
                            // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
@@ -957,7 +963,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const unsigned my_pub = flags + 4 * half, his_pub = flags + 4 * (half ^ 1);
     const unsigned my_ack = flags + 8 + 4 * half, his_ack = flags + 8 + 4 * (half ^ 1);
     int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
-    int steps_done = 0;       // sources I have run the front half of
+    [[maybe_unused]] int steps_done = 0;  // sources I have run the front half of
     bool dead = false;        // a wait timed out (pair_wait)
     auto publish = [&]() {
         JF_WAVE_LDS_SYNC();
