@@ -223,7 +223,9 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     // resident pair (2048 on MI355X): larger groups mean fewer inverse transforms and fewer partial blocks for the
     // mix; 32 at full size measures the same as 16 (profiles/r02_experiments.md)
     const long long n_items = (long long)K * e->S;
+    static const int tune_g = getenv("JF_TUNE_G") ? atoi(getenv("JF_TUNE_G")) : 0;  // tuning runs: the automatic size
     const int G = e->src_group > 0 ? e->src_group
+                  : (tune_g > 0 && e->S % tune_g == 0) ? tune_g
                   : (e->S % 16 == 0 && n_items >= 32768) ? 16
                   : (e->S % 8 == 0 && n_items >= 16384) ? 8
                   : (e->S % 4 == 0 && n_items >= 8192) ? 4
