@@ -42,7 +42,8 @@ sys.path.insert(0, ROOT)
 
 B = 256
 SOURCES_PER_GPU = 1024
-BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "64"))
+# blocks per jf_batch_run: 128 = 0.74 s of audio per launch (64: -5.5 %, 256: +3 %; profiles/r02_experiments.md)
+BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "128"))
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md; needs packed FMAs: 2 x 78.6)
 TOL32 = 4e-7                # HIP vs float32 oracle, per source (tests/)
@@ -202,8 +203,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 256 warm-up steps (80 ms) because the first ~100 steps after an idle GPU run 10-15 % slower
-    # (clock ramp; profiles/r01_experiments.md), then 512 timed steps = 32 768 blocks x 1024 sources
-    ap.add_argument("--steps", type=int, default=512)
+    # (clock ramp; profiles/r01_experiments.md), then 256 timed steps = 32 768 blocks x 1024 sources
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
     ap.add_argument("--reverb", action="store_true",

@@ -21,10 +21,12 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if not any(n in row.get("Kernel_Name", "") for n in ("fused_pair_kernel", "fused_block_kernel")): continue
         tot[row["Counter_Name"]][0] += float(row["Counter_Value"]); tot[row["Counter_Name"]][1] += 1
+import os
+ITEMS = 1024 * int(os.environ.get("JF_BLOCKS_PER_STEP", "128"))   # source-blocks per launch of bench.py
 w = tot["SQ_WAVES"][0] / max(tot["SQ_WAVES"][1], 1)
 with open("$OUT/summary.txt", "w") as o:
     for c in sorted(tot):
         s, n = tot[c]
-        line = f"{c:28s} per-launch {s/n:14.0f}  per-wave {s/n/w:10.1f}  per-item {s/n/65536:9.2f}"
+        line = f"{c:28s} per-launch {s/n:14.0f}  per-wave {s/n/w:10.1f}  per-item {s/n/ITEMS:9.2f}"
         print(line); o.write(line + "\n")
 PY

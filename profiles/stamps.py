@@ -13,7 +13,7 @@ spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "jefferso
 wl = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(wl)
 hrir = np.load(os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
-S, KB = 1024, 64
+S, KB = 1024, 64   # 4096 units = two per resident pair (bench.py runs 128 blocks: four)
 eng = jf.Engine(256, 512, S, hrir=hrir, max_batch_blocks=KB)
 ids = np.arange(S)
 for s in ids:

@@ -1,6 +1,6 @@
 """The configurations BASELINE.json quotes, at their own sizes, against the oracle on a real MI355X:
 
-* configs[2] in the exact shape bench.py times (1024 moving sources x 64 blocks per launch, automatic source
+* configs[2] in the exact shape bench.py times (1024 moving sources x 128 blocks per launch, automatic source
   grouping = fused_pair_kernel<4> with G = 16), the whole mix against the float32 C oracle and sampled source
   groups against the float64 model;
 * the group kernel with more work units than resident wavefronts (every wave loops);
@@ -49,11 +49,11 @@ def _ordered_mix(part):
 
 
 def test_bench_shape_against_the_oracle(jf, hrir):
-    """Exactly what bench.py launches: S = 1024, K = 64 blocks per call, B = 256, default grouping, two
+    """Exactly what bench.py launches: S = 1024, K = 128 blocks per call, B = 256, default grouping, two
     consecutive calls (so that windows, counters and crossfade state carry).  Every block of the mix against the
-    float32 C oracle run on all 1024 sources; 8 sampled groups of 16 sources against the float64 model."""
+    float32 C oracle run on all 1024 sources; 4 sampled groups of 16 sources against the float64 model."""
     wl = _workload()
-    S, K, B, CALLS = 1024, 64, 256, 2
+    S, K, B, CALLS = 1024, 128, 256, 2
     ids = np.arange(S)
     pos = wl.trajectories(jf, ids, CALLS * K)
     sigs = [wl.source_signal_and_start(s)[0] for s in ids]   # the 1 s signals of the bench
@@ -94,7 +94,7 @@ def test_bench_shape_against_the_oracle(jf, hrir):
     assert np.abs(mix - omix).max() <= 6e-5
 
     # sampled groups against the float64 model (the truth for the tolerance)
-    for g in (0, 1, 13, 31, 32, 47, 62, 63):
+    for g in (0, 13, 32, 63):
         src = order[16 * g: 16 * g + 16].tolist()
         mod = model64.Model(B, 512, 16, hrir)
         for j, s in enumerate(src):
