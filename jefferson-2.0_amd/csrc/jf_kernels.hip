@@ -1435,7 +1435,7 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
     const float frac = 1 + fsvs * (float)((double)r * (double)r);
     {
         // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-        double c = (double)fsvs * (double)r / 513.0;
+        double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
         c -= floor(c);
         d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
     }
@@ -1520,7 +1520,7 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
         const float frac = 1 + fsvs * (float)((double)r * (double)r);
         {
             // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-            double c = (double)fsvs * (double)r / 513.0;
+            double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
             c -= floor(c);
             d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
         }
@@ -1557,16 +1557,22 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
         const int n_big = new_is_big ? n : n_o, n_small = new_is_big ? n_o : n;
         bool share = n > 0;
         int from = 0;
-        for (int i = 0; i < n_small && share; i++) {
-            int at = -1;
-            for (int k = from; k < n_big; k++)
-                if (at < 0 && big_rows[k] == small_rows[i]) at = k;
-            if (at < 0) {
-                share = false;
-            } else {
+        // fully unrolled with predicates (run-time array indices would put the arrays into scratch memory)
 #pragma unroll
-                for (int k = 0; k < 4; k++) ex_w[k] = k == at ? small_w[i] : ex_w[k];
-                from = at + 1;
+        for (int i = 0; i < 4; i++) {
+            const bool live_i = i < n_small && share;
+            int at = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (at < 0 && k >= from && k < n_big && big_rows[k] == small_rows[i]) at = k;
+            if (live_i) {
+                if (at < 0) {
+                    share = false;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ex_w[k] = k == at ? small_w[i] : ex_w[k];
+                    from = at + 1;
+                }
             }
         }
         if (share) {
