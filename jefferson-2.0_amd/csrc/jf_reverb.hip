@@ -27,11 +27,23 @@ JF_DEV float2 rv_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b
 JF_DEV float2 rv_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 JF_DEV float2 rv_mulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
-// acc += x * h (complex) as two packed f32 FMAs (jf_packed.h: the f32 vector peak needs v_pk_fma_f32;
-// written as asm because the compiler materialises the broadcast pairs with v_mov instead, +32 VGPRs for
-// a tile's window), and the element-wise acc += x .* h for the packed pair of real bins 0 and B.
+// acc += x * h (complex): four f32 FMAs.  The packed form (two v_pk_fma_f32 with op_sel broadcasts, pcmac of
+// jf_packed.h; JF_RV_SCALAR_MAC=0) runs the tiled kernel in the same time (profiles/r02_experiments.md section 4) but
+// needs even-aligned register pairs for the window: 128 VGPRs and 20 B of scratch where this form takes 124 and none.
 typedef c2 rv_v2;
-JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) { acc = pcmac(x, h, acc); }
+#ifndef JF_RV_SCALAR_MAC
+#define JF_RV_SCALAR_MAC 1
+#endif
+JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) {
+#if JF_RV_SCALAR_MAC
+    acc.x = __builtin_fmaf(x.x, h.x, acc.x);
+    acc.y = __builtin_fmaf(x.x, h.y, acc.y);
+    acc.x = __builtin_fmaf(-x.y, h.y, acc.x);
+    acc.y = __builtin_fmaf(x.y, h.x, acc.y);
+#else
+    acc = pcmac(x, h, acc);
+#endif
+}
 
 // Wave-private LDS hand-off (see jf_kernels.hip)
 #define JF_RV_SYNC()                                            \
@@ -287,6 +299,8 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
 // KB, so that the window's register indices are static).  The packed pair in bin 0 is carried as if it
 // were complex; mac_finish recomputes it from the compact copies.  Waves then each finish two blocks.
 constexpr int kTileWaves = 8;
+
+
 #ifndef JF_TILE_ATTR
 #define JF_TILE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU: 128 VGPRs
 #endif
@@ -300,44 +314,85 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bh = wave % BH, c = wave / BH;
-    const int kt = blockIdx.x / P.S, s = blockIdx.x - kt * P.S;
+    // The tiles of one source read the same stretch of its delay line, KB slots apart: they are given workgroup
+    // numbers that are equal mod 8 (same XCD, same L2) and next to each other in dispatch order, so that the later
+    // readers find the slots in that L2 instead of fetching them again.
+    int kt, s;
+    if (P.S % 8 == 0) {
+        const int n_tiles = gridDim.x / P.S, per = 8 * n_tiles;
+        const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+        kt = r >> 3;
+        s = 8 * grp + (r & 7);
+    } else {
+        kt = blockIdx.x / P.S;
+        s = blockIdx.x - kt * P.S;
+    }
     const int k0 = kt * KB;
 
-    const float2 *fdl = P.fdl + (size_t)s * P.Rg * B + 64 * bh + lane;
-    const float2 *hs = P.hspec + 64 * bh + lane;
+    // Addresses as a wave-uniform base (scalar registers) + one per-lane byte offset: the delay-line slot of X(-p) steps
+    // back by one per partition (with a wrap), the IR spectrum forward by one -- no division and no 64-bit vector
+    // arithmetic in the loop.
+    const char *fdl0 = reinterpret_cast<const char *>(P.fdl + (size_t)s * P.Rg * B);
+    const char *hsp = reinterpret_cast<const char *>(P.hspec);
+    unsigned voff = 8u * (64 * bh + lane);
+    asm volatile("" : "+v"(voff));
+    auto load_at = [&](const char *base) {
+        const float2 *q = reinterpret_cast<const float2 *>(base + voff);
+        return rv_v2{q->x, q->y};
+    };
+    auto slot_of = [&](int u) {  // delay-line slot of the spectrum of block k0 + u (u may be far in the past)
+        int slot = (P.head + k0 + u) % P.Rg;
+        return slot < 0 ? slot + P.Rg : slot;
+    };
     rv_v2 acc[KB], xr[KB];
 #pragma unroll
     for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
     const int chunk = (P.P + NC * KB - 1) / (NC * KB) * KB;
     const int pa = c * chunk;
     const int pb = pa + chunk < P.P ? pa + chunk : P.P;
-    auto load_x = [&](int u) {  // this lane's bin of the spectrum of block k0 + u (u may be far in the past)
-        int slot = (P.head + k0 + u) % P.Rg;
-        if (slot < 0) slot += P.Rg;
-        const float2 v = fdl[(size_t)slot * B];
-        return rv_v2{v.x, v.y};
-    };
     // window before the chunk's first partition: X(i - pa), i = 1..KB-1, kept at xr[(i - pa) mod KB] = xr[i]
 #pragma unroll
-    for (int i = 1; i < KB; i++) xr[i] = load_x(i - pa);
-    auto step = [&](int j, int p) {  // j = p mod KB, a constant after unrolling
-        const float2 hv = hs[(size_t)p * B];
-        const rv_v2 h = rv_v2{hv.x, hv.y};
-        xr[(KB - j) % KB] = load_x(-p);  // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
+    for (int i = 1; i < KB; i++) {
+#ifdef JF_RV_EXP_NOXLOAD  // timing experiment (wrong results): no delay-line loads
+        xr[i] = rv_v2{(float)i, (float)lane};
+#else
+        xr[i] = load_at(fdl0 + (size_t)slot_of(i - pa) * (B * 8));
+#endif
+    }
+    int xslot = slot_of(-pa);                     // slot of X(-p), p = pa
+    const char *hp = hsp + (size_t)pa * (B * 8);  // H_p
+    auto step = [&](int j) {  // j = p mod KB, a constant after unrolling
+#ifdef JF_RV_EXP_NOHLOAD  // timing experiment (wrong results): no IR spectrum loads
+        const rv_v2 h = rv_v2{(float)xslot, (float)lane};
+#else
+        const rv_v2 h = load_at(hp);
+#endif
+        // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
+#ifdef JF_RV_EXP_NOXLOAD
+        xr[(KB - j) % KB] = rv_v2{(float)xslot, (float)lane};
+#else
+        xr[(KB - j) % KB] = load_at(fdl0 + (size_t)(unsigned)xslot * (B * 8));
+#endif
+        xslot = xslot == 0 ? P.Rg - 1 : xslot - 1;
+        hp += B * 8;
 #pragma unroll
         for (int i = 0; i < KB; i++) rv_cmac(acc[i], xr[(i + KB - j) % KB], h);  // X(i - p)
     };
     int p0 = pa;
     for (; p0 + KB <= pb; p0 += KB) {  // straight-line groups: loads of later steps may move above earlier MACs
 #pragma unroll
-        for (int j = 0; j < KB; j++) step(j, p0 + j);
+        for (int j = 0; j < KB; j++) step(j);
     }
 #pragma unroll
     for (int j = 0; j < KB; j++)
-        if (p0 + j < pb) step(j, p0 + j);  // wave-uniform
+        if (p0 + j < pb) step(j);  // wave-uniform
 #pragma unroll
     for (int i = 0; i < KB; i++) s_red[c][i][64 * bh + lane] = make_float2(acc[i].x, acc[i].y);
     __syncthreads();
+#ifdef JF_RV_EXP_NOFINISH  // timing experiment (wrong results): one block of the tile finished instead of all
+    if (wave == 0) mac_finish<B, NC, true>(&s_red[0][0][0], KB * B, s_fft[wave], P, s, k0, lane);
+    return;
+#endif
 #pragma unroll 1
     for (int i = wave; i < KB; i += kTileWaves)
         if (k0 + i < P.K) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
