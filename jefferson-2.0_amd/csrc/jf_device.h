@@ -37,6 +37,9 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #ifndef JF_CHUNK_LOADS
 #define JF_CHUNK_LOADS 8  // table-row loads (16 B per lane each) a wave keeps in flight per round
 #endif
+#ifndef JF_TABLE_DISTANCE
+#define JF_TABLE_DISTANCE 1  // 1: distance factors from the twiddle table + small-angle correction; 0: minimax sin/cos
+#endif
 #ifndef JF_STAGE_LOADS
 #define JF_STAGE_LOADS 4  // pair kernel: table-row loads per stage of a half-filter; two stages are in flight
 #endif

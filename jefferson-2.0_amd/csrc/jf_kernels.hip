@@ -393,23 +393,52 @@ JF_DEV float2 distance_from_phase(unsigned p, float inv_frac) {
                        __uint_as_float(__float_as_uint(ss * inv_frac) ^ neg_im));
 }
 
+// The same from the FFT's own twiddle table (LDS, kTwU: exp(+2 pi i j / 1024), j = 0..511, rounded from double):
+// the phase is split into the nearest 1/1024 turn and a remainder |x| <= pi/1024, and the table value is corrected by
+// cos x - 1 = -x^2/2 (next term 4e-12) and sin x = x - x^3/6 (next term 2e-15) as small addends to it -- one rounding
+// on top of the table's, the argument needs no second float (x is known to 1.8e-10), 20 instructions and one LDS read
+// instead of 33.
+JF_DEV float2 distance_from_phase_tab(unsigned p, float inv_frac, const float2 *tw) {
+    const unsigned p2 = p + 0x200000u;  // + 1/2048 turn: round to the nearest table entry
+    const int rem = (int)(p2 & 0x3FFFFFu) - 0x200000;
+    const float2 t = tw[kTwU + ((p2 >> 22) & 511u)];  // (cos, sin) of entry j mod 512; entry j + 512 is its negative
+    const float x = (float)rem * 0x1.921fb6p-30f;      // 2 pi / 2^32
+    const float x2 = x * x;
+    const float sd = x * fmaf(x2, -0x1.555556p-3f, 1.0f);  // sin x
+    const float eh = 0.5f * x2;                            // 1 - cos x
+    const float re = t.x - fmaf(t.y, sd, t.x * eh);   // cos(a + x) = cos a - (cos a (1 - cos x) + sin a sin x)
+    const float im = t.y - fmaf(-t.x, sd, t.y * eh);  // sin(a + x) = sin a - (sin a (1 - cos x) - cos a sin x)
+    const float sf = __uint_as_float(__float_as_uint(inv_frac) | (p2 & 0x80000000u));  // inv_frac > 0; second half turn: -
+    return make_float2(re * sf, -im * sf);
+}
+
 // D of this lane's bins lane + 64 q, q = 0..7, and Re D[512].  Phase words by 64-bit accumulation (two adds per bin
 // instead of two quarter-rate 32-bit multiplies): hi32(k c mod 2^64), k = lane + 64 q; every bin evaluated on its own.
 // JF_FAST_DISTANCE (off): D[lane + 64 q] = D[lane] E^q with the wave-uniform step E = exp(-2 pi i 64 c), whose
 // powers lanes 0..8 evaluate and broadcast through scalar registers -- 135 fewer instructions per source-block, 4.5 %
 // of the batch kernel's time, but one more rounding per factor: on a full-scale signal (|y| ~ 1.2) the output error
 // against float64 grows from 2.06e-7 to 2.90e-7, past the reference's 2e-7 (profiles/r02_experiments.md).
-JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int lane, float2 (&dq)[8], float &d512x) {
+JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int lane, float2 (&dq)[8], float &d512x,
+                             [[maybe_unused]] const float2 *tw) {
     const unsigned long long c64 = ((unsigned long long)c_hi << 32) | c_lo;
 #ifndef JF_FAST_DISTANCE
     unsigned long long ph = (unsigned long long)(unsigned)lane * c64;
     const unsigned long long step = c64 << 6;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
+#if JF_TABLE_DISTANCE
+        dq[q] = distance_from_phase_tab((unsigned)(ph >> 32), inv_frac, tw);
+        if (q & 1) __builtin_amdgcn_sched_barrier(0);  // two table reads in flight, not eight (registers)
+#else
         dq[q] = distance_from_phase((unsigned)(ph >> 32), inv_frac);
+#endif
         ph += step;
     }
+#if JF_TABLE_DISTANCE
+    d512x = distance_from_phase_tab((unsigned)((c64 << 9) >> 32), inv_frac, tw).x;
+#else
     d512x = distance_from_phase((unsigned)((c64 << 9) >> 32), inv_frac).x;
+#endif
 #else
     const float2 d0 = distance_from_phase((unsigned)(((unsigned long long)(unsigned)lane * c64) >> 32), inv_frac);
     const float2 e = distance_from_phase((unsigned)(((unsigned long long)(unsigned)(lane & 15) * (c64 << 6)) >> 32), 1.0f);
@@ -618,7 +647,7 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     const float sinv = inv_frac * (1.0f / 2048.0f);
     float d512x;
     if (D_EARLY) {
-        distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
+        distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (b == P.K - 1) {
@@ -646,7 +675,7 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
-    if (!D_EARLY) distance_factors(c_hi, c_lo, sinv, lane, dq, d512x);
+    if (!D_EARLY) distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
 #pragma unroll
     for (int q = 0; q < 8; q++) xd[q] = cmul(X[q], dq[q]);
     const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
@@ -987,7 +1016,6 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     constexpr int B = 64 * NOUT;
     const int G = P.G, SG = P.S / G;
     const int n_units = P.K * SG;
-    const int a = lane & 3, i = lane >> 2;
     const int qb = 4 * half;
     const bool special = lane == 0 && half == 0;
     const unsigned lofs = 64u * qb + lane;
@@ -1155,10 +1183,11 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         float2 fr[NOUT];
         if (take) {
             await_partner();
+            const int ln = opaque(lane);  // or the addresses below are worked out at kernel entry and kept (spilled)
             float2 v[16];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float2 theirs = pmail[64 * q + lane];
+                const float2 theirs = pmail[64 * q + ln];
                 const float2 own = f2_of(half == 0 ? zko[q] : zkn[q]);
                 v[q] = half == 0 ? own : theirs;
                 v[4 + q] = half == 0 ? theirs : own;
@@ -1170,26 +1199,29 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int qn = 7 - j, q0 = (8 - j) & 7;  // bin read by lanes 1..63 / by lane 0
-                const float2 *pn = (qn < 4 ? lo : hi) + 64 * (qn & 3) + (64 - lane);
+                const float2 *pn = (qn < 4 ? lo : hi) + 64 * (qn & 3) + (64 - ln);
                 const float2 *p0 = (q0 < 4 ? lo : hi) + 64 * (q0 & 3);
-                v[8 + j] = *(lane == 0 ? p0 : pn);
+                v[8 + j] = *(ln == 0 ? p0 : pn);
             }
             consumed();
             ifft1024_lastq_wave<NOUT, true>(v, fr, buf, s_tw, opaque(lane));
         }
+        // per-lane frame numbers, fade weights and output offsets from an opaque lane index: worked out here, once per
+        // unit, instead of at kernel entry and held (or spilled) through the source loop
+        const int lf = opaque(lane), af = lf & 3, fi = lf >> 2;
         if (any_xfade) {
             if (half == 0) {
                 mail_free(npub);
 #pragma unroll
-                for (int j = 0; j < NOUT; j++) mail[64 * j + lane] = fr[j];
+                for (int j = 0; j < NOUT; j++) mail[64 * j + lf] = fr[j];
                 publish();
             } else {
                 await_partner();
 #pragma unroll
                 for (int j = 0; j < NOUT; j++) {
-                    const float2 old = pmail[64 * j + lane];
+                    const float2 old = pmail[64 * j + lf];
                     // kernels.cu:132-137
-                    const int n_out = i + 16 * (NOUT * a + j);  // frame inside the block
+                    const int n_out = fi + 16 * (NOUT * af + j);  // frame inside the block
                     const float fn = (float)n_out / ((float)B - 1.0f);
                     fr[j] = make_float2(old.x * (1.0f - fn) + fr[j].x * fn, old.y * (1.0f - fn) + fr[j].y * fn);
                 }
@@ -1199,7 +1231,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         if (half == 1) {
             float2 *out = reinterpret_cast<float2 *>(P.partial) + ((size_t)b * SG + sg) * B;
 #pragma unroll
-            for (int j = 0; j < NOUT; j++) out[i + 16 * (NOUT * a + j)] = fr[j];
+            for (int j = 0; j < NOUT; j++) out[fi + 16 * (NOUT * af + j)] = fr[j];
         }
 #ifdef JF_EXP_STAMPS
         if (stamper && round < 2) stamps[4 * wid + 1 + round] = __builtin_amdgcn_s_memrealtime();
@@ -1742,7 +1774,7 @@ __global__ __launch_bounds__(64) void stage_debug_kernel(const RingTable rt, int
     const unsigned c_hi = (unsigned)(dp->c_fix >> 32), c_lo = (unsigned)dp->c_fix;
     float2 dq[8];
     float d512x;
-    distance_factors(c_hi, c_lo, dp->inv_frac, lane, dq, d512x);
+    distance_factors(c_hi, c_lo, dp->inv_frac, lane, dq, d512x, s_tw);
     float2 *dout = dist + (size_t)blockIdx.x * kNc;
 #pragma unroll
     for (int q = 0; q < 8; q++) dout[lane + 64 * q] = dq[q];

@@ -22,15 +22,16 @@ for name, sig, blocks in (("noise 0.5", noise, 12), ("castanets", cast, 40)):
         m = model64.Model(256, 512, 1, hrir)
         for x in (e, m):
             x.set_signal(0, sig)
-        worst = peak = 0.0
+        worst = peak = sq = 0.0
         for b in range(blocks):
             for x in (e, m):
                 x.set_spherical(0, 10 * (b % 3), (45 + 7 * b) % 360, r)
             y, y64 = e.process_block(), m.process_block()
             worst = max(worst, np.abs(y - y64).max() / max(1.0, np.abs(y64).max()))
             peak = max(peak, np.abs(y64).max())
+            sq += float(np.mean((y - y64) ** 2))
         e.close()
-        print(f"{name:10s} r {r:4.2f}  peak {peak:6.3f}  max err / max(1,|y|) {worst:.3e}")
+        print(f"{name:10s} r {r:4.2f}  peak {peak:6.3f}  max err / max(1,|y|) {worst:.3e}  rms err {np.sqrt(sq / blocks):.3e}")
 # the stage tap: D against float64, in ulps of its modulus
 coords = [(0.0, 0.0, 0.05), (0.5, 0.0, 0.0), (0.3, 0.4, 1.2), (0.0, 3.0, 4.0), (2.0, -1.0, 7.0), (10.0, 5.0, -20.0),
           (60.0, 0.0, 80.0), (0.0, 100.0, 0.0), (57.7, 57.7, 57.8), (1e-3, 0.0, 0.0)]
@@ -41,4 +42,5 @@ e.close()
 for i, c in enumerate(coords):
     d64 = model64.distance_factor(c, 513)
     ulp = np.abs(d64[0]) * 2.0 ** -23
-    print(f"D tap {c}: max err {np.abs(D[i, :512] - d64[:512]).max() / ulp:.2f} ulp of |D|")
+    err = np.abs(D[i, :512] - d64[:512]) / ulp
+    print(f"D tap {c}: max err {err.max():.2f} ulp of |D|, rms {np.sqrt(np.mean(err ** 2)):.3f}")
