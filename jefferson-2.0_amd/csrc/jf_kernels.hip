@@ -1335,6 +1335,7 @@ JF_DEV bool dev_interp_corrected(const RingTable &rt, float ele, float azi, int 
     const int r0 = (int)q + 4;
     const int ring[2] = {r0, on_ring ? r0 : r0 + 1};
     const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+#pragma unroll
     for (int j = 0; j < 2; j++) {
         const int r = ring[j];
         const float d = rt.inc[r];
@@ -1513,10 +1514,18 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
             w[0] = 1.0f;
             n = ok ? 1 : 0;
         }
-    } else if (!old_half) {
-        n = dev_interp_terms(rt, ele, azi, rows, w, corrected);
-    } else if (moved) {
-        n = dev_interp_terms(rt, old_ele, old_azi, rows, w, corrected);
+    } else {
+        // ONE call for both lanes of a pair, each with its own position: as two calls under `old_half` the wave ran the
+        // rule twice, once with the even and once with the odd lanes masked off
+        const float e_in = old_half ? old_ele : ele, a_in = old_half ? old_azi : azi;
+        const int n_in = dev_interp_terms(rt, e_in, a_in, rows, w, corrected);
+        const bool used = !old_half || moved;  // a source that did not move has no old set
+        n = used ? n_in : 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            rows[t] = used ? rows[t] : 0;
+            w[t] = used ? w[t] : 0.0f;
+        }
     }
     // the other half's result (the even lane needs the old set for the pair-kernel layout)
     const int n_other = __shfl_xor(n, 1);
