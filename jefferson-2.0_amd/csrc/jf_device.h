@@ -59,7 +59,7 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 #define JF_PAIR_ROTATE_PRIO 1  // persistent kernels: 1 = progress-ordered wave priorities (0: the hardware's oldest-first: -5.5 %)
 #endif
 #ifndef JF_UNIT_ZIGZAG
-#define JF_UNIT_ZIGZAG 1  // pair kernel: every other round of units in reverse order (balances expensive and cheap units)
+#define JF_UNIT_ZIGZAG 2  // order of the units over the rounds of the pair kernel (see there): 2 rotated, 1 zigzag, 0 plain
 #endif
 constexpr int kWavesPerWg = JF_WAVES_PER_WG;
 

@@ -1020,13 +1020,19 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const bool special = lane == 0 && half == 0;
     const unsigned lofs = 64u * qb + lane;
     const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
-    // Rounds of units over the persistent pairs, every other round in reverse (JF_UNIT_ZIGZAG): the first blocks of a
-    // call gather their windows the slow way, and a pair whose unit came from the expensive end of one round takes
-    // the cheap end of the next.
+    // Rounds of units over the persistent pairs.  Units differ in cost -- the first blocks of a call gather their windows
+    // the slow way -- and so do pairs: the SIMD's arbiter serves its oldest wave first on a tie, and the last pairs of a
+    // workgroup leave the kernel ~12 us after the first (profiles/stamps.py).  JF_UNIT_ZIGZAG = 2: every round the
+    // pair -> unit map is rotated by one workgroup, so the expensive units (slots 0..2 of a group's blocks) always go to
+    // pairs 0..2 of a workgroup, and to another workgroup every round; 1: every other round in reverse (the expensive
+    // units then alternate between the first and the LAST pairs of a workgroup: 1.3 % slower); 0: plain.
     const int n_pairs = gridDim.x * kPairsPerWg, my_pair = blockIdx.x * kPairsPerWg + pair;
 #pragma unroll 1
     for (int round = 0; round * n_pairs < n_units; round++) {
-#if JF_UNIT_ZIGZAG
+#if JF_UNIT_ZIGZAG == 2
+        // rotation by one workgroup per round: the pair-in-workgroup index of a unit's slot stays what it is
+        const int unit = round * n_pairs + (my_pair + 8 * round) % n_pairs;
+#elif JF_UNIT_ZIGZAG
         const int unit = (round & 1) ? (round + 1) * n_pairs - 1 - my_pair : round * n_pairs + my_pair;
 #else
         const int unit = round * n_pairs + my_pair;
