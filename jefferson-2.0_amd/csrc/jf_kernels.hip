@@ -955,6 +955,9 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
         filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
 }
 
+#ifndef JF_PAIR_MIX_AGES
+#define JF_PAIR_MIX_AGES 1  // which two waves of a workgroup form a pair: 1 = w and 15 - w, 2 = same SIMD, 0 = 2i and 2i + 1
+#endif
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
@@ -977,7 +980,19 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Which waves pair up.  The SIMD's arbiter serves its oldest wave first on a tie, and a pair runs at the pace of its
+    // slower wave: as (2i, 2i + 1) the last pairs of a workgroup left the kernel 12 us after the first (profiles/stamps.py)
+    // and the SIMDs ran half empty meanwhile.  As (w, 15 - w) -- an old wave with a young one, on different SIMDs -- every
+    // pair is held back alike: units take 5 % longer, the pairs leave within 4 us of each other, the kernel is 5 % shorter.
+#if JF_PAIR_MIX_AGES == 2
+    // both waves of a pair on one SIMD (wave w runs on SIMD w % 4), oldest with youngest and the middle two together: 1 % slower
+    const int pair = 2 * (wave & 3) + (((wave >> 2) == 1 || (wave >> 2) == 2) ? 1 : 0), half = wave >> 3;
+    static_assert(kPairsPerWg == 8, "16 waves");
+#elif JF_PAIR_MIX_AGES
+    const int pair = wave < kPairsPerWg ? wave : 2 * kPairsPerWg - 1 - wave, half = wave < kPairsPerWg ? 0 : 1;
+#else
     const int pair = wave >> 1, half = wave & 1;
+#endif
 #ifdef JF_EXP_STAMPS  // timing experiment: when does every wave start and finish (100 MHz real-time counter)
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(P.err) + 16);
     const int wid = blockIdx.x * kPairsPerWg + pair;  // pair index: 4 stamps per pair, written by its wave 1
