@@ -299,6 +299,9 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
 // KB, so that the window's register indices are static).  The packed pair in bin 0 is carried as if it
 // were complex; mac_finish recomputes it from the compact copies.  Waves then each finish two blocks.
 constexpr int kTileWaves = 8;
+#ifndef JF_RV_PROGRESS_PRIO
+#define JF_RV_PROGRESS_PRIO 1
+#endif
 
 
 #ifndef JF_TILE_ATTR
@@ -379,9 +382,24 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
         for (int i = 0; i < KB; i++) rv_cmac(acc[i], xr[(i + KB - j) % KB], h);  // X(i - p)
     };
     int p0 = pa;
+    [[maybe_unused]] int groups_done = 0;
     for (; p0 + KB <= pb; p0 += KB) {  // straight-line groups: loads of later steps may move above earlier MACs
 #pragma unroll
-        for (int j = 0; j < KB; j++) step(j);
+        for (int j = 0; j < KB; j++) {
+#if JF_RV_PROGRESS_PRIO
+            // progress-ordered priorities (see fused_pair_kernel): the SIMD's arbiter serves its oldest wave first, and a
+            // workgroup finishes with its slowest wave
+            if (j % (KB / JF_RV_PROGRESS_PRIO) == 0) {
+                switch (3 - (groups_done++ & 3)) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+#endif
+            step(j);
+        }
     }
 #pragma unroll
     for (int j = 0; j < KB; j++)
