@@ -901,7 +901,7 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #ifdef JF_EXP_NOROWLOAD  // timing experiment (wrong results): the filter arithmetic without its table loads
-                h[st & 1][q][t] = make_float4(xh[q].x, xh[q].y, (float)boff, (float)t);
+                h[st & 1][q][t] = make_float4((float)(st + q), 1.0f, (float)boff, (float)t);
 #else
                 h[st & 1][q][t] =
                     *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff);
