@@ -400,7 +400,11 @@ def main():
                 "flop_model": "jefferson-2.0_amd/workload.py flops_window (textbook counts; tests/test_abi.py)",
                 "table_rows_per_source_block": rows / items,
                 "other_kernels": other,
-                "why_not_hbm": "the 5.8 MB HRTF table is cache-resident: compulsory HBM bytes are ~1.3 KB per source-block"}
+                "why_not_hbm": "the 5.8 MB HRTF table is cache-resident: compulsory HBM bytes are ~1.3 KB per source-block",
+                # what the vector unit sustains on this chip with every CU busy (profiles/micro/valu_rate.hip, 4 waves per
+                # SIMD, register operands): the spec figure assumes 2.4 GHz, the clock under that load is ~1.9-2.0 GHz
+                "peak_sustained_measured": {"v_fma_f32": 120.2, "v_pk_fma_f32": 137.4, "unit": "TFLOP/s",
+                                            "frac_of_v_fma_f32": tf / 120.2}}
         # SURVEY.md 8(d)'s algorithmic bytes (table rows re-read per item): a CACHE-level rate, not an HBM rate
         roof["algorithmic_cache_gbps"] = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         roof["algorithmic_bytes_per_launch"] = abytes / launches
@@ -431,10 +435,17 @@ def main():
         roof["hbm"] = hbm
         if fpmc and "SQ_INSTS_VALU" in fpmc:
             iss = {"valu_insts_per_source_block": fpmc["SQ_INSTS_VALU"] / (S * KB), "source": pmc_note}
-            if fpmc.get("GRBM_GUI_ACTIVE") and fpmc.get("SQ_ACTIVE_INST_VALU"):
-                # SQ_ACTIVE_INST_VALU counts 4-cycle units summed over the 1024 SIMDs (one per instruction of a wave that
-                # is alone on its SIMD); GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                iss["valu_busy_share_of_kernel_time"] = fpmc["SQ_ACTIVE_INST_VALU"] / 1024 * 4 / (fpmc["GRBM_GUI_ACTIVE"] / 8)
+            if fpmc.get("GRBM_GUI_ACTIVE") and fpmc.get("SQ_INSTS_VALU"):
+                # A SIMD retires one wave64 vector instruction per ~2 cycles when two or more of its waves have one
+                # ready (MI355X_MICROARCH.md; profiles/micro/valu_rate.hip measures 1.09 ns at 4 waves per SIMD), one
+                # per 4 cycles from a single wave; packed-f32 instructions take twice that.  GRBM_GUI_ACTIVE is summed
+                # over the 8 XCDs, SQ_INSTS_VALU over the 1024 SIMDs.
+                per_simd = fpmc["SQ_INSTS_VALU"] / 1024
+                cycles = fpmc["GRBM_GUI_ACTIVE"] / 8
+                iss["valu_pipe_busy_share_at_2_cycles_per_inst"] = per_simd * 2 / cycles
+                iss["valu_issue_share_at_4_cycles_per_inst"] = per_simd * 4 / cycles
+                iss["valu_rate_note"] = ("2 cycles: what the SIMD needs with >= 2 waves ready (plain f32; packed f32 twice "
+                                         "that); 4 cycles: what one wave alone can issue")
             if fpmc.get("SQ_INSTS_VMEM_RD"):
                 iss["vmem_loads_per_source_block"] = fpmc["SQ_INSTS_VMEM_RD"] / (S * KB)
             if fpmc.get("SQ_WAVE_CYCLES") and fpmc.get("SQ_WAIT_ANY"):
@@ -488,10 +499,12 @@ def main():
                            "unit": "GB/s", "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None})
             else:
                 # block tiles: each delay-line slot is read once per tile of 16 blocks and stays in the Infinity
-                # Cache; the bound is fp32 FMA issue (8 flops per complex multiply-accumulate, packed FMAs)
+                # Cache; the bound is fp32 FMA issue (8 flops per complex multiply-accumulate, four FMAs)
                 tfr = 8.0 * macs / t / 1e12 if t > 0 else 0.0
                 rv.update({"bound": "valu-fp32", "achieved": tfr, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                            "frac": tfr / FP32_VECTOR_PEAK_TF, "traffic": None,
+                           "peak_sustained_measured": {"v_fma_f32": 120.2, "v_pk_fma_f32": 137.4, "unit": "TFLOP/s",
+                                                       "frac_of_v_fma_f32": tfr / 120.2},
                            "algorithmic_cache_gbps": rb / t / 1e9 if t > 0 else 0.0,
                            "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
