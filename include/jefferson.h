@@ -262,11 +262,16 @@ int jf_debug_set_rt_max_sources(jf_engine *e, int n);
 /* ';'-separated names of the kernels the last processing call launched, in launch order (bench.py labels its
  * roofline with them).  The string is owned by the engine and valid until the next call of this function. */
 const char *jf_debug_last_kernels(jf_engine *e);
-/* G the last batch pipeline run used (1 = fused_block_kernel, > 1 = fused_group_kernel). */
+/* G the last batch pipeline run used (1 = fused_block_kernel, > 1 = fused_pair_kernel). */
 int jf_debug_last_source_group(const jf_engine *e);
 /* Caps the persistent grid of the fused kernel at `workgroups` (0 = what the device holds): with a small cap every
  * wavefront loops over several work units, which full-size calls do only beyond 4096 units. */
 int jf_debug_set_grid_limit(jf_engine *e, int workgroups);
+/* jf_batch_run prepares the descriptors of the window that FOLLOWS its own in the uploaded trajectory inside its mix
+ * launch (mix_prep_kernel), and the next jf_batch_run uses them if it asks for exactly that window; anything else
+ * that runs or changes the engine's state in between discards them.  on = 0 switches this off (every run launches
+ * prep_kernel and mix_kernel); default on.  Results are bit-identical either way. */
+int jf_debug_set_prep_ahead(jf_engine *e, int on);
 /*
  * Stage taps the reference's own tests compare (precision_test.cu:60-75 distance factor, :225-241 and :374-404
  * weighted spectra), through the device code of the fused kernels.  positions[n][JF_POS_FLOATS];

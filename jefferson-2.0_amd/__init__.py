@@ -86,6 +86,7 @@ _SIGS = {
     "jf_debug_last_kernels": (C.c_char_p, [C.c_void_p]),
     "jf_debug_last_source_group": (C.c_int, [C.c_void_p]),
     "jf_debug_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_set_prep_ahead": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_stage_taps": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _f, _f]),
     "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jf_debug_set_rt_max_sources": (C.c_int, [C.c_void_p, C.c_int]),
@@ -333,6 +334,9 @@ class Engine:
 
     def set_grid_limit(self, wgs):
         self._chk(lib().jf_debug_set_grid_limit(self.h, int(wgs)))
+
+    def set_prep_ahead(self, on):
+        self._chk(lib().jf_debug_set_prep_ahead(self.h, int(bool(on))))
 
     def last_block_peak(self):
         return float(lib().jf_last_block_peak(self.h))

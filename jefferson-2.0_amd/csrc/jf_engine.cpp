@@ -30,6 +30,8 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
                               const float4 *d_htab, const float2 *d_tw, float2 *d_dist, float2 *d_spec,
                               hipStream_t st);
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
+hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, int K, int B, const RingTable &rt, int mode,
+                           const float *d_pos_next, ItemDesc *d_desc_next, int S, int K_next, int canon, hipStream_t st);
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
                            hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
@@ -67,6 +69,19 @@ struct jf_engine {
     SrcState *d_state[2] = {nullptr, nullptr};
     float *d_hist[2] = {nullptr, nullptr};
     ItemDesc *d_desc = nullptr;
+    // Descriptors of the window that follows the last jf_batch_run, written by that run's mix launch (mix_prep_kernel)
+    // into the second buffer; the next run takes them instead of launching prep_kernel if it asks for exactly that window
+    // of the same trajectory in the same mode and layout -- anything else that runs or touches the state in between
+    // clears `ahead.valid`.
+    ItemDesc *d_desc_ahead = nullptr;
+    struct {
+        bool valid = false;
+        int first = 0, K = 0, mode = 0, canon = 0;
+        unsigned long traj_gen = 0;
+    } ahead;
+    unsigned long traj_gen = 0;  // bumped by every jf_batch_upload_positions
+    bool prep_ahead = true;      // jf_debug_set_prep_ahead
+    bool last_prep_skipped = false, last_mix_prep = false;  // what the last run launched (jf_debug_last_kernels)
     float *d_partial = nullptr;
     float *d_mix = nullptr;
     float *d_pos_rt = nullptr;  // [S][5]
@@ -207,7 +222,8 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
 }
 
 // prep -> [reverb] -> fused -> mix on the engine stream, K blocks starting at d_pos.
-int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
+// first_block: index of d_pos's first block in the uploaded trajectory (jf_batch_run), -1 for positions from elsewhere.
+int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int first_block = -1) {
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
     if (e->profiling) {
@@ -234,8 +250,16 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     FusedParams P;
     P.G = (e->S % G == 0) ? G : 1;
     const int canon = P.G > 1;  // descriptors in the pair-kernel layout
+    const int mode_now = kernel_mode(e);
+    // per-kernel timing (profiling >= 2) keeps prep and mix as launches of their own
+    const bool have = e->ahead.valid && e->profiling < 2 && first_block >= 0 && e->ahead.first == first_block &&
+                      e->ahead.K == K && e->ahead.mode == mode_now && e->ahead.canon == canon &&
+                      e->ahead.traj_gen == e->traj_gen;
+    e->ahead.valid = false;
+    e->last_prep_skipped = have;
+    if (have) std::swap(e->d_desc, e->d_desc_ahead);
     if (ep) JF_HIP(e, hipEventRecord(ep->a, e->stream));
-    JF_HIP(e, launch_prep(e->rt, kernel_mode(e), d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
+    if (!have) JF_HIP(e, launch_prep(e->rt, mode_now, d_pos, e->d_state[p], e->d_desc, e->S, K, canon, e->stream));
     if (ep) JF_HIP(e, hipEventRecord(ep->b, e->stream));
     {
         const int rc = run_reverb_stage(e, p, K);
@@ -255,7 +279,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     P.K = K;
     P.B = e->B;
     e->last_group = P.G;
-    P.mode = kernel_mode(e);
+    P.mode = mode_now;
     P.err = e->hd_err;
     P.order = e->d_order;
     int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
@@ -264,7 +288,21 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out) {
     JF_HIP(e, launch_fused(P, max_wgs, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
     if (em) JF_HIP(e, hipEventRecord(em->a, e->stream));
-    JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
+    // the window that follows in the trajectory, if there is a whole one: its descriptors ride along with the mix
+    const bool ahead_ok = e->prep_ahead && e->profiling < 2 && first_block >= 0 && first_block + 2 * K <= e->traj_blocks;
+    e->last_mix_prep = ahead_ok;
+    if (ahead_ok) {
+        JF_HIP(e, launch_mix_prep(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->rt, mode_now,
+                                  d_pos + (size_t)K * e->S * 5, e->d_desc_ahead, e->S, K, canon, e->stream));
+        e->ahead.valid = true;
+        e->ahead.first = first_block + K;
+        e->ahead.K = K;
+        e->ahead.mode = mode_now;
+        e->ahead.canon = canon;
+        e->ahead.traj_gen = e->traj_gen;
+    } else {
+        JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
+    }
     if (em) JF_HIP(e, hipEventRecord(em->b, e->stream));
     if (e->profiling) e->ev_used++;
     e->cur = p ^ 1;
@@ -305,6 +343,7 @@ void free_reverb(jf_engine *e) {
 
 // zero one source's (or every source's, src < 0) window, counters and reverb state
 int reset_sources(jf_engine *e, int src) {
+    e->ahead.valid = false;  // the old position of the next block changes
     const size_t s0 = src < 0 ? 0 : (size_t)src, ns = src < 0 ? (size_t)e->S : 1;
     const int p = e->cur;
     JF_HIP(e, hipMemset(e->d_hist[p] + s0 * kN, 0, sizeof(float) * kN * ns));
@@ -337,6 +376,7 @@ void destroy_engine(jf_engine *e) {
         (void)hipFree(e->d_hist[i]);
     }
     (void)hipFree(e->d_desc);
+    (void)hipFree(e->d_desc_ahead);
     (void)hipFree(e->d_partial);
     (void)hipFree(e->d_mix);
     (void)hipFree(e->d_pos_rt);
@@ -397,6 +437,8 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             JF_HIP(e, hipMemset(e->d_hist[i], 0, sizeof(float) * S * kN));
         }
         JF_HIP(e, hipMalloc(&e->d_desc, sizeof(ItemDesc) * S * K));
+        JF_HIP(e, hipMalloc(&e->d_desc_ahead, sizeof(ItemDesc) * S * K));
+        if (const char *v = getenv("JF_PREP_AHEAD")) e->prep_ahead = atoi(v) != 0;  // tuning runs (jf_debug_set_prep_ahead)
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
@@ -667,6 +709,7 @@ int jf_submit_block(jf_engine *e) {
             // few sources: ONE launch does descriptors, spatialisation and mix, reading the positions
             // from and writing the stereo block to pinned host memory -- no copies, one sync
             const int p = e->cur;
+            e->ahead.valid = false;  // this block moves every source's old position
             {
                 const int rc = run_reverb_stage(e, p, 1);  // the wet ring is then this block's signal
                 if (rc) return rc;
@@ -872,6 +915,8 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     DeviceGuard bind(e);
     if (!e || total_blocks <= 0 || !positions) return fail(e, JF_ERR_ARG, "bad trajectory");
     JF_HIP(e, hipStreamSynchronize(e->stream));
+    e->traj_gen++;
+    e->ahead.valid = false;
     const size_t bytes = sizeof(float) * 5 * (size_t)e->S * (size_t)total_blocks;
     if (total_blocks > e->traj_blocks) {
         (void)hipFree(e->d_traj);
@@ -910,7 +955,8 @@ int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) 
     if (first_block < 0 || first_block + n_blocks > e->traj_blocks)
         return fail(e, JF_ERR_ARG, "window outside the uploaded trajectory");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
-    return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix);
+    return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix,
+                      first_block);
     });
 }
 
@@ -1124,7 +1170,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
     try {
         const std::string nb = std::to_string(e->B / 64), bs = std::to_string(e->B);
         std::string k;
-        if (!e->last_rt) k = "prep_kernel;";
+        if (!e->last_rt && !e->last_prep_skipped) k = "prep_kernel;";
         if (e->rv_P > 0) {
             k += "reverb_fft_kernel<" + bs + ">;";
             const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
@@ -1132,12 +1178,22 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
         }
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
-        else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb + ">;mix_kernel";
+        else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb +
+                  (e->last_mix_prep ? ">;mix_prep_kernel" : ">;mix_kernel");
         e->kernels = k;
         return e->kernels.c_str();
     } catch (...) {
         return "";
     }
+}
+
+int jf_debug_set_prep_ahead(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    e->prep_ahead = on != 0;
+    e->ahead.valid = false;
+    return JF_OK;
+    });
 }
 
 int jf_debug_set_grid_limit(jf_engine *e, int workgroups) {

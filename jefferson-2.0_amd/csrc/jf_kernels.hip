@@ -1269,13 +1269,11 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 // their own wave, then the 16 group sums are added in group order.  One workgroup
 // = 64 consecutive output floats of one block x 16 source groups.
 constexpr int kMixGroups = 16;
-__global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__restrict__ partial,
-                                                              float *__restrict__ mix, int S, int K,
-                                                              int blk /* 2B */) {
-    __shared__ float red[kMixGroups][64];
+JF_DEV void mix_body(const float *__restrict__ partial, float *__restrict__ mix, int S, int blk /* 2B */, int wg,
+                     float (&red)[kMixGroups][64]) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int chunks = blk / 64;
-    const int b = blockIdx.x / chunks, n = (blockIdx.x - b * chunks) * 64 + lane;
+    const int b = wg / chunks, n = (wg - b * chunks) * 64 + lane;
     const int per = (S + kMixGroups - 1) / kMixGroups;
     const int s0 = grp * per, s1 = min(S, s0 + per);
     const float *p = partial + (size_t)b * S * blk + n;
@@ -1289,6 +1287,12 @@ __global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__res
         for (int g = 1; g < kMixGroups; g++) t += red[g][lane];
         mix[(size_t)b * blk + n] = t;
     }
+}
+__global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ mix, int S, int K,
+                                                              int blk /* 2B */) {
+    __shared__ float red[kMixGroups][64];
+    mix_body(partial, mix, S, blk, blockIdx.x, red);
 }
 
 // ----------------------------------------------- indices and weights (a2,a3)
@@ -1501,9 +1505,10 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
 // Two adjacent lanes per item: the even one does the new position's rule and the distance part, the odd one
 // the old position's rule (the kernel is a short dependent chain per thread at one wave per SIMD: halving
 // the chain halves its time).  Same arithmetic as make_desc, which the real-time kernel uses.
-__global__ void prep_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
-                            const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K, int canon) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+// st == nullptr: the window continues the trajectory (the block before its first one is at pos - 5 S), as it does for a
+// window prepared ahead of its run (mix_prep_kernel); else the old position of block 0 is the state the last run left.
+JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ pos, const SrcState *__restrict__ st,
+                      ItemDesc *__restrict__ desc, int S, int K, int canon, int tid) {
     const int item = tid >> 1;
     const bool old_half = tid & 1;
     const bool live = item < S * K;  // both lanes of a pair agree; no early return before the shuffles
@@ -1512,7 +1517,7 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
     const float *p = pos + (size_t)it * 5;
     const float ele = p[0], azi = p[1];
     float old_ele, old_azi;
-    if (b == 0) {
+    if (b == 0 && st != nullptr) {
         old_ele = st[s].old_ele;
         old_azi = st[s].old_azi;
     } else {
@@ -1661,6 +1666,31 @@ __global__ void prep_kernel(const RingTable rt, int mode, const float *__restric
     }
     d.flags = flags;
     d.n_new = n;
+}
+
+__global__ void prep_kernel(const RingTable rt, int mode, const float *__restrict__ pos,
+                            const SrcState *__restrict__ st, ItemDesc *__restrict__ desc, int S, int K, int canon) {
+    prep_body(rt, mode, pos, st, desc, S, K, canon, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// mix_kernel of one run and prep_kernel of the next window of the trajectory in ONE launch (the first workgroups
+// prepare, the other n_mix mix): both are short chains at low occupancy, and one after the other they leave the GPU idle
+// twice per run.  The engine launches this form when the run came from jf_batch_run and the window that follows it
+// lies inside the uploaded trajectory; the descriptors go to the engine's other descriptor buffer and are used if the
+// next run asks for exactly that window (jf_engine.cpp: run_blocks).
+__global__ __launch_bounds__(64 * kMixGroups) void mix_prep_kernel(const float *__restrict__ partial,
+                                                                   float *__restrict__ mix, int S_groups, int blk,
+                                                                   int n_mix, const RingTable rt, int mode,
+                                                                   const float *__restrict__ pos,
+                                                                   ItemDesc *__restrict__ desc, int S, int K, int canon) {
+    __shared__ float red[kMixGroups][64];
+    // the preparing workgroups first: theirs is the long chain (12 us against 2.7 us per round of mixing workgroups),
+    // and dispatched last they would start when the mix is nearly over
+    const int n_prep = (int)gridDim.x - n_mix;
+    if ((int)blockIdx.x < n_prep)
+        prep_body(rt, mode, pos, nullptr, desc, S, K, canon, (int)blockIdx.x * (64 * kMixGroups) + (int)threadIdx.x);
+    else
+        mix_body(partial, mix, S_groups, blk, (int)blockIdx.x - n_prep, red);
 }
 
 __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const float *azi, int *rows,
@@ -1954,6 +1984,17 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
     case 4: hipLaunchKernelGGL(rt_block_kernel<4>, grid, block, 0, st, P, rt, pos, o); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, int K, int B, const RingTable &rt, int mode,
+                           const float *d_pos_next, ItemDesc *d_desc_next, int S, int K_next, int canon, hipStream_t st) {
+    const int blk = 2 * B;
+    const int n_mix = K * (blk / 64);
+    const int per = 64 * kMixGroups;
+    const int n_prep = (2 * S * K_next + per - 1) / per;
+    hipLaunchKernelGGL(mix_prep_kernel, dim3(n_mix + n_prep), dim3(per), 0, st, d_partial, d_mix, S_groups, blk, n_mix, rt,
+                       mode, d_pos_next, d_desc_next, S, K_next, canon);
     return hipGetLastError();
 }
 

@@ -381,3 +381,75 @@ def test_pair_kernel_odd_group_sizes(jf, hrir, castanets, B, G):
     assert np.abs(want).max() > 0.1
     assert np.abs(outs[G] - outs[1]).max() <= TOL32 * S / 4
     assert np.abs(outs[G] - want).max() <= TOL32 * S / 4
+
+
+def test_descriptors_prepared_ahead_change_nothing(jf, hrir, castanets):
+    """jf_batch_run writes the descriptors of the window that follows its own inside its mix launch (mix_prep_kernel) and
+    the next run uses them if it asks for exactly that window.  Two engines, one with that switched off, through
+    sequential windows, a jump, another window size, a mode switch, a source reset and a new trajectory: every block
+    bit-identical, and the kernel lists say when the shortcut was taken."""
+    wl = _workload()
+    S, B, K, T = 32, 128, 8, 64
+    ids = np.arange(S)
+    pos = wl.trajectories(jf, ids, T)
+    a = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    b = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    b.set_prep_ahead(False)
+    for e in (a, b):
+        for s in ids:
+            e.set_signal(int(s), castanets[1000 * s: 1000 * s + 30000])
+        e.set_source_group(4)     # the pair kernel (canonical descriptors)
+        e.upload_positions(pos)
+
+    def run(first, k):
+        out = []
+        for e in (a, b):
+            e.batch_run(first, k)
+            e.synchronize()
+            out.append(e.read_device(e.mix_device_ptr(), (k, 2 * B)))
+        assert np.array_equal(out[0], out[1]), (first, k)
+        assert np.abs(out[0]).max() > 1e-3
+        return a.last_kernels(), b.last_kernels()
+
+    ka, kb = run(0, K)
+    assert ka[0] == "prep_kernel" and ka[-1] == "mix_prep_kernel" and kb == ["prep_kernel", "fused_pair_kernel<2>", "mix_kernel"]
+    ka, kb = run(K, K)            # the window prepared ahead
+    assert ka == ["fused_pair_kernel<2>", "mix_prep_kernel"] and kb[0] == "prep_kernel"
+    ka, _ = run(2 * K, K)
+    assert "prep_kernel" not in ka
+    ka, _ = run(5 * K, K)         # a jump: the prepared window is not the one asked for
+    assert ka[0] == "prep_kernel"
+    ka, _ = run(6 * K, K)
+    assert "prep_kernel" not in ka
+    ka, _ = run(7 * K, K)         # the last window of the trajectory: nothing follows it
+    assert ka == ["fused_pair_kernel<2>", "mix_kernel"]
+    ka, _ = run(0, 4)             # another window size
+    assert ka[0] == "prep_kernel"
+    ka, _ = run(4, 4)
+    assert "prep_kernel" not in ka
+    ka, _ = run(8, K)             # prepared for 4 blocks, asked for 8
+    assert ka[0] == "prep_kernel"
+    for e in (a, b):
+        e.set_mode(jf.JF_MODE_FD_BASIC)
+    ka, _ = run(16, K)            # prepared in the other mode
+    assert ka[0] == "prep_kernel"
+    ka, _ = run(24, K)
+    assert "prep_kernel" not in ka
+    for e in (a, b):
+        e.set_mode(jf.JF_MODE_FD_COMPLEX)
+        e.reset(3)                # its old position is (0, 0) again: the prepared descriptors assumed the trajectory's
+    ka, _ = run(32, K)
+    assert ka[0] == "prep_kernel"
+    for e in (a, b):
+        e.process_block()         # a per-block call in between moves every old position
+    ka, _ = run(40, K)
+    assert ka[0] == "prep_kernel"
+    pos2 = pos[::-1].copy()
+    for e in (a, b):
+        e.upload_positions(pos2)  # same window indices, another trajectory
+    ka, _ = run(48, K)
+    assert ka[0] == "prep_kernel"
+    ka, _ = run(56, K)
+    assert "prep_kernel" not in ka
+    a.close()
+    b.close()
