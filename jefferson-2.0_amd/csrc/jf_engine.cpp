@@ -235,17 +235,18 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
         em = next_events(e, e->ev_mix);
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
-    // sources a pair of wavefronts sums before it stores a stereo block: as many as leave one unit for every
+    // sources a pair of wavefronts sums before it stores a stereo block: as many as leave about two units for every
     // resident pair (2048 on MI355X): larger groups mean fewer inverse transforms and fewer partial blocks for the
-    // mix; 32 at full size measures the same as 16 (profiles/r02_experiments.md)
+    // mix (profiles/group_sweep.py times every size against this choice)
     const long long n_items = (long long)K * e->S;
     static const int tune_g = getenv("JF_TUNE_G") ? atoi(getenv("JF_TUNE_G")) : 0;  // tuning runs: the automatic size
     const int G = e->src_group > 0 ? e->src_group
                   : (tune_g > 0 && e->S % tune_g == 0) ? tune_g
+                  : (e->S % 32 == 0 && n_items >= 131072) ? 32
                   : (e->S % 16 == 0 && n_items >= 32768) ? 16
                   : (e->S % 8 == 0 && n_items >= 16384) ? 8
                   : (e->S % 4 == 0 && n_items >= 8192) ? 4
-                  : (e->S % 2 == 0 && n_items >= 4096)  ? 2
+                  : (e->S % 2 == 0 && (n_items >= 4096 || e->S >= 1024)) ? 2
                                                          : 1;
     FusedParams P;
     P.G = (e->S % G == 0) ? G : 1;
@@ -930,7 +931,8 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     // automatic grouping the sources are ordered by the table row nearest to their first position, so that the units a
     // compute unit works on at a time read neighbouring rows of the 5.8 MB table (the L2 of an XCD holds 4 MB); the mix is
     // the same sum in another association.  jf_debug_set_source_group pins consecutive sources (identity order).
-    const bool want_sorted = e->src_group == 0 && e->S > 1;
+    static const bool sort_off = getenv("JF_SORT_SOURCES") && atoi(getenv("JF_SORT_SOURCES")) == 0;  // tuning runs
+    const bool want_sorted = e->src_group == 0 && e->S > 1 && !sort_off;
     if (want_sorted || e->sorted_order) {
         std::vector<std::pair<int, int>> key((size_t)e->S);
         for (int s = 0; s < e->S; s++) {
