@@ -1742,19 +1742,24 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
     __shared__ ItemDesc s_desc[kRtWaves];
     constexpr int B = 64 * NOUT;
     const int tid = threadIdx.x;
-    for (int j = tid; j < kTwPack; j += 64 * kRtWaves) s_tw[j] = P.tw[j];
-    __syncthreads();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int j = tid; j < kTwPack; j += 64 * kRtWaves) s_tw[j] = P.tw[j];
+    // the first source's descriptor before the barrier: its position comes over PCIe (host-mapped memory) and the index/
+    // weight rule is a long chain in one lane -- both overlap with the twiddle loads of the other lanes
+    const int s_first = blockIdx.x * kRtWaves + wave;
+    if (lane == 0 && s_first < P.S)
+        make_desc(rt, P.mode, pos + 5 * s_first, P.st_in[s_first].old_ele, P.st_in[s_first].old_azi, s_desc[wave]);
+    __syncthreads();
     float2 *buf = s_buf + wave * kWaveLds;
     const int a = lane & 3, i = lane >> 2;
     float2 acc[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; j++) acc[j] = make_float2(0.f, 0.f);
 #pragma unroll 1
-    for (int s = blockIdx.x * kRtWaves + wave; s < P.S; s += gridDim.x * kRtWaves) {
+    for (int s = s_first; s < P.S; s += gridDim.x * kRtWaves) {
         const float *p = pos + 5 * s;
-        if (lane == 0) make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, s_desc[wave]);
+        if (lane == 0 && s != s_first) make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, s_desc[wave]);
         JF_WAVE_LDS_SYNC();
         spatialise_item<NOUT>(P, &s_desc[wave], p, 0, s, buf, s_tw, lane, acc);
         JF_WAVE_LDS_SYNC();
