@@ -9,8 +9,8 @@
 //   window gather (signal ring / previous window)            a5
 //   real FFT 1024 = complex FFT 512 (radix 8x8x8 Stockham, two LDS exchanges)
 //     + split post-pass; the Hermitian partner Z[512-k] comes from lane 64 - lane through LDS (mirror8)  a6
-//   distance factor D[k]: exact 64-bit fixed-point phase k*c mod 1, float minimax sin/cos of the
-//     remainder after the nearest quarter turn (no f64, no table)        a7
+//   distance factor D[k]: exact 64-bit fixed-point phase k*c mod 1, the nearest 1/1024 turn from the FFT's
+//     twiddle table corrected by the small-angle terms of the remainder (no f64)   a7
 //   sum_i w_i H_i[k] from the interleaved table, * X[k] D[k], both ears  a8
 //   inverse: Z = Y_L + j Y_R, built in registers (upper half mirrored through LDS, mirror8),
 //     1024-point inverse as 4 decimated 256-point transforms
@@ -23,8 +23,8 @@
 // filter sets of G consecutive sources summed as spectra and inverted once; rt_block_kernel: one launch per audio
 // block for the per-block calls.
 //
-// A second tiny kernel sums the per-source blocks in source order (a12), a
-// third computes indices/weights (a2, a3) for every item.
+// mix_kernel sums the per-source (per-group) blocks in source order (a12), prep_kernel computes indices/weights
+// (a2, a3) for every item; mix_prep_kernel is both in one launch (this run's mix, the next window's descriptors).
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
@@ -802,7 +802,7 @@ __global__ JF_FUSED_BOUNDS void fused_block_kernel(const FusedParams P) {
 // two inverse transforms per unit instead of G + 1, and one round of table-row loads per source for both
 // sets when they share rows (a source that moved by a degree inside one grid cell interpolates between the
 // same four rows with other weights).  Two spectral sums are 64 floats per lane -- more than a wavefront can
-// hold at four waves per SIMD -- so a unit is worked by a PAIR of wavefronts (2p, 2p + 1 of a workgroup) that
+// hold at four waves per SIMD -- so a unit is worked by a PAIR of wavefronts (w and 15 - w of a workgroup) that
 // split the BINS of the sums, not the transforms: every FFT stays a one-wave transform.
 //   * wave `half` keeps the sums of bins lane + 64 q, q = 4 half .. 4 half + 3, of both sets: Z[k] and
 //     Z[N-k], 32 registers;
