@@ -44,6 +44,8 @@ B = 256
 SOURCES_PER_GPU = 1024
 # blocks per jf_batch_run: 128 = 0.74 s of audio per launch (64: -5.5 %, 256: +3 %; profiles/r02_experiments.md)
 BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "128"))
+# --reverb (batch form): 256 blocks of 128 = the same 0.74 s of audio per launch (32: -35 %, 64: -21 %, 128: -8 %)
+REVERB_BLOCKS_PER_STEP = int(os.environ.get("JF_REVERB_BLOCKS_PER_STEP", "256"))
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md; needs packed FMAs: 2 x 78.6)
 TOL32 = 4e-7                # HIP vs float32 oracle, per source (tests/)
@@ -266,7 +268,7 @@ def main():
         K, W = (40, 10) if args.realtime else (6, 2)
     ir = None
     if args.reverb:
-        B, S, KB = 128, 256, (1 if args.realtime else 32)
+        B, S, KB = 128, 256, (1 if args.realtime else REVERB_BLOCKS_PER_STEP)
         rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
         ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
         ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)

@@ -2,6 +2,7 @@
 # A/B of library variants on the batch reverb (config 5): profiles/reverb_ab.sh <tag> ...   ("-" = the product library)
 # Prints the average duration of every reverb kernel under rocprofv3 for each variant.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+export JF_REVERB_BLOCKS_PER_STEP=${JF_REVERB_BLOCKS_PER_STEP:-32}  # the size the round's A/B numbers were taken at
 for T in "$@"; do
   if [ "$T" = "-" ]; then unset JF_LIB; N=product; else export JF_LIB=$REPO/jefferson-2.0_amd/libjefferson_hip_$T.so; N=$T; fi
   OUT=$REPO/gpurun_out/rvab_$N

@@ -3,6 +3,7 @@
 # usage (through gpurun): bash profiles/reverb_batch_profile.sh <tag>
 TAG=${1:-rv}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+export JF_REVERB_BLOCKS_PER_STEP=${JF_REVERB_BLOCKS_PER_STEP:-32}  # the size the round's A/B numbers were taken at
 OUT=$REPO/gpurun_out/reverb_$TAG
 mkdir -p $OUT
 cd $REPO

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over the batch reverb's multiply-accumulate kernel: profiles/reverb_pmc.sh <tag> [lib-tag]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+export JF_REVERB_BLOCKS_PER_STEP=${JF_REVERB_BLOCKS_PER_STEP:-32}  # the size the round's A/B numbers were taken at
 OUT=$REPO/gpurun_out/rvpmc_${1:-x}
 [ -n "$2" ] && export JF_LIB=$REPO/jefferson-2.0_amd/libjefferson_hip_$2.so
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
