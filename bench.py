@@ -492,7 +492,10 @@ def main():
                                          "overlap-save (690 partitions of 128), 128-sample blocks"
                                          + (", ONE block per call (real-time shape)" if args.realtime else ""))
             macs = S * KB * P * B
-            rv = {"kernel": "reverb_fft_kernel + " + mac_name, "avg_launch_ms": t * 1e3,
+            # the reverb stage's kernels as the engine launched them (one-block calls run the transform inside the
+            # multiply-accumulate kernel)
+            rv_kernels = [k for k in kernels if k.startswith("reverb_")]
+            rv = {"kernel": " + ".join(rv_kernels) if rv_kernels else mac_name, "avg_launch_ms": t * 1e3,
                   "algorithmic_bytes_per_launch": rb, "multiply_accumulates_per_launch": macs}
             if args.realtime:
                 # one block per call: every source's 690 KB of delay line is read once per block and nothing in

@@ -1174,9 +1174,10 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         std::string k;
         if (!e->last_rt && !e->last_prep_skipped) k = "prep_kernel;";
         if (e->rv_P > 0) {
-            k += "reverb_fft_kernel<" + bs + ">;";
+            if (e->last_rv_form != 4) k += "reverb_fft_kernel<" + bs + ">;";  // 4: stage A runs inside the MAC kernel
             const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
             if (e->last_rv_form == 3) k += "reverb_mac_tiled_kernel<" + bs + "," + std::to_string(tile) + ">;";
+            else if (e->last_rv_form == 4) k += "reverb_mac_kernel<" + bs + ",1,true>;";
             else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
         }
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";

@@ -81,17 +81,10 @@ JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, i
 }  // namespace
 
 // ---------------------------------------------------------------- stage A --
-// One wavefront per (block k, source s): spectrum of [x_{k-1}, x_k] into the FDL.
+// Spectrum of [x_{k-1}, x_k] of source s into the FDL, by one wavefront (a, b: 2 x B float2 of LDS).  x0: also left in
+// LDS for the caller (the real-time form of stage B uses it at once), or null.
 template <int B>
-__global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
-    __shared__ float2 s_buf[4][2 * B];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= P.K * P.S) return;
-    const int k = g / P.S, s = g - k * P.S;
-    float2 *a = s_buf[wave], *b = s_buf[wave] + B;
-
+JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b, int lane, float2 *x0) {
     const SrcSignal sg = P.dry[s];
     const int L = sg.length;  // >= 1024 (tiled / zero buffer)
     const int dc0 = P.dry_count_in[s];
@@ -149,7 +142,20 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
             P.fdl[(size_t)P.S * P.Rg * B + (size_t)s * P.Rg + (size_t)((P.head + k) % P.Rg)] = x;
         }
         out[q] = x;
+        if (x0) x0[q] = x;
     }
+}
+
+// One wavefront per (block k, source s).
+template <int B>
+__global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
+    __shared__ float2 s_buf[4][2 * B];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= P.K * P.S) return;
+    const int k = g / P.S, s = g - k * P.S;
+    rv_forward<B>(P, k, s, s_buf[wave], s_buf[wave] + B, lane, nullptr);
 }
 
 // Last step of stage B for one (block k, source s), by one wavefront: add the NW partial spectra
@@ -221,12 +227,18 @@ JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const Reve
 // every CU), each lane owns B/64 consecutive bins of every source of the group; an IR spectrum H_p is
 // loaded once and used for the T sources (T = 4 in batch calls: 1.25 instead of 2 loads per
 // multiply-accumulate); LDS reduce; waves 0..T-1 each invert one source and write its wet block.
+// FUSE (T = 1, calls of one block: the audio callback's shape): stage A runs inside this kernel.  The last wave
+// transforms the new block and takes partition 0 from LDS while the other 15 stream the older partitions, which do not
+// depend on it: the transform costs neither a launch nor the gap behind it (5.1 us + gap of a 35.6 us step).  A wave's
+// partitions and their order are fixed, the sums deterministic.
 constexpr int kMacWaves = 16;
-template <int B, int T>
+template <int B, int T, bool FUSE = false>
 __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const ReverbParams P) {
+    static_assert(!FUSE || T == 1, "the fused form is the one-source form");
     constexpr int NB = B / 64;
     __shared__ float2 s_red[kMacWaves][T][B];
     __shared__ float2 s_fft[T][2 * B];
+    __shared__ float2 s_x0[FUSE ? B : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int SG = P.S / T;
@@ -242,10 +254,32 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
 #pragma unroll
         for (int i = 0; i < NB; i++) acc[t][i] = make_float2(0.f, 0.f);
     }
-    int slot = (P.head + k - wave) % P.Rg;
+    const bool transformer = FUSE && wave == kMacWaves - 1;
+    if (transformer) {
+        rv_forward<B>(P, k, s0, s_fft[0], s_fft[0] + B, lane, s_x0);
+        JF_RV_SYNC();
+        // partition 0: the spectrum just made, from LDS
+        const float2 *hp = hs;
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const float2 h = hp[i], x = s_x0[lane * NB + i];
+            acc[0][i].x += x.x * h.x - x.y * h.y;
+            acc[0][i].y += x.x * h.y + x.y * h.x;
+            if (i == 0) {
+                acc0[0].x += x.x * h.x;
+                acc0[0].y += x.y * h.y;
+            }
+        }
+    }
+    // this wave's partitions: p_first, p_first + stride, ...  In the fused form the transformer's chain (the block's
+    // samples, seven LDS passes, the split) is as long as the other waves' whole stream, so it takes partition 0 only
+    // and partitions 1 .. P-1 are dealt to the other 15 waves.
+    const int stride = FUSE ? kMacWaves - 1 : kMacWaves;
+    const int p_first = !FUSE ? wave : transformer ? P.P : 1 + wave;
+    int slot = (P.head + k - p_first) % P.Rg;
     if (slot < 0) slot += P.Rg;
 #pragma unroll 2
-    for (int p = wave; p < P.P; p += kMacWaves) {
+    for (int p = p_first; p < P.P; p += stride) {
         float2 h[NB];
         const float2 *hp = hs + (size_t)p * B;
         if (NB == 2) {
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
             acc0[t].x += x[0].x * h[0].x;
             acc0[t].y += x[0].y * h[0].y;
         }
-        slot -= kMacWaves;
+        slot -= stride;
         if (slot < 0) slot += P.Rg;
     }
 #pragma unroll
@@ -464,6 +498,10 @@ template <int B, int T>
 static void launch_mac(const ReverbParams &P, hipStream_t st) {
     hipLaunchKernelGGL((reverb_mac_kernel<B, T>), dim3(P.K * (P.S / T)), dim3(64 * kMacWaves), 0, st, P);
 }
+template <int B>
+static void launch_fft(const ReverbParams &P, hipStream_t st) {
+    hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3((P.K * P.S + 3) / 4), dim3(256), 0, st, P);
+}
 template <int B, int KB>
 static void launch_mac_tiled(const ReverbParams &P, hipStream_t st) {
     hipLaunchKernelGGL((reverb_mac_tiled_kernel<B, KB>), dim3((P.K + KB - 1) / KB * P.S), dim3(64 * kTileWaves), 0, st, P);
@@ -474,27 +512,27 @@ template <int B, int T, int KB>
 static int launch_mac_any(const ReverbParams &P, hipStream_t st) {
     const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
     const long long tiles = (long long)((P.K + KB - 1) / KB) * P.S;
-    if (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) return launch_mac_tiled<B, KB>(P, st), 3;
-    if (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) return launch_mac<B, T>(P, st), 2;
-    return launch_mac<B, 1>(P, st), 1;
+    const int form = (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) ? 3
+                     : (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) ? 2
+                                                                                                      : 1;
+    if (form == 1 && P.K == 1 && force != 1) {  // a call of one block: stage A inside the kernel (pinning form 1 keeps two kernels)
+        hipLaunchKernelGGL((reverb_mac_kernel<B, 1, true>), dim3(P.S), dim3(64 * kMacWaves), 0, st, P);
+        return 4;
+    }
+    launch_fft<B>(P, st);
+    if (form == 3) launch_mac_tiled<B, KB>(P, st);
+    else if (form == 2) launch_mac<B, T>(P, st);
+    else launch_mac<B, 1>(P, st);
+    return form;
 }
 
+// form_used: 1, 2, 3 as above (after reverb_fft_kernel); 4 = form 1 with stage A fused in (no reverb_fft_kernel)
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used) {
     int form = 0;
-    const dim3 ga((P.K * P.S + 3) / 4), blk(256);
     switch (P.B) {
-    case 64:
-        hipLaunchKernelGGL(reverb_fft_kernel<64>, ga, blk, 0, st, P);
-        form = launch_mac_any<64, 4, 16>(P, st);
-        break;
-    case 128:
-        hipLaunchKernelGGL(reverb_fft_kernel<128>, ga, blk, 0, st, P);
-        form = launch_mac_any<128, 4, 16>(P, st);
-        break;
-    case 256:
-        hipLaunchKernelGGL(reverb_fft_kernel<256>, ga, blk, 0, st, P);
-        form = launch_mac_any<256, 2, 8>(P, st);
-        break;
+    case 64: form = launch_mac_any<64, 4, 16>(P, st); break;
+    case 128: form = launch_mac_any<128, 4, 16>(P, st); break;
+    case 256: form = launch_mac_any<256, 2, 8>(P, st); break;
     default: return hipErrorInvalidValue;
     }
     if (form_used) *form_used = form;

@@ -12,5 +12,11 @@ for T in "$@"; do
   RC=$?
   if [ $RC -ne 0 ]; then echo "FAILED $N rc=$RC: $(tail -n 2 $OUT/trace.log | tr '\n' ' ')"; continue; fi
   echo "== $N"
-  grep -h "reverb" $OUT/trace/*/*kernel_stats.csv | sed "s/<\([0-9]*\), \([0-9]*\)>/<\1;\2>/" | awk -F, '{printf "   %-60s calls %s avg %.1f us\n", $1, $2, $4/1000}'
+  python3 - "$OUT" <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/trace/*/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "reverb" in r["Name"]:
+            print("   %-64s calls %5s avg %8.1f us" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1000))
+PY
 done

@@ -100,14 +100,27 @@ def test_reverb_two_second_ir(jf, hrir, castanets):
     assert np.abs(got - want).max() <= tol
 
 
-def test_reverb_blockwise_equals_batch(jf, hrir, castanets):
-    B, S, K = 128, 2, 9
-    ir = _ir(700)
+@pytest.mark.parametrize("B,n_ir", [(128, 700), (128, 128 * 83 + 5), (256, 256 * 19), (64, 64 * 3)])
+def test_reverb_blockwise_equals_batch(jf, hrir, castanets, B, n_ir):
+    """Per-block calls (stage A fused into the multiply-accumulate kernel: the last wave transforms the new block and
+    takes partition 0, the other 15 share the rest) against batch calls of the same form with its two kernels:
+    bit-identical when that form is pinned for both, and the fused form within the float64 tolerance of the model and
+    of the batch.  IR lengths from 3 to 83 partitions: fewer partitions than waves, and many."""
+    S, K = 2, 9
+    ir = _ir(n_ir)
+    P = -(-n_ir // B)
     sigs = [castanets[:6000], castanets[7000:12000]]
     pos = _positions(jf, S, K)
-    a = _run(jf, hrir, B, S, K, 4, ir, 0.5, sigs, pos)
-    b = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)
+    a = _run(jf, hrir, B, S, K, 4, ir, 0.5, sigs, pos, form=1)
+    b = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True, form=1)
     assert np.array_equal(a, b)
+    c = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)   # default: the fused form
+    want = _model(hrir, B, S, K, ir, 0.5, sigs, pos)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * S
+    assert np.abs(want).max() > 0.01
+    assert np.abs(c - want).max() <= tol
+    assert np.abs(c - a).max() <= 2 * tol
+    assert P <= 8 or not np.array_equal(c, a)   # really another association
 
 
 @pytest.mark.parametrize("B,P,max_k", [(128, 21, 11), (256, 9, 7), (64, 70, 16), (128, 3, 8)])
