@@ -83,8 +83,10 @@ JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, i
 // ---------------------------------------------------------------- stage A --
 // Spectrum of [x_{k-1}, x_k] of source s into the FDL, by one wavefront (a, b: 2 x B float2 of LDS).  x0: also left in
 // LDS for the caller (the real-time form of stage B uses it at once), or null.
+// tw: exp(+2 pi i j / 1024), j < 512 -- P.tw, or a copy of it in LDS (every pass of the transform reads it).
 template <int B>
-JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b, int lane, float2 *x0) {
+JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b, int lane, float2 *x0,
+                       const float2 *tw) {
     const SrcSignal sg = P.dry[s];
     const int L = sg.length;  // >= 1024 (tiled / zero buffer)
     const int dc0 = P.dry_count_in[s];
@@ -126,7 +128,7 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
         if (lane == 0) P.dry_count_out[s] = (int)(((long long)dc0 + (long long)P.K * B) % L);
     }
     JF_RV_SYNC();
-    const float2 *Z = cfft_small<B, -1>(a, b, P.tw, lane);
+    const float2 *Z = cfft_small<B, -1>(a, b, tw, lane);
     // real-FFT split: X[k] = E + (-i) W^k O, W = exp(-2 pi i / 2B)
     float2 *out = P.fdl + ((size_t)s * P.Rg + (size_t)((P.head + k) % P.Rg)) * B;
     for (int q = lane; q < B; q += 64) {
@@ -134,7 +136,7 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
         const float2 zm = Z[(B - q) & (B - 1)];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-        const float2 wo = rv_mulc(o, P.tw[q * (512 / B)]);
+        const float2 wo = rv_mulc(o, tw[q * (512 / B)]);
         float2 x = make_float2(e.x + wo.y, e.y - wo.x);
         if (q == 0) {
             x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B]), both real
@@ -150,12 +152,15 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
 template <int B>
 __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
     __shared__ float2 s_buf[4][2 * B];
+    __shared__ float2 s_tw[512];  // the transform reads a twiddle in each of its log2 B passes: from LDS, not from global memory
+    for (int j = threadIdx.x; j < 512; j += 256) s_tw[j] = P.tw[j];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x * 4 + wave;
     if (g >= P.K * P.S) return;
     const int k = g / P.S, s = g - k * P.S;
-    rv_forward<B>(P, k, s, s_buf[wave], s_buf[wave] + B, lane, nullptr);
+    rv_forward<B>(P, k, s, s_buf[wave], s_buf[wave] + B, lane, nullptr, s_tw);
 }
 
 // Last step of stage B for one (block k, source s), by one wavefront: add the NW partial spectra
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     }
     const bool transformer = FUSE && wave == kMacWaves - 1;
     if (transformer) {
-        rv_forward<B>(P, k, s0, s_fft[0], s_fft[0] + B, lane, s_x0);
+        rv_forward<B>(P, k, s0, s_fft[0], s_fft[0] + B, lane, s_x0, P.tw);
         JF_RV_SYNC();
         // partition 0: the spectrum just made, from LDS
         const float2 *hp = hs;
