@@ -34,7 +34,7 @@ typedef c2 rv_v2;
 #ifndef JF_RV_SCALAR_MAC
 #define JF_RV_SCALAR_MAC 1
 #endif
-JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) {
+[[maybe_unused]] JF_DEV void rv_cmac(rv_v2 &acc, rv_v2 x, rv_v2 h) {
 #if JF_RV_SCALAR_MAC
     acc.x = __builtin_fmaf(x.x, h.x, acc.x);
     acc.y = __builtin_fmaf(x.x, h.y, acc.y);
@@ -417,8 +417,28 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
 #endif
         xslot = xslot == 0 ? P.Rg - 1 : xslot - 1;
         hp += B * 8;
+        // acc[i] += X(i - p) * h.  The four FMAs of a product as two sweeps over the blocks -- the real parts of X first,
+        // then the imaginary parts: the two FMAs on one accumulator component are then 32 instructions apart instead
+        // of 2 (profiles/micro/cmac_tile.hip: 114.8 against 104.6 TFLOP/s for this loop on registers alone; in the
+        // kernel, where the loads set the pace, the same time at 90 VGPRs instead of 124).  The same operations on
+        // every accumulator in the same order: bit-identical sums.
+#if JF_RV_SCALAR_MAC
 #pragma unroll
-        for (int i = 0; i < KB; i++) rv_cmac(acc[i], xr[(i + KB - j) % KB], h);  // X(i - p)
+        for (int i = 0; i < KB; i++) {
+            const rv_v2 x = xr[(i + KB - j) % KB];
+            acc[i].x = __builtin_fmaf(x.x, h.x, acc[i].x);
+            acc[i].y = __builtin_fmaf(x.x, h.y, acc[i].y);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const rv_v2 x = xr[(i + KB - j) % KB];
+            acc[i].x = __builtin_fmaf(-x.y, h.y, acc[i].x);
+            acc[i].y = __builtin_fmaf(x.y, h.x, acc[i].y);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < KB; i++) rv_cmac(acc[i], xr[(i + KB - j) % KB], h);
+#endif
     };
     int p0 = pa;
     [[maybe_unused]] int groups_done = 0;
