@@ -205,8 +205,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 256 warm-up steps (80 ms) because the first ~100 steps after an idle GPU run 10-15 % slower
-    # (clock ramp; profiles/r01_experiments.md), then 256 timed steps = 32 768 blocks x 1024 sources
-    ap.add_argument("--steps", type=int, default=256)
+    # (clock ramp; profiles/r01_experiments.md), then 1024 timed steps = 131 072 blocks x 1024 sources (0.29 s)
+    ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
     ap.add_argument("--reverb", action="store_true",
