@@ -257,7 +257,7 @@ int jf_debug_set_reverb_form(jf_engine *e, int form);
 /* Per-block calls (jf_process_block / jf_submit_block / jf_callback) with at most n sources use the
  * one-launch real-time kernel (descriptors + spatialisation + mix per workgroup of 16 sources, pinned host
  * I/O, the workgroups' blocks added on the host in order); above that, the batch pipeline with one block.
- * Default 256; 0 disables the real-time kernel. */
+ * Default 8192; 0 disables the real-time kernel. */
 int jf_debug_set_rt_max_sources(jf_engine *e, int n);
 /* ';'-separated names of the kernels the last processing call launched, in launch order (bench.py labels its
  * roofline with them).  The string is owned by the engine and valid until the next call of this function. */

@@ -53,7 +53,7 @@ struct EventPair {
 };
 }  // namespace
 
-constexpr int kRtMaxWgs = 16;  // workgroups (of 16 sources each) of the one-launch real-time kernel
+constexpr int kRtMaxWgs = 128;  // workgroups (16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
 
 struct jf_engine {
     jf_config cfg{};
@@ -118,7 +118,8 @@ struct jf_engine {
     int rt_wgs = 0;                 // partial blocks the block in flight left there (0: one finished block)
     float *hd_pos = nullptr, *hd_out = nullptr;  // their device addresses
     int *h_err = nullptr, *hd_err = nullptr;     // pinned + mapped error word of the fused kernels
-    int rt_max_sources = 256;       // per-block calls with at most this many sources take the one-launch path
+    int rt_max_sources = 8192;      // per-block calls with at most this many sources take the one-launch path
+                                    // (profiles/latency_rt_sweep.py: 32 against 54 us at 1024 sources, 75 against 105 at 8192)
     bool in_flight = false;         // a submitted block not yet collected
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
@@ -733,7 +734,7 @@ int jf_submit_block(jf_engine *e) {
             P.err = e->hd_err;
             P.order = e->d_order;
             P.mode = kernel_mode(e);
-            // one 16-wave workgroup per 16 sources (at most kRtMaxWgs: then a wave takes several sources)
+            // one 16-wave workgroup per 16 sources (at most kRtMaxWgs = 2048 sources: beyond that a wave takes several)
             int wgs = (e->S + 15) / 16;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
             JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, wgs, e->stream));

@@ -60,19 +60,20 @@ def test_realtime_kernel_more_sources_than_waves(jf, hrir, castanets):
     assert np.abs(got - want).max() <= TOL32 * 4
 
 
-@pytest.mark.parametrize("S,B", [(100, 256), (256, 128), (300, 64)])
+@pytest.mark.parametrize("S,B", [(100, 256), (256, 128), (300, 64), (1030, 256), (2100, 128)])
 def test_realtime_kernel_many_workgroups(jf, hrir, castanets, S, B):
-    """Default settings: up to 256 sources go through the one-launch kernel with one workgroup per 16 sources,
-    the workgroups' blocks added on the host in order (300 sources: the batch pipeline).  Against the oracle and
-    against the batch pipeline (rt_max = 0): same items, other association of the sum."""
+    """Default settings: up to 8192 sources go through the one-launch kernel with one workgroup per 16 sources (at most
+    128 workgroups: with 2100 sources a wave takes two), the workgroups' blocks added on the host in order.  Against the
+    oracle and against the batch pipeline (rt_max = 0): same items, other association of the sum."""
     K = 5
-    a = _setup(jf, hrir, castanets, S, B, 256)
+    a = _setup(jf, hrir, castanets, S, B, 8192)
     b = _setup(jf, hrir, castanets, S, B, 0)
     o = oracle_lib.Engine(B, 512, S, hrir)
     for s in range(S):
         o.set_signal(s, 0.3 * np.roll(castanets, 777 * s)[: 9000 + 101 * s])
     got, want = _run(a, S, K, o)
     ref, _ = _run(b, S, K)
+    assert a.last_kernels()[-1].startswith("rt_block_kernel") and b.last_kernels()[-1].startswith("mix")
     a.close()
     b.close()
     assert np.abs(want).max() > 0.1
