@@ -47,8 +47,15 @@ BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "128"))
 # --reverb (batch form): 256 blocks of 128 = the same 0.74 s of audio per launch (32: -35 %, 64: -21 %, 128: -8 %)
 REVERB_BLOCKS_PER_STEP = int(os.environ.get("JF_REVERB_BLOCKS_PER_STEP", "256"))
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming read achieves from HBM (same guide)
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md; needs packed FMAs: 2 x 78.6)
 TOL32 = 4e-7                # HIP vs float32 oracle, per source (tests/)
+RV_GAIN = 0.5               # --reverb: gain of the wet signal
+
+
+def kN_BLOCKS(block):
+    """blocks a 1024-sample window reaches back"""
+    return -(-1024 // block)
 
 
 def cpu_share():
@@ -79,27 +86,36 @@ def load_workload():
     return wl
 
 
-def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, KB, n_blocks, gpu_mix, gpu_groups, G, order):
+def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, KB, n_blocks, gpu_mix, gpu_groups, G, order,
+                           reverb=None):
     """The oracle (CPU restatement of the reference's path) on the n_blocks blocks that END with the last timed
     step of the GPU run, all host threads, parallel over sources: its wall time is the CPU baseline, its output
     the check of that step (`verified`).  The oracle starts n_blocks - KB blocks earlier with empty windows; a
     window holds 1024 samples = 4 blocks, so the compared blocks see exactly the GPU's history.
     gpu_mix [KB][2B]: the GPU's mix of the last step; gpu_groups: {group index: [KB][2B]} stereo blocks of
     sampled groups of G sources, group g = sources order[G g .. G g + G - 1] (the engine's processing order; None at
-    N > 1, where rank 0 only holds the reduced mix)."""
+    N > 1, where rank 0 only holds the reduced mix).
+    reverb = (ir, gain): the convolution-reverb stage ahead of the spatialiser (oracle: jfo_reverb_set_ir, the stream
+    form of cudaPart.cu:65-205); the caller then asks for P + 4 more blocks of history, P = partitions of the IR."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     S = len(src_ids)
-    first = last_first_block + KB - n_blocks          # absolute block index since the start of the run; may be negative
+    first = last_first_block + KB - n_blocks          # absolute block index since the start of the run
+    if first < 0:   # a short run: the GPU's own history starts at block 0 with empty windows, and so does the oracle's
+        n_blocks, first = n_blocks + first, 0
     ora = oracle_lib.Engine(B, 512, S, hrir)
     for j, sid in enumerate(src_ids):
         sig = wl.source_signal_and_start(sid)[0]
         ora.set_signal(j, np.roll(sig, -((first * B) % len(sig))))   # the looped stream as the GPU reads it at `first`
+    if reverb is not None:
+        ora.set_reverb(reverb[0], reverb[1])
     if n_pos is None:   # pos holds exactly the blocks first .. first + n_blocks - 1
-        p = np.ascontiguousarray(pos)
+        p = np.ascontiguousarray(pos[-n_blocks:])
     else:
         p = np.ascontiguousarray(pos[[(first + b) % n_pos for b in range(n_blocks)]])
-    threads = min(oracle_lib.lib().jfo_num_threads(), cpu_share())
+    # every host core this process may use -- whatever OMP_NUM_THREADS says (torch.distributed.run exports 1 to its
+    # ranks): the oracle takes the count as its num_threads clause
+    threads = cpu_share()
     warm = oracle_lib.Engine(B, 512, min(S, 64), hrir)              # warm the thread pool on something else
     warm.process_batch(np.ascontiguousarray(p[:2, :min(S, 64)]), n_threads=threads)
     warm.close()
@@ -107,17 +123,28 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
     omix, opart = ora.process_batch(p, want_partial=True, n_threads=threads)
     dt = time.perf_counter() - t0
     ora.close()
+    what = "moving-source workload" if reverb is None else \
+        f"workload (reverb stage of {-(-len(reverb[0]) // B)} partitions + spatialiser)"
     base = {"value": S * n_blocks * B / dt, "unit": "source-frames/s", "cores": threads, "kind": "port",
-            "sample": f"{S} sources x {n_blocks} blocks of the same moving-source workload (the blocks that end with "
+            "sample": f"{S} sources x {n_blocks} blocks of the same {what} (the blocks that end with "
                       f"the last timed step), {dt:.2f} s wall on {threads} threads = the host-CPU share of this "
                       f"process (float32 C oracle, OpenMP over sources)"}
     # ---- check of the last timed step
     want_mix = opart[:, -KB:].astype(np.float64).sum(axis=0)
     err_mix = float(np.abs(gpu_mix - want_mix).max())
     peak = float(np.abs(want_mix).max())
-    # float32 accumulation of S sources on both sides: the tests' bound for |mix| ~ 10 is 3e-5 at S = 1024
-    ok = err_mix <= 3e-6 * max(1.0, peak) * max(1.0, S / 1024.0)
-    check = {"max_abs_err_mix": err_mix, "mix_peak": peak, "blocks_checked": KB, "sources_checked": S,
+    # float32 accumulation of S sources on both sides: the tests' bound for |mix| ~ 10 is 3e-5 at S = 1024.  With the
+    # reverb stage every source's signal carries the float32 sum over P partitions on both sides as well: the tests'
+    # per-source bound is (2e-7 + 1e-7 sqrt(P)) max(1, |y|); the S sources' errors add like noise
+    if reverb is None:
+        bound = 3e-6 * max(1.0, peak) * max(1.0, S / 1024.0)
+        tol_src = TOL32
+    else:
+        tol_src = 4e-7 + 2e-7 * float(np.sqrt(-(-len(reverb[0]) // B)))
+        src_peak = float(np.abs(opart[:, -KB:]).max())
+        bound = tol_src * max(1.0, src_peak) * float(np.sqrt(S)) + 3e-6 * max(1.0, peak)
+    ok = err_mix <= bound
+    check = {"max_abs_err_mix": err_mix, "mix_peak": peak, "bound_mix": bound, "blocks_checked": KB, "sources_checked": S,
              "against": "float32 C oracle (oracle/jf_oracle.c), summed in float64"}
     if gpu_groups:
         worst = 0.0
@@ -126,7 +153,8 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
             worst = max(worst, float(np.abs(blk - want).max()))
         check["max_abs_err_group_blocks"] = worst
         check["groups_checked"] = sorted(gpu_groups)
-        ok = ok and worst <= TOL32 * G
+        check["bound_group_blocks"] = tol_src * G
+        ok = ok and worst <= tol_src * G
     return base, bool(ok), check
 
 
@@ -198,7 +226,11 @@ def spawn_ranks(n, argv):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
-    return subprocess.call(cmd)
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks unless the variable is set: the CPU baseline of an
+    # N > 1 line must use the same host cores as the N = 1 line's (it passes its own thread count as well)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(cpu_share()))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -215,6 +247,11 @@ def main():
     ap.add_argument("--realtime", action="store_true",
                     help="with --reverb: one block per call (the audio callback's shape), where the delay line "
                          "is read from HBM: roofline of the per-block multiply-accumulate kernel")
+    ap.add_argument("--rv-sources", type=int, default=256,
+                    help="with --reverb: sources (512 puts the real-time form's 362 MB delay line past the 256 MB "
+                         "Infinity Cache: the HBM-bound measurement)")
+    ap.add_argument("--rv-ir-seconds", type=float, default=2.0,
+                    help="with --reverb: length of the impulse response (4.0 = media/s1_r1_b_441_mono.wav's: 1379 partitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes")
     ap.add_argument("--cpu-sample-blocks", type=int, default=256)
@@ -229,11 +266,16 @@ def main():
     world = int(world_env or "1")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # started by a launcher (WORLD_SIZE set): the ranks form a process group and the mix goes through the reduce even
+    # when the group has one rank -- the N > 1 code path on a one-GPU box (tests/test_gpu_engine.py)
+    use_dist = world_env is not None
 
-    pmc, pmc_note = None, "not collected"
+    pmc, pmc_note = None, ("not collected: the counter passes run only at N = 1 (a profiled child per rank would "
+                           "share the GPUs with the measurement)" if world > 1 else "not collected (--no-pmc / --pmc-child)")
     if world == 1 and not args.pmc_child and not args.no_pmc:
         extra = ((["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
-                 + (["--realtime"] if args.realtime else []))
+                 + (["--realtime"] if args.realtime else [])
+                 + (["--rv-sources", str(args.rv_sources), "--rv-ir-seconds", str(args.rv_ir_seconds)] if args.reverb else []))
         pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
 
     backend = os.environ.get("JF_DIST_BACKEND", "nccl")
@@ -248,7 +290,7 @@ def main():
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        if world > 1:
+        if use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -268,9 +310,10 @@ def main():
         K, W = (40, 10) if args.realtime else (6, 2)
     ir = None
     if args.reverb:
-        B, S, KB = 128, 256, (1 if args.realtime else REVERB_BLOCKS_PER_STEP)
+        B, S, KB = 128, args.rv_sources, (1 if args.realtime else REVERB_BLOCKS_PER_STEP)
+        n_ir = int(round(args.rv_ir_seconds * 44100))
         rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
-        ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
+        ir = rng.standard_normal(n_ir) * np.exp(-6.9 * np.arange(n_ir) / float(n_ir))
         ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
     src_lo = rank * S  # weak scaling: every rank brings its own 1024 sources
     src_ids = np.arange(src_lo, src_lo + S)
@@ -281,7 +324,7 @@ def main():
     if os.environ.get("JF_SOURCE_GROUP"):
         eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
     if ir is not None:
-        eng.set_reverb(ir, 0.5)
+        eng.set_reverb(ir, RV_GAIN)
     # The trajectories are periodic (azimuth + 1 degree per block: 360 blocks), so a long run walks one
     # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
     # costs the same 20 B x sources x lcm(360, blocks per step) of host and device memory.
@@ -310,7 +353,7 @@ def main():
                 pending[j].wait()  # stream-level wait: the engine stream must not overwrite mixes[j] early
             pending[j] = None
         eng.batch_run((i * KB) % n_pos, KB, mixes[j].data_ptr())
-        if world > 1:
+        if use_dist:
             with torch.cuda.stream(ext):  # the collective is ordered after the kernels just enqueued
                 if backend == "nccl":
                     pending[j] = dist.reduce(mixes[j], dst=0, op=dist.ReduceOp.SUM, async_op=True)
@@ -324,7 +367,7 @@ def main():
                 pending[j] = None
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -355,7 +398,7 @@ def main():
     i_last = prewarm + W + K - 1
     last_mix = mixes[i_last & 1].cpu().numpy().copy()
     groups = {}
-    if world == 1 and ir is None:
+    if world == 1:
         part = eng.read_device(eng.partial_device_ptr(), (KB, S // G, 2 * B))
         for g in sorted({0, 1, (S // G) // 3, (S // G) // 2, S // G - 2, S // G - 1}):
             groups[int(g)] = part[:, g].copy()
@@ -373,7 +416,7 @@ def main():
                  "mix_kernel_us": p2["mix_ms"] / max(p2["launches"], 1) * 1e3,
                  "source": "HIP events on the engine stream, 16 untimed steps after the timed region"}
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -418,16 +461,7 @@ def main():
             traffic = fpmc["FETCH_SIZE"] * 1024 * 2 + fpmc["WRITE_SIZE"] * 1024
             src = pmc_note
         else:
-            traffic, src = None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if ir is None and not args.stationary and os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    src = f"REPLAYED from profiles/traffic_latest.json ({tj.get('measured_at', 'round 1 build')}); live " \
-                          f"collection failed: {pmc_note}"
-                except Exception:
-                    traffic = None
+            traffic, src = None, None   # never a figure from another run: null and the reason (`source`)
         if traffic is not None:
             roof["traffic"] = traffic
             hbm.update({"bytes_per_launch": traffic, "achieved": traffic / (fused_s / launches) / 1e9,
@@ -468,12 +502,12 @@ def main():
                        "kernels": kernels,
                        "parallelism": (f"sources sharded x{world}, "
                                        + ("RCCL reduce" if backend == "nccl" else f"{backend} all_reduce (rehearsal, not RCCL)")
-                                       + " of the stereo mix") if world > 1 else "1 GPU"},
+                                       + " of the stereo mix") if use_dist else "1 GPU"},
             "real_time_factor": (KB * K * B / 44100.0) / dt,
             "us_per_source_block": dt / (S * KB * K) * 1e6,
             "roofline": roof,
         }
-        if world > 1:
+        if use_dist:
             # the only exchange of the path: the sum of the per-rank stereo mixes
             out["comm"] = {"collective": ("reduce(sum, dst=0)" if backend == "nccl" else "all_reduce(sum)")
                                          + " of float32[%d][%d] per step" % (KB, 2 * B),
@@ -488,8 +522,10 @@ def main():
             rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
             t = reverb_ms / launches * 1e-3
             mac_name = next((k for k in kernels if k.startswith("reverb_mac")), "reverb_mac")
-            out["config"]["workload"] = ("configs[4]: 256 sources + 2 s convolution-reverb IR, partitioned "
-                                         "overlap-save (690 partitions of 128), 128-sample blocks"
+            std = S == 256 and len(ir) == 88200
+            out["config"]["workload"] = (("configs[4]: " if std else "configs[4] scaled: ")
+                                         + f"{S} sources + {len(ir) / 44100.0:g} s convolution-reverb IR, partitioned "
+                                           f"overlap-save ({P} partitions of 128), 128-sample blocks"
                                          + (", ONE block per call (real-time shape)" if args.realtime else ""))
             macs = S * KB * P * B
             # the reverb stage's kernels as the engine launched them (one-block calls run the transform inside the
@@ -498,10 +534,21 @@ def main():
             rv = {"kernel": " + ".join(rv_kernels) if rv_kernels else mac_name, "avg_launch_ms": t * 1e3,
                   "algorithmic_bytes_per_launch": rb, "multiply_accumulates_per_launch": macs}
             if args.realtime:
-                # one block per call: every source's 690 KB of delay line is read once per block and nothing in
-                # a 181 MB stream is reused within the call -> HBM (Infinity Cache permitting) is the bound
-                rv.update({"bound": "hbm", "achieved": rb / t / 1e9 if t > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": rb / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0, "traffic": None})
+                # one block per call: every source's P KB of delay line is read once per block and nothing of the
+                # stream is reused within the call.  Between calls the whole delay line is re-read: if it fits the
+                # 256 MiB Infinity Cache (256 sources x 690 partitions: 181 MB) the stream comes out of THAT, and
+                # FETCH_SIZE (the L2's fabric-side requests) cannot tell the two apart; past it (512 sources or a 4 s
+                # impulse response: 362 MB) the bytes come from HBM.  `level` says which this run is.
+                fdl_bytes = S * (P + KB) * B * 8
+                in_mall = fdl_bytes + P * B * 8 <= 256 * 2 ** 20
+                gbs = rb / t / 1e9 if t > 0 else 0.0
+                rv.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "level": "infinity-cache (the delay line fits the 256 MiB MALL: NOT an HBM figure)" if in_mall
+                                    else "hbm (the delay line is larger than the 256 MiB Infinity Cache)",
+                           "delay_line_bytes": fdl_bytes,
+                           "frac_of_achievable_6300": gbs / HBM_ACHIEVABLE_GBS,
+                           "achievable_note": "MI355X_MICROARCH.md: 8 TB/s spec peak, ~6.3 TB/s achievable from HBM"})
             else:
                 # block tiles: each delay-line slot is read once per tile of 16 blocks and stays in the Infinity
                 # Cache; the bound is fp32 FMA issue (8 flops per complex multiply-accumulate, four FMAs)
@@ -514,17 +561,25 @@ def main():
                            "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 rv["traffic"] = pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024
-                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only; FETCH_SIZE counts Infinity-Cache hits too: " \
-                                       "the 177 MB delay line fits the 256 MB cache)"
-            out["reverb_roofline"] = rv
+                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only; FETCH_SIZE x 2 + WRITE_SIZE; " \
+                                                  "FETCH_SIZE counts Infinity-Cache hits too)"
+            # the reverb stage's multiply-accumulate kernel is this configuration's dominant kernel: its roofline is the
+            # line's `roofline`; the spatialiser's fused kernel (a sixth of the step) keeps its own under another key
+            out["spatialiser_roofline"] = out["roofline"]
+            out["roofline"] = rv
+            out["metric"] = "source-frames/s (sources x frames/sec) at 128-sample blocks, reverb + spatialiser"
         if world == 1 and ir is None:
             try:
                 out["single_source_block_latency_us"] = single_source_latency_us(jf, hrir)
             except Exception as ex:
                 out["single_source_block_latency_us"] = {"error": str(ex)}
-        if not args.no_cpu_baseline and ir is None:
+        if not args.no_cpu_baseline:
             all_ids = np.arange(0, world * S)
             nb = max(KB + 4, min(args.cpu_sample_blocks, max(KB + 4, 262144 // len(all_ids))))
+            if ir is not None:
+                # the compared blocks must see the GPU's delay line: P partitions of history + the window's 1024 samples
+                nb = KB + (-(-len(ir) // B)) + kN_BLOCKS(B)
+            nb = min(nb, i_last * KB + KB)   # no more than the run has processed
             if world == 1:
                 all_pos, all_n = pos, n_pos
             else:
@@ -534,7 +589,8 @@ def main():
                 all_pos = wl.trajectories(jf, all_ids, nb, moving=not args.stationary, first_block=first)
                 all_n = None
             base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, all_n, i_last * KB, KB, nb,
-                                                     last_mix, groups, G, order)
+                                                     last_mix, groups, G, order,
+                                                     reverb=(ir, RV_GAIN) if ir is not None else None)
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
             out["verified"] = ok
@@ -542,7 +598,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

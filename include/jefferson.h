@@ -32,7 +32,13 @@ enum {
     JF_OK = 0,
     JF_ERR_ARG = -1,     /* bad argument / out-of-range index */
     JF_ERR_RANGE = -2,   /* position the reference cannot interpolate (ele outside (-50, 90]) or |coords| == 0 */
-    JF_ERR_DEVICE = -3,  /* HIP runtime error; text in jf_last_error */
+    JF_ERR_DEVICE = -3,  /* HIP runtime error; text in jf_last_error.  Also the kernels' own fault report: the batch kernel
+                            bounds every wait between its wavefronts (~0.1 s), and a wait that runs out -- impossible by
+                            its protocol -- raises a host-visible error word instead of hanging the GPU.  That condition
+                            is FATAL for the engine: the next jf_synchronize / jf_collect_block / jf_process_* / jf_callback
+                            returns JF_ERR_DEVICE ("hand-off timed out"), jf_pa_callback hands PortAudio silence, and so
+                            does every later processing call; destroy the engine (the reference's checkCudaErrors
+                            exits the process, cufftDefines.cuh:69-77) */
     JF_ERR_IO = -4,      /* HRIR / WAV file problem */
     JF_ERR_STATE = -5,   /* call out of order (e.g. collect without submit) */
     JF_ERR_NOMEM = -6
@@ -245,9 +251,11 @@ int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb k
  * jf_debug_source_order reports); a value > 0 must divide n_sources and groups CONSECUTIVE sources.  The mix is the
  * same sum in a different association. */
 int jf_debug_set_source_group(jf_engine *e, int group);
-/* order[n_sources]: unit u of the batch pipeline sums sources order[G u] .. order[G u + G - 1].  With automatic
- * grouping jf_batch_upload_positions orders the sources by the table row nearest to their first position (units that
- * run side by side then read neighbouring rows of the table); otherwise the identity. */
+/* order[n_sources]: unit u of the LAST batch run summed sources order[G u] .. order[G u + G - 1], G =
+ * jf_debug_last_source_group.  With automatic grouping jf_batch_upload_positions orders the sources by the table row
+ * nearest to their first position (units that run side by side then read neighbouring rows of the table); with a
+ * pinned group size, and whenever the last run resolved to G = 1 (per-source blocks: block u of
+ * jf_batch_partial_device is source u), the identity. */
 int jf_debug_source_order(const jf_engine *e, int *order);
 /* Form of the reverb's multiply-accumulate stage: 0 = by call size (default); 1 = one workgroup per
  * (block, source) -- what real-time calls use; 2 = groups of sources share each IR partition spectrum;

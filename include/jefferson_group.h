@@ -50,6 +50,24 @@ int jf_group_source_set_signal(jf_group *g, int src, const float *mono, size_t n
 int jf_group_source_set_spherical(jf_group *g, int src, float ele, float azi, float r);
 int jf_group_source_set_cartesian(jf_group *g, int src, float x, float y, float z);
 
+/* precision_test.cu:2097-2107 (jf_source_reset): window, play position and old position of global source `src`. */
+int jf_group_source_reset(jf_group *g, int src);
+
+/* Data::type (DataTag.cuh:16, read at every block, Audio.cu:104) and Data::pauseStatus (DataTag.cuh:15, Audio.cu:101)
+ * of the one job: forwarded to every engine (jf_set_mode / jf_set_pause), in effect from the next block on. */
+int jf_group_set_mode(jf_group *g, int mode);
+int jf_group_set_pause(jf_group *g, int paused);
+
+/* The convolution reverb stage ahead of the spatialiser (jf_reverb_set_ir; the reference's offline cudaFFT,
+ * cudaPart.cu:65-205) on every engine: the impulse response is one per job, every GPU convolves its own sources
+ * (the delay lines shard with the sources, nothing is exchanged).  n_ir = 0 switches the stage off.  Resets every
+ * source's state, like jf_reverb_set_ir. */
+int jf_group_reverb_set_ir(jf_group *g, const float *ir, size_t n_ir, float gain);
+
+/* max |sample| of the last block jf_group_process_block handed out -- the clip alert of callback_func
+ * (Audio.cu:111-113) is taken on the SUM over the sources, i.e. here on the sum over the GPUs. */
+float jf_group_last_block_peak(const jf_group *g);
+
 /*
  * callback_func with the CPU path's timing (Audio.cu:118-158) over all GPUs: every engine is handed its block at
  * once (jf_submit_block), then the blocks are collected and added in shard order ON THE HOST -- 2 * frames_per_buffer
@@ -74,6 +92,16 @@ int jf_group_batch_run(jf_group *g, int first_block, int n_blocks);
 int jf_group_batch_fetch(jf_group *g, float *out_mix);
 /* Waits for everything enqueued on every engine's stream. */
 int jf_group_synchronize(jf_group *g);
+
+/*
+ * Failure semantics.  The shards advance together: if a call that moves audio state (process_block, batch_run,
+ * batch_fetch, process_batch) fails on one GPU after others have already advanced, the shards are out of step and the
+ * group is marked FAILED: every later processing call returns JF_ERR_STATE ("group failed") until the job is rebuilt
+ * (jf_group_destroy + jf_group_create).  Setters and getters keep working so that the host can read
+ * jf_group_last_error / jf_last_error(jf_group_engine(g, i)).  Several GPUs (n_gpus > 1) have only run on a
+ * one-GPU box as a communicator of size 1 so far.
+ */
+int jf_group_failed(const jf_group *g);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,10 @@
  *                    blocks -- positions changed and the stream paused/resumed from the "UI side" in between -- and
  *                    compares every block with jf_callback on a twin engine fed the same calls
  *   jf_ctest group N one job over N GPUs (jefferson_group.h: one engine per GPU, RCCL reduce of the mixes) against
- *                    one engine holding all sources: per-block calls (host sum) and batch calls (ncclReduce)
+ *                    one engine holding all sources: per-block calls (host sum) and batch calls (ncclReduce); then the
+ *                    same with the job-wide controls -- mode switch, reverb stage, pause, source reset, clip peak
+ *   jf_ctest bench N [steps] the bench workload from a C host: 1024 moving sources per GPU, 256-sample blocks, 128
+ *                    blocks per jf_group_batch_run / _fetch; prints source-frames/s (bench.py's metric)
  *
  * Synthetic HRIRs and signals (no files).  Exit code 0 = all comparisons hold; prints one line per check.
  */
@@ -12,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/jefferson.h"
 #include "../../include/jefferson_group.h"
@@ -155,18 +159,122 @@ static int test_group(int n_gpus) {
     const double tol = n_gpus == 1 ? 0.0 : 4e-7 * S;
     printf("group: %d GPU(s), %d sources: batch max diff %g, per-block max diff %g (tolerance %g), peak %g\n",
            jf_group_num_gpus(grp), S, d_batch, d_block, tol, peak);
+
+    /* ---- the job-wide controls (Data::type, Data::pauseStatus, the reverb stage, reset), forwarded to every GPU */
+    enum { NIR = 3 * B + 17 };
+    float ir[NIR];
+    for (int n = 0; n < NIR; n++) ir[n] = 0.2f * frand() * expf(-(float)n / 100.0f);
+    CHECK(jf_reverb_set_ir(one, ir, NIR, 0.8f));
+    CHECK(jf_group_reverb_set_ir(grp, ir, NIR, 0.8f));
+    double d_ctl = 0, pk = 0, peak_ctl = 0, d_peak = 0;
+    int silent = 0;
+    for (int k = 0; k < 24; k++) {
+        if (k == 6 || k == 12) { /* nearest-HRTF mode for blocks 6..11 */
+            CHECK(jf_set_mode(one, k == 6 ? JF_MODE_FD_BASIC : JF_MODE_FD_COMPLEX));
+            CHECK(jf_group_set_mode(grp, k == 6 ? JF_MODE_FD_BASIC : JF_MODE_FD_COMPLEX));
+        }
+        if (k == 15 || k == 18) { /* paused for blocks 15..17: silence, nothing consumed */
+            CHECK(jf_set_pause(one, k == 15));
+            CHECK(jf_group_set_pause(grp, k == 15));
+        }
+        if (k == 20) { /* sources on both sides of a shard boundary start over */
+            CHECK(jf_source_reset(one, 0));
+            CHECK(jf_group_source_reset(grp, 0));
+            CHECK(jf_source_reset(one, S - 1));
+            CHECK(jf_group_source_reset(grp, S - 1));
+        }
+        for (int s = 0; s < S; s++) {
+            CHECK(jf_source_set_spherical(one, s, (float)(-30 + (11 * s) % 100), (float)((20 * s + 7 * k) % 360), 1.0f));
+            CHECK(jf_group_source_set_spherical(grp, s, (float)(-30 + (11 * s) % 100), (float)((20 * s + 7 * k) % 360), 1.0f));
+        }
+        CHECK(jf_process_block(one, a));
+        CHECK(jf_group_process_block(grp, b));
+        const double d = max_abs_diff(b, a, 2 * B, &pk);
+        if (d > d_ctl) d_ctl = d;
+        if (pk > peak_ctl) peak_ctl = pk;
+        if (pk == 0) silent++;
+        /* the clip alert's quantity: on one GPU the engine's own figure, always the peak of what was handed out */
+        double pb = 0;
+        max_abs_diff(a, b, 2 * B, &pb);
+        const double dp = fabs((double)jf_group_last_block_peak(grp) - pb);
+        if (dp > d_peak) d_peak = dp;
+    }
+    const int bad_mode = jf_group_set_mode(grp, 7) != JF_ERR_ARG;
+    const int bad_src = jf_group_source_reset(grp, S) != JF_ERR_ARG;
+    /* three partitions of float32 sums on top of the spatialiser's tolerance */
+    const double tol_ctl = n_gpus == 1 ? 0.0 : 8e-7 * S;
+    printf("group controls: reverb + mode switch + pause + reset over 24 blocks: max diff %g (tolerance %g), peak %g, "
+           "%d silent blocks (3 paused), clip-peak mismatch %g, failed flag %d\n",
+           d_ctl, tol_ctl, peak_ctl, silent, d_peak, jf_group_failed(grp));
+    const int ok_ctl = d_ctl <= tol_ctl && peak_ctl > 0.02 && silent == 3 && d_peak == 0 && !bad_mode && !bad_src &&
+                       jf_group_failed(grp) == 0;
     jf_group_destroy(grp);
     jf_engine_destroy(one);
     free(pos);
     free(a);
     free(b);
     free(hrir);
-    return (d_batch <= tol && d_block <= tol && peak > 0.05) ? 0 : 1;
+    return (d_batch <= tol && d_block <= tol && peak > 0.05 && ok_ctl) ? 0 : 1;
+}
+
+static double now_s(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+/* The bench workload driven from a plain-C host through jefferson_group.h: 1024 looped noise
+ * sources per GPU, azimuth + 1 degree per block (a crossfade every block), 128 blocks of 256 samples per run; run i + 1
+ * is enqueued as soon as run i has been fetched.  Prints one line with bench.py's metric. */
+static int test_bench(int n_gpus, int steps) {
+    enum { B = 256, PER_GPU = 1024, KB = 128, TAPS = 128 };
+    const int S = PER_GPU * n_gpus;
+    /* the trajectory is periodic in 360 blocks; lcm(360, 128) = 5760 blocks are uploaded once and walked round */
+    const int n_pos = 5760;
+    float *hrir = make_hrir(TAPS);
+    jf_config cfg = {B, 512, S, 0, KB, 0};
+    jf_group *grp = NULL;
+    CHECK(jf_group_create(&cfg, n_gpus, NULL, hrir, TAPS, &grp));
+    float *sig = (float *)malloc(sizeof(float) * 44100);
+    for (int s = 0; s < S; s++) {
+        for (int i = 0; i < 44100; i++) sig[i] = frand();
+        CHECK(jf_group_source_set_signal(grp, s, sig, 44100));
+    }
+    free(sig);
+    float *pos = (float *)malloc(sizeof(float) * JF_POS_FLOATS * (size_t)S * n_pos);
+    for (int s = 0; s < S; s++) {
+        const float r = 0.5f + 3.0f * (frand() + 0.5f), ele = (float)(-40 + (7 * s) % 121);
+        for (int k = 0; k < n_pos; k++)
+            CHECK(jf_position_from_spherical(ele, (float)((37 * s + k) % 360), r, pos + ((size_t)k * S + s) * JF_POS_FLOATS));
+    }
+    CHECK(jf_group_batch_upload_positions(grp, n_pos, pos));
+    free(pos);
+    float *mix = (float *)malloc(sizeof(float) * 2 * B * KB);
+    const int warm = 64;
+    double t0 = 0, peak = 0;
+    for (int i = 0; i < warm + steps; i++) {
+        if (i == warm) t0 = now_s();
+        CHECK(jf_group_batch_run(grp, (i * KB) % n_pos, KB));
+        CHECK(jf_group_batch_fetch(grp, mix));
+    }
+    const double dt = now_s() - t0;
+    for (int i = 0; i < 2 * B * KB; i++)
+        if (fabs((double)mix[i]) > peak) peak = fabs((double)mix[i]);
+    printf("bench: %d GPU(s) x %d sources, %d steps of %d blocks of %d: %.4e source-frames/s, %.4f ms per step, "
+           "real-time factor %.0f, |mix| peak %.3f (plain C host: jf_group_batch_run + _fetch per step)\n",
+           n_gpus, PER_GPU, steps, KB, B, (double)S * KB * B * steps / dt, dt / steps * 1e3,
+           (double)KB * steps * B / 44100.0 / dt, peak);
+    jf_group_destroy(grp);
+    free(mix);
+    free(hrir);
+    return peak > 0.1 ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "pa")) return test_pa();
     if (argc >= 2 && !strcmp(argv[1], "group")) return test_group(argc >= 3 ? atoi(argv[2]) : 1);
-    fprintf(stderr, "usage: jf_ctest pa | group [n_gpus]\n");
+    if (argc >= 2 && !strcmp(argv[1], "bench"))
+        return test_bench(argc >= 3 ? atoi(argv[2]) : 1, argc >= 4 ? atoi(argv[3]) : 256);
+    fprintf(stderr, "usage: jf_ctest pa | group [n_gpus] | bench [n_gpus [steps]]\n");
     return 64;
 }

@@ -156,6 +156,14 @@ int fail(jf_engine *e, int code, const std::string &msg) {
 
 bool valid_src(const jf_engine *e, int s) { return e && s >= 0 && s < e->S; }
 
+// The error word of the fused kernels (host-mapped): set when a wait between the two wavefronts of a pair timed out
+// (fused_pair_kernel; impossible by its protocol, and bounded so that a fault cannot hang the GPU).  The blocks of that
+// launch are wrong and the sources' state is undefined from then on, so the condition is FATAL for the engine: every
+// call that hands out or produces audio afterwards returns JF_ERR_DEVICE (jf_pa_callback: silence); the engine can
+// only be destroyed.  Valid after a synchronisation of the engine's stream.
+constexpr const char *kHandOffMsg = "fused_pair_kernel: a wavefront hand-off timed out (fatal: destroy the engine)";
+bool device_fault(const jf_engine *e) { return e->h_err && *(volatile int *)e->h_err != 0; }
+
 // Every ABI entry that reaches HIP binds the engine's device for its duration: the callback runs on
 // PortAudio's thread, the setters on the UI thread, and a host with one engine per GPU switches devices
 // between calls -- a thread's current device is 0 until somebody sets it.
@@ -225,6 +233,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
 // prep -> [reverb] -> fused -> mix on the engine stream, K blocks starting at d_pos.
 // first_block: index of d_pos's first block in the uploaded trajectory (jf_batch_run), -1 for positions from elsewhere.
 int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int first_block = -1) {
+    if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);  // fatal: see device_fault
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
     if (e->profiling) {
@@ -240,9 +249,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     // resident pair (2048 on MI355X): larger groups mean fewer inverse transforms and fewer partial blocks for the
     // mix (profiles/group_sweep.py times every size against this choice)
     const long long n_items = (long long)K * e->S;
-    static const int tune_g = getenv("JF_TUNE_G") ? atoi(getenv("JF_TUNE_G")) : 0;  // tuning runs: the automatic size
     const int G = e->src_group > 0 ? e->src_group
-                  : (tune_g > 0 && e->S % tune_g == 0) ? tune_g
                   : (e->S % 32 == 0 && n_items >= 131072) ? 32
                   : (e->S % 16 == 0 && n_items >= 32768) ? 16
                   : (e->S % 8 == 0 && n_items >= 16384) ? 8
@@ -440,7 +447,6 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         }
         JF_HIP(e, hipMalloc(&e->d_desc, sizeof(ItemDesc) * S * K));
         JF_HIP(e, hipMalloc(&e->d_desc_ahead, sizeof(ItemDesc) * S * K));
-        if (const char *v = getenv("JF_PREP_AHEAD")) e->prep_ahead = atoi(v) != 0;  // tuning runs (jf_debug_set_prep_ahead)
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
@@ -703,6 +709,7 @@ int jf_submit_block(jf_engine *e) {
     DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a block is already in flight");
+    if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
     if (e->paused.load(std::memory_order_relaxed)) {  // Audio.cu:101: nothing is consumed, output is silence
         JF_HIP(e, hipMemsetAsync(e->d_mix, 0, sizeof(float) * 2 * e->B, e->stream));
     } else {
@@ -762,6 +769,10 @@ int jf_collect_block(jf_engine *e, float *out) {
     if (!e || !out) return JF_ERR_ARG;
     if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
     JF_HIP(e, hipStreamSynchronize(e->stream));
+    if (device_fault(e)) {  // per-block calls with more than rt_max_sources sources run the pair kernel too
+        e->in_flight = false;
+        return fail(e, JF_ERR_DEVICE, kHandOffMsg);
+    }
     memcpy(out, e->h_out_pinned, sizeof(float) * 2 * e->B);
     // the real-time kernel's workgroups each left the sum of their sources: add them in workgroup order
     for (int g = 1; g < e->rt_wgs; g++) {
@@ -932,8 +943,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     // automatic grouping the sources are ordered by the table row nearest to their first position, so that the units a
     // compute unit works on at a time read neighbouring rows of the 5.8 MB table (the L2 of an XCD holds 4 MB); the mix is
     // the same sum in another association.  jf_debug_set_source_group pins consecutive sources (identity order).
-    static const bool sort_off = getenv("JF_SORT_SOURCES") && atoi(getenv("JF_SORT_SOURCES")) == 0;  // tuning runs
-    const bool want_sorted = e->src_group == 0 && e->S > 1 && !sort_off;
+    const bool want_sorted = e->src_group == 0 && e->S > 1;
     if (want_sorted || e->sorted_order) {
         std::vector<std::pair<int, int>> key((size_t)e->S);
         for (int s = 0; s < e->S; s++) {
@@ -968,7 +978,7 @@ int jf_synchronize(jf_engine *e) {
     DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
-    if (*(volatile int *)e->h_err) return fail(e, JF_ERR_DEVICE, "fused_pair_kernel: a wavefront hand-off timed out");
+    if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
     return JF_OK;
     });
 }
@@ -987,7 +997,7 @@ int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *
         JF_HIP(e, hipMemcpyAsync(out_mix + (size_t)b0 * blk, e->d_mix, sizeof(float) * blk * k, hipMemcpyDeviceToHost,
                                  e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
-        if (*(volatile int *)e->h_err) return fail(e, JF_ERR_DEVICE, "fused_pair_kernel: a wavefront hand-off timed out");
+        if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
     }
     return JF_OK;
     });
@@ -1069,7 +1079,8 @@ int jf_debug_set_source_group(jf_engine *e, int group) {
 
 int jf_debug_source_order(const jf_engine *e, int *order) {
     if (!e || !order) return JF_ERR_ARG;
-    for (int s = 0; s < e->S; s++) order[s] = e->order[s];
+    // the per-source kernel (a run that resolved to G = 1) does not go through the order: its block u is source u
+    for (int s = 0; s < e->S; s++) order[s] = e->last_group > 1 ? e->order[s] : s;
     return JF_OK;
 }
 

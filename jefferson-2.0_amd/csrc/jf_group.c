@@ -20,6 +20,8 @@ struct jf_group {
     float *blk;    /* [2B] host scratch of jf_group_process_block */
     int traj_blocks;
     int run_blocks; /* > 0: a batch run is in flight (not yet fetched) */
+    int failed;     /* a processing call failed part-way: the shards are out of step (jefferson_group.h) */
+    float last_peak; /* max |sample| of the last block handed out by jf_group_process_block */
     char err[256];
 };
 
@@ -172,17 +174,92 @@ int jf_group_source_set_cartesian(jf_group *g, int src, float x, float y, float 
     return JF_OK;
 }
 
+/* a processing step on shard i: a failure once any shard may have advanced marks the group failed */
+#define JG_STEP(g, i, call)                                                          \
+    do {                                                                             \
+        int rc_ = (call);                                                            \
+        if (rc_ != JF_OK) {                                                          \
+            (g)->failed = 1;                                                         \
+            return fail((g), rc_, #call, jf_last_error((g)->eng[i]));                \
+        }                                                                            \
+    } while (0)
+#define JG_ALIVE(g) \
+    if ((g)->failed) return fail_keep((g), JF_ERR_STATE, "group failed: the shards are out of step; destroy and re-create it")
+
+static int fail_keep(jf_group *g, int code, const char *what) { /* keeps the text of the failure that caused it */
+    if (!strstr(g->err, "group failed")) {
+        char first[128];
+        memcpy(first, g->err, sizeof(first) - 1);
+        first[sizeof(first) - 1] = 0;
+        snprintf(g->err, 256, "%s (first failure: %s)", what, first);
+    }
+    return code;
+}
+
+int jf_group_failed(const jf_group *g) { return g ? g->failed : JF_ERR_ARG; }
+float jf_group_last_block_peak(const jf_group *g) { return g ? g->last_peak : 0.0f; }
+
+int jf_group_source_reset(jf_group *g, int src) {
+    const int i = g ? shard_of(g, src) : -1;
+    if (i < 0) return fail(g, JF_ERR_ARG, "bad source index", NULL);
+    if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    JG_ENG(g, i, jf_source_reset(g->eng[i], src - g->lo[i]));
+    return JF_OK;
+}
+
+int jf_group_set_mode(jf_group *g, int mode) {
+    if (!g) return JF_ERR_ARG;
+    if (mode != JF_MODE_FD_COMPLEX && mode != JF_MODE_FD_BASIC) return fail(g, JF_ERR_ARG, "unknown mode", NULL);
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_set_mode(g->eng[i], mode));
+    return JF_OK;
+}
+
+int jf_group_set_pause(jf_group *g, int paused) {
+    if (!g) return JF_ERR_ARG;
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_set_pause(g->eng[i], paused));
+    return JF_OK;
+}
+
+int jf_group_reverb_set_ir(jf_group *g, const float *ir, size_t n_ir, float gain) {
+    if (!g || (n_ir && !ir)) return fail(g, JF_ERR_ARG, "bad impulse response", NULL);
+    if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    JG_ALIVE(g);
+    /* all or nothing would need a second set of delay lines: a failure part-way (out of device memory on one GPU)
+     * leaves engines with and without the stage, i.e. a failed group */
+    for (int i = 0; i < g->n; i++) {
+        const int rc = jf_reverb_set_ir(g->eng[i], ir, n_ir, gain);
+        if (rc != JF_OK) {
+            if (i > 0 || rc != JF_ERR_ARG) g->failed = 1;
+            return fail(g, rc, "jf_reverb_set_ir", jf_last_error(g->eng[i]));
+        }
+    }
+    return JF_OK;
+}
+
 int jf_group_process_block(jf_group *g, float *out) {
     if (!g || !out) return fail(g, JF_ERR_ARG, "null argument", NULL);
     if (g->run_blocks) return fail(g, JF_ERR_STATE, "a batch run is in flight (jf_group_batch_fetch first)", NULL);
+    JG_ALIVE(g);
     /* every GPU gets its block before any is waited for */
-    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_submit_block(g->eng[i]));
+    for (int i = 0; i < g->n; i++) {
+        const int rc = jf_submit_block(g->eng[i]);
+        if (rc != JF_OK) {
+            if (i > 0) g->failed = 1; /* shards 0 .. i-1 have a block in flight */
+            return fail(g, rc, "jf_submit_block", jf_last_error(g->eng[i]));
+        }
+    }
     memset(out, 0, sizeof(float) * 2 * (size_t)g->B);
     for (int i = 0; i < g->n; i++) {
-        JG_ENG(g, i, jf_collect_block(g->eng[i], i == 0 ? out : g->blk));
+        JG_STEP(g, i, jf_collect_block(g->eng[i], i == 0 ? out : g->blk));
         if (i > 0)
             for (int k = 0; k < 2 * g->B; k++) out[k] += g->blk[k]; /* Audio.cu:109-110, shard by shard */
     }
+    float peak = 0.0f;
+    for (int k = 0; k < 2 * g->B; k++) {
+        const float a = out[k] < 0.0f ? -out[k] : out[k];
+        if (a > peak) peak = a;
+    }
+    g->last_peak = peak; /* Audio.cu:111-113 looks at the summed output */
     return JF_OK;
 }
 
@@ -215,20 +292,29 @@ int jf_group_batch_run(jf_group *g, int first_block, int n_blocks) {
     if (n_blocks <= 0 || n_blocks > g->maxK) return fail(g, JF_ERR_ARG, "n_blocks exceeds max_batch_blocks", NULL);
     if (first_block < 0 || first_block + n_blocks > g->traj_blocks)
         return fail(g, JF_ERR_ARG, "window outside the uploaded trajectory", NULL);
+    JG_ALIVE(g);
     /* every engine's kernels, each on its own stream, its mix into its reduce buffer */
-    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_batch_run(g->eng[i], first_block, n_blocks, g->d_red[i]));
-    /* the one exchange of the path: sum of the mixes to the first GPU, behind the kernels on the same streams */
-    const size_t count = (size_t)n_blocks * 2 * (size_t)g->B;
-    JG_NCCL(g, ncclGroupStart());
     for (int i = 0; i < g->n; i++) {
-        ncclResult_t s = ncclReduce(g->d_red[i], g->d_red[i], count, ncclFloat, ncclSum, 0, g->comm[i],
-                                    (hipStream_t)jf_engine_stream(g->eng[i]));
-        if (s != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return fail(g, JF_ERR_DEVICE, "ncclReduce", ncclGetErrorString(s));
+        const int rc = jf_batch_run(g->eng[i], first_block, n_blocks, g->d_red[i]);
+        if (rc != JF_OK) {
+            if (i > 0) g->failed = 1; /* shards 0 .. i-1 have advanced */
+            return fail(g, rc, "jf_batch_run", jf_last_error(g->eng[i]));
         }
     }
-    JG_NCCL(g, ncclGroupEnd());
+    /* the one exchange of the path: sum of the mixes to the first GPU, behind the kernels on the same streams.
+     * From here on every shard has advanced: any failure leaves the group failed, and the collective group is always
+     * closed (ncclGroupEnd) so that no stream is left with half a collective. */
+    const size_t count = (size_t)n_blocks * 2 * (size_t)g->B;
+    ncclResult_t s = ncclGroupStart(), s_end;
+    for (int i = 0; s == ncclSuccess && i < g->n; i++)
+        s = ncclReduce(g->d_red[i], g->d_red[i], count, ncclFloat, ncclSum, 0, g->comm[i],
+                       (hipStream_t)jf_engine_stream(g->eng[i]));
+    s_end = ncclGroupEnd();
+    if (s == ncclSuccess) s = s_end;
+    if (s != ncclSuccess) {
+        g->failed = 1;
+        return fail(g, JF_ERR_DEVICE, "ncclReduce of the mixes", ncclGetErrorString(s));
+    }
     g->run_blocks = n_blocks;
     return JF_OK;
 }
@@ -236,6 +322,7 @@ int jf_group_batch_run(jf_group *g, int first_block, int n_blocks) {
 int jf_group_batch_fetch(jf_group *g, float *out_mix) {
     if (!g || !out_mix) return fail(g, JF_ERR_ARG, "null argument", NULL);
     if (!g->run_blocks) return fail(g, JF_ERR_STATE, "no batch run in flight", NULL);
+    JG_ALIVE(g);
     int prev = -1;
     (void)hipGetDevice(&prev);
     JG_HIP(g, hipSetDevice(g->dev[0]));
@@ -245,9 +332,13 @@ int jf_group_batch_fetch(jf_group *g, float *out_mix) {
     if (s == hipSuccess) s = hipStreamSynchronize(st);
     if (prev >= 0) (void)hipSetDevice(prev);
     g->run_blocks = 0;
-    JG_HIP(g, s);
-    /* the other GPUs' part of the reduce ends with the root's; their kernels' own errors surface here */
-    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_synchronize(g->eng[i]));
+    if (s != hipSuccess) {
+        g->failed = 1;
+        return fail(g, JF_ERR_DEVICE, "copy of the reduced mix", hipGetErrorString(s));
+    }
+    /* the other GPUs' part of the reduce ends with the root's; their kernels' own errors (the batch kernel's error
+     * word: a hand-off that timed out, fatal for that engine) surface here */
+    for (int i = 0; i < g->n; i++) JG_STEP(g, i, jf_synchronize(g->eng[i]));
     return JF_OK;
 }
 

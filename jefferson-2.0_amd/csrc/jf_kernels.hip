@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
+#include "jf_experiments.h"
 #include "jf_packed.h"
 
 namespace jf {
@@ -38,9 +39,7 @@ namespace jf {
 // Used on the lane index where the compiler would otherwise keep dozens of loop-invariant per-lane addresses and
 // constants alive across a whole persistent kernel -- and spill them.
 JF_DEV int opaque(int x) {
-#ifndef JF_EXP_NO_OPAQUE
-    asm volatile("" : "+v"(x));
-#endif
+    JF_EXP_OPAQUE(x);
     return x;
 }
 typedef float __attribute__((address_space(1))) gfloat;  // float in global memory
@@ -76,7 +75,7 @@ JF_DEV ItemDesc load_desc(const ItemDesc *p) {
     return d;
 }
 
-// LDS traffic below is private to one wavefront; LDS ops of a wave execute in
+// LDS traffic that is PRIVATE TO ONE WAVEFRONT (the FFT exchanges, the mirrors): LDS ops of a wave execute in
 // issue order, so all that is needed is to stop the compiler from moving a
 // lane's reads above other lanes' writes.
 #define JF_WAVE_LDS_SYNC()                                      \
@@ -84,6 +83,20 @@ JF_DEV ItemDesc load_desc(const ItemDesc *p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
         __builtin_amdgcn_wave_barrier();                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+// LDS traffic BETWEEN THE TWO WAVEFRONTS OF A PAIR (mailboxes and their flag words): workgroup-scope release before a
+// flag is written, workgroup-scope acquire after one has been read, both restricted to the local address space -- on
+// gfx950 an s_waitcnt lgkmcnt(0), and no wait for the table-row loads that may be in flight (a fence over all address
+// spaces would add vmcnt(0)).
+#define JF_PAIR_RELEASE()                                                 \
+    do {                                                                  \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   \
+        __builtin_amdgcn_wave_barrier();                                  \
+    } while (0)
+#define JF_PAIR_ACQUIRE()                                                 \
+    do {                                                                  \
+        __builtin_amdgcn_wave_barrier();                                  \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   \
     } while (0)
 
 JF_DEV float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -589,20 +602,12 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     // the signal) every lane works out where its samples are; all loads are in flight together either way.
     int start0 = base + q0;  // signal index of the window's first sample (meaningful for q0 >= 0), < L + N
     start0 = start0 >= L ? start0 - L : start0;
-#ifdef JF_EXP_FASTGATHER  // timing experiment (wrong results): every window takes the one-stretch path
-    start0 = (q0 >= 0 && start0 + kN <= L) ? start0 : 0;
-    if (true) {
-#else
-    if (q0 >= 0 && start0 + kN <= L) {
-#endif
-        const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
+    bool one_stretch = q0 >= 0 && start0 + kN <= L;
+    JF_EXP_GATHER_PATH(one_stretch, start0);
+    if (one_stretch) {
+        [[maybe_unused]] const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
 #pragma unroll
-#ifdef JF_EXP_NOWINLOAD  // timing experiment (wrong results): no window loads on the usual path
-        for (int r = 0; r < 8; r++) z[r] = make_float2((float)(start0 + r), (float)lane);
-        (void)p;
-#else
-        for (int r = 0; r < 8; r++) z[r] = make_float2(p[64 * r].x, p[64 * r].y);
-#endif
+        for (int r = 0; r < 8; r++) z[r] = JF_EXP_WINDOW_PAIR(p, r, start0, lane);
     } else {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -667,11 +672,7 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     }
 
     if (n_new <= 0) return false;
-#ifdef JF_EXP_NOFRONT  // timing experiment (wrong results): window loads only, no transform, no distance factor
-#pragma unroll
-    for (int q = 0; q < 8; q++) xd[q] = z[q];
-    return true;
-#endif
+    JF_EXP_FRONT_SHORTCUT(xd, z);
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
@@ -837,9 +838,7 @@ JF_DEV void lds_flag_write(unsigned addr, int v) {
 // Every wait is bounded (about a tenth of a second): a hand-off that never arrives -- impossible by the protocol
 // above -- raises the host-visible error word and lets the grid drain instead of hanging the GPU.
 JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
-#ifdef JF_EXP_NOWAIT  // timing experiment (wrong results): what do the hand-off waits cost?
-    return;
-#endif
+    JF_EXP_WAIT_SHORTCUT();
     if (dead) return;  // after one time-out this wave no longer waits for anything
     for (int spins = 0; lds_flag_read(flag) < v; spins++) {
         __builtin_amdgcn_s_sleep(1);
@@ -900,12 +899,9 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
         for (int q = 0; q < QC; q++)
 #pragma unroll
             for (int t = 0; t < NT; t++)
-#ifdef JF_EXP_NOROWLOAD  // timing experiment (wrong results): the filter arithmetic without its table loads
-                h[st & 1][q][t] = make_float4((float)(st + q), 1.0f, (float)boff, (float)t);
-#else
-                h[st & 1][q][t] =
-                    *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff);
-#endif
+                h[st & 1][q][t] = JF_EXP_ROW_LOAD(
+                    reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff), st, q,
+                    boff, t);
     };
     load_stage(0);
     if (NS > 1) load_stage(1);
@@ -993,12 +989,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #else
     const int pair = wave >> 1, half = wave & 1;
 #endif
-#ifdef JF_EXP_STAMPS  // timing experiment: when does every wave start and finish (100 MHz real-time counter)
-    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(P.err) + 16);
-    const int wid = blockIdx.x * kPairsPerWg + pair;  // pair index: 4 stamps per pair, written by its wave 1
-    const bool stamper = lane == 0 && half == 1 && wid < 2048;
-    if (stamper) stamps[4 * wid] = __builtin_amdgcn_s_memrealtime();
-#endif
+    JF_EXP_STAMP_SETUP(P, pair, half, lane);
     float2 *base = s_pair + pair * kPairLds;
     float2 *buf = base + half * kPairWave;  // my FFT work space
     float2 *mail = buf + kPairWork;         // my two mailbox slots
@@ -1009,23 +1000,23 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
     [[maybe_unused]] int steps_done = 0;  // sources I have run the front half of
     bool dead = false;        // a wait timed out (pair_wait)
-    auto publish = [&]() {
-        JF_WAVE_LDS_SYNC();
+    auto publish = [&]() {  // my mailbox stores, then the flag: release
+        JF_PAIR_RELEASE();
         npub++;
-        if (lane == 0) lds_flag_write(my_pub, npub);
+        if (lane == 0 && !JF_EXP_PUBLISH_DROPPED(npub)) lds_flag_write(my_pub, npub);
     };
-    auto await_partner = [&]() {  // the partner's next hand-off is in its mailbox
+    auto await_partner = [&]() {  // the partner's next hand-off is in its mailbox: flag, then the mailbox loads: acquire
         nseen++;
         pair_wait(his_pub, nseen, P.err, dead);
-        JF_WAVE_LDS_SYNC();
+        JF_PAIR_ACQUIRE();
     };
-    auto consumed = [&]() {  // I am done reading the partner's mailbox
-        JF_WAVE_LDS_SYNC();
+    auto consumed = [&]() {  // I am done reading the partner's mailbox (my loads have returned before the flag says so)
+        JF_PAIR_RELEASE();
         if (lane == 0) lds_flag_write(my_ack, nseen);
     };
-    auto mail_free = [&](int upto) {  // the partner has consumed my hand-offs 1 .. upto
+    auto mail_free = [&](int upto) {  // the partner has consumed my hand-offs 1 .. upto: its flag, then my stores
         pair_wait(his_ack, upto, P.err, dead);
-        JF_WAVE_LDS_SYNC();
+        JF_PAIR_ACQUIRE();
     };
 
     constexpr int B = 64 * NOUT;
@@ -1078,12 +1069,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = c2{0.f, 0.f};
         // fetch(xh): see filtered_half.  A source with two filters (its sets do not share rows) fetches once.
         auto accumulate = [&](const ItemDesc *dp, auto &&fetch) {
-#ifdef JF_EXP_NOFILTER  // timing experiment (wrong results): fronts and hand-offs only
-            float2 xq[4];
-            fetch(xq);
-            zkn[0] += c2_of(xq[0]);
-            return;
-#endif
+            JF_EXP_FILTER_SHORTCUT(fetch, zkn);
             const int nn = dp->n_new;
             auto add_new = [&](int q, c2 zk, c2 zmv, c2, c2) {
                 zkn[q] += zk;
@@ -1254,13 +1240,9 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #pragma unroll
             for (int j = 0; j < NOUT; j++) out[fi + 16 * (NOUT * af + j)] = fr[j];
         }
-#ifdef JF_EXP_STAMPS
-        if (stamper && round < 2) stamps[4 * wid + 1 + round] = __builtin_amdgcn_s_memrealtime();
-#endif
+        JF_EXP_STAMP_ROUND(round);
     }
-#ifdef JF_EXP_STAMPS
-    if (stamper) stamps[4 * wid + 3] = __builtin_amdgcn_s_memrealtime();
-#endif
+    JF_EXP_STAMP_END();
 }
 
 // ---------------------------------------------------------------- mixing --

@@ -29,6 +29,12 @@ _SIGS = {
     "jf_group_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jf_group_batch_fetch": (C.c_int, [C.c_void_p, _f]),
     "jf_group_synchronize": (C.c_int, [C.c_void_p]),
+    "jf_group_source_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_group_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_group_set_pause": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_group_reverb_set_ir": (C.c_int, [C.c_void_p, _f, C.c_size_t, C.c_float]),
+    "jf_group_last_block_peak": (C.c_float, [C.c_void_p]),
+    "jf_group_failed": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
@@ -130,3 +136,22 @@ class Group:
 
     def synchronize(self):
         self._chk(lib().jf_group_synchronize(self.h))
+
+    def reset(self, s):
+        self._chk(lib().jf_group_source_reset(self.h, s))
+
+    def set_mode(self, mode):
+        return lib().jf_group_set_mode(self.h, int(mode))
+
+    def set_pause(self, paused):
+        self._chk(lib().jf_group_set_pause(self.h, int(bool(paused))))
+
+    def set_reverb(self, ir, gain=1.0):
+        ir = np.ascontiguousarray(ir, np.float32)
+        self._chk(lib().jf_group_reverb_set_ir(self.h, _fp(ir) if len(ir) else None, len(ir), gain))
+
+    def last_block_peak(self):
+        return float(lib().jf_group_last_block_peak(self.h))
+
+    def failed(self):
+        return lib().jf_group_failed(self.h)

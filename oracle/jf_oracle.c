@@ -408,6 +408,10 @@ typedef struct {
     float old_ele, old_azi;
     float *x;    /* CPUSoundSource.h:22, window of N samples */
     float *last; /* last 2*B output */
+    /* convolution reverb ahead of the spatialiser (jfo_reverb_set_ir): frequency-domain delay line of the last P
+     * input spectra (planar re / im, P x (B + 1) each, slot = block index mod P) and the previous dry block */
+    float *rv_xr, *rv_xi, *rv_prev;
+    int rv_head;
 } jfo_source;
 
 struct jfo_engine {
@@ -416,6 +420,11 @@ struct jfo_engine {
     float *table; /* [710][2][Nc][2] */
     jfo_source *src;
     jfo_plan ph, pf;
+    /* reverb stage: P partitions of B taps, spectra of [h_p, 0] (2B-point r2c, B + 1 bins, planar), pre-scaled by
+     * gain / (2B) (the c2r is unnormalised) */
+    int rv_P;
+    float *rv_hr, *rv_hi;
+    jfo_plan rv_ph, rv_pf; /* n = B and n = 2B */
 };
 
 jfo_engine *jfo_create(int B, int hrtf_len, int n_sources, const float *hrir, int taps) {
@@ -449,6 +458,8 @@ jfo_engine *jfo_create(int B, int hrtf_len, int n_sources, const float *hrir, in
     return e;
 }
 
+static void reverb_free(jfo_engine *e);
+
 void jfo_destroy(jfo_engine *e) {
     if (!e) return;
     for (int s = 0; s < e->n_sources; s++) {
@@ -456,6 +467,7 @@ void jfo_destroy(jfo_engine *e) {
         free(e->src[s].x);
         free(e->src[s].last);
     }
+    reverb_free(e);
     free(e->src);
     free(e->table);
     plan_free(&e->ph);
@@ -512,6 +524,184 @@ void jfo_source_reset(jfo_engine *e, int s) {
     q->count = 0;
     q->old_azi = 0.0f;
     q->old_ele = 0.0f;
+    if (e->rv_P > 0) {
+        const size_t nb = (size_t)e->rv_P * (size_t)(e->B + 1);
+        memset(q->rv_xr, 0, sizeof(float) * nb);
+        memset(q->rv_xi, 0, sizeof(float) * nb);
+        memset(q->rv_prev, 0, sizeof(float) * (size_t)e->B);
+        q->rv_head = 0;
+    }
+}
+
+static size_t scratch_floats_spat(const jfo_engine *e) {
+    return (size_t)e->Nc * 8 + (size_t)e->N * 5 + 16;
+}
+
+/* ------------------------------------------------------ convolution reverb --
+ * The reference convolves the whole input file with a reverb impulse response before playback and
+ * matches the result's RMS to the input's (cudaPart.cu:65-205: PadData :87-88, r2c of both :138-139,
+ * pointwise product scaled by 1/new_size :146, c2r :153, rms / rms2 gain :118,161-165); the result
+ * becomes the source's looped `buf` (:171-172).  That code is disabled (reverbFlag = false, :20) and
+ * its kernel calls have swapped arguments (:146,165): what is restated here is
+ * its intent.  Two forms:
+ *   jfo_reverb_offline -- the reference's own whole-signal form: circular convolution of length
+ *     new_size with the RMS gain, as cudaFFT would leave it in `buf`;
+ *   jfo_reverb_set_ir  -- the same convolution as a stream ahead of the spatialiser (what a real-time
+ *     engine has to do): every block of B dry samples goes through a uniformly partitioned
+ *     overlap-save convolution (partitions of B taps, 2B-point transforms, a delay line of the last P
+ *     input spectra) and the window of the spatialiser is fed the reverberated block.  Float32
+ *     throughout, the products added in partition order p = 0 .. P-1. */
+static void reverb_free(jfo_engine *e) {
+    if (e->rv_P <= 0) return;
+    for (int s = 0; s < e->n_sources; s++) {
+        free(e->src[s].rv_xr);
+        free(e->src[s].rv_xi);
+        free(e->src[s].rv_prev);
+        e->src[s].rv_xr = e->src[s].rv_xi = e->src[s].rv_prev = NULL;
+    }
+    free(e->rv_hr);
+    free(e->rv_hi);
+    e->rv_hr = e->rv_hi = NULL;
+    plan_free(&e->rv_ph);
+    plan_free(&e->rv_pf);
+    e->rv_P = 0;
+}
+
+int jfo_reverb_set_ir(jfo_engine *e, const float *ir, int n_ir, float gain) {
+    const int B = e->B, nb = B + 1;
+    if (n_ir < 0 || (n_ir > 0 && !ir) || (B & (B - 1))) return -1;
+    reverb_free(e);
+    for (int s = 0; s < e->n_sources; s++) jfo_source_reset(e, s); /* as the engine does when the stage changes */
+    if (n_ir == 0) return 0;
+    const int P = (n_ir + B - 1) / B;
+    plan_init(&e->rv_ph, B);
+    plan_init(&e->rv_pf, 2 * B);
+    e->rv_hr = (float *)calloc((size_t)P * nb, sizeof(float));
+    e->rv_hi = (float *)calloc((size_t)P * nb, sizeof(float));
+    float *x = (float *)malloc(sizeof(float) * 2 * (size_t)B);
+    float *X = (float *)malloc(sizeof(float) * 2 * (size_t)nb);
+    float *work = (float *)malloc(sizeof(float) * 2 * (size_t)B);
+    const float scale = gain / (float)(2 * B);
+    for (int p = 0; p < P; p++) {
+        memset(x, 0, sizeof(float) * 2 * (size_t)B);
+        for (int n = 0; n < B && p * B + n < n_ir; n++) x[n] = ir[p * B + n];
+        rfft_plan(&e->rv_ph, &e->rv_pf, x, X, work);
+        for (int k = 0; k < nb; k++) {
+            e->rv_hr[(size_t)p * nb + k] = X[2 * k] * scale;
+            e->rv_hi[(size_t)p * nb + k] = X[2 * k + 1] * scale;
+        }
+    }
+    free(x);
+    free(X);
+    free(work);
+    for (int s = 0; s < e->n_sources; s++) {
+        jfo_source *q = &e->src[s];
+        q->rv_xr = (float *)calloc((size_t)P * nb, sizeof(float));
+        q->rv_xi = (float *)calloc((size_t)P * nb, sizeof(float));
+        q->rv_prev = (float *)calloc((size_t)B, sizeof(float));
+        q->rv_head = 0;
+    }
+    e->rv_P = P;
+    return 0;
+}
+
+/* One block of one source through the stream form: blk[B] holds the dry block on entry, the reverberated block on
+ * return.  scratch: 12 B + 16 floats. */
+static void reverb_block(const jfo_engine *e, jfo_source *q, float *blk, float *scratch) {
+    const int B = e->B, nb = B + 1, P = e->rv_P;
+    float *in = scratch;             /* 2B: [previous dry block, this dry block] */
+    float *X = in + 2 * B;           /* 2 nb */
+    float *Y = X + 2 * nb;           /* 2 nb */
+    float *z = Y + 2 * nb;           /* 4B: complex output of the c2r */
+    float *work = z + 4 * B;         /* 2B */
+    memcpy(in, q->rv_prev, sizeof(float) * (size_t)B);
+    memcpy(in + B, blk, sizeof(float) * (size_t)B);
+    memcpy(q->rv_prev, blk, sizeof(float) * (size_t)B);
+    rfft_plan(&e->rv_ph, &e->rv_pf, in, X, work);
+    float *xr = q->rv_xr + (size_t)q->rv_head * nb, *xi = q->rv_xi + (size_t)q->rv_head * nb;
+    for (int k = 0; k < nb; k++) {
+        xr[k] = X[2 * k];
+        xi[k] = X[2 * k + 1];
+    }
+    float *restrict yr = Y, *restrict yi = Y + nb;
+    for (int k = 0; k < nb; k++) yr[k] = yi[k] = 0.0f;
+    int slot = q->rv_head;
+    for (int p = 0; p < P; p++) { /* planar and restrict-qualified so that the compiler vectorises over the bins */
+        const float *restrict ar = q->rv_xr + (size_t)slot * nb, *restrict ai = q->rv_xi + (size_t)slot * nb;
+        const float *restrict hr = e->rv_hr + (size_t)p * nb, *restrict hi = e->rv_hi + (size_t)p * nb;
+        for (int k = 0; k < nb; k++) {
+            yr[k] += ar[k] * hr[k] - ai[k] * hi[k];
+            yi[k] += ar[k] * hi[k] + ai[k] * hr[k];
+        }
+        slot = slot == 0 ? P - 1 : slot - 1;
+    }
+    q->rv_head = q->rv_head + 1 == P ? 0 : q->rv_head + 1;
+    for (int k = 0; k < nb; k++) {
+        X[2 * k] = yr[k];
+        X[2 * k + 1] = yi[k];
+    }
+    irfft2_plan(&e->rv_pf, X, NULL, z);
+    for (int n = 0; n < B; n++) blk[n] = z[2 * (B + n)]; /* overlap-save: the last B samples are valid */
+}
+
+/* cudaPart.cu:87-88 / kernels.cu:169-188: both signals zero-padded to new_size */
+int jfo_reverb_padded_size(int n, int n_ir) { return n + (n_ir - n_ir / 2); }
+
+/* cudaPart.cu:118 and :161: sqrt(sum(x^2) / new_size).  (thrust::transform_reduce adds floats in an unspecified
+ * tree order; the sum is formed in double here and rounded once.) */
+static float rms_of(const float *x, int n) {
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) acc += (double)x[i] * (double)x[i];
+    return (float)sqrt(acc / (double)n);
+}
+
+/* The whole-signal form, cudaPart.cu:87-172: out[new_size] = (rms / rms2) * c2r(r2c(x) * r2c(ir) / new_size), a
+ * CIRCULAR convolution of length new_size (the tail of the linear convolution wraps onto the start).  new_size is
+ * not a power of two in general and this oracle's FFT is radix-2, so the linear convolution is formed with a
+ * power-of-two transform and folded -- the same numbers up to float32 rounding.  Returns rms / rms2 (1 if either is 0). */
+float jfo_reverb_offline(const float *x, int n, const float *ir, int n_ir, float *out) {
+    if (n <= 0 || n_ir <= 0 || n > (1 << 28) || n_ir > (1 << 28)) return 1.0f;
+    const int new_size = jfo_reverb_padded_size(n, n_ir);
+    int m = 1;
+    while (m < n + n_ir) m <<= 1;
+    jfo_plan ph, pf;
+    plan_init(&ph, m / 2);
+    plan_init(&pf, m);
+    float *a = (float *)calloc((size_t)m, sizeof(float));
+    float *b = (float *)calloc((size_t)m, sizeof(float));
+    float *A = (float *)malloc(sizeof(float) * ((size_t)m + 2));
+    float *Bs = (float *)malloc(sizeof(float) * ((size_t)m + 2));
+    float *work = (float *)malloc(sizeof(float) * (size_t)m);
+    float *z = (float *)malloc(sizeof(float) * 2 * (size_t)m);
+    memcpy(a, x, sizeof(float) * (size_t)n);
+    memcpy(b, ir, sizeof(float) * (size_t)n_ir);
+    rfft_plan(&ph, &pf, a, A, work);
+    rfft_plan(&ph, &pf, b, Bs, work);
+    const float scale = 1.0f / (float)m;
+    for (int k = 0; k <= m / 2; k++) { /* kernels.cu:44-53: (a * b) * scale */
+        const float cr = A[2 * k] * Bs[2 * k] - A[2 * k + 1] * Bs[2 * k + 1];
+        const float ci = A[2 * k] * Bs[2 * k + 1] + A[2 * k + 1] * Bs[2 * k];
+        A[2 * k] = scale * cr;
+        A[2 * k + 1] = scale * ci;
+    }
+    irfft2_plan(&pf, A, NULL, z);
+    for (int i = 0; i < new_size; i++) out[i] = 0.0f;
+    for (int i = 0; i < n + n_ir - 1; i++) out[i % new_size] += z[2 * i];
+    double e_in = 0.0; /* the padded signal's rms: its new_size - n zeros add nothing to the sum */
+    for (int i = 0; i < n; i++) e_in += (double)x[i] * (double)x[i];
+    const float rms = (float)sqrt(e_in / (double)new_size), rms2 = rms_of(out, new_size);
+    float g = 1.0f;
+    if (rms > 0.0f && rms2 > 0.0f) g = rms / rms2;
+    for (int i = 0; i < new_size; i++) out[i] *= g; /* cudaPart.cu:165 */
+    free(a);
+    free(b);
+    free(A);
+    free(Bs);
+    free(work);
+    free(z);
+    plan_free(&ph);
+    plan_free(&pf);
+    return g;
 }
 
 /* One filter set: Y = sum_i ((X * H_i) * w_i) * D, then both c2r.
@@ -577,6 +767,8 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
             n += chunk;
         }
     }
+    /* reverb on: the B samples just fed are the DRY block; the window gets the reverberated block instead */
+    if (e->rv_P > 0) reverb_block(e, q, dst, scratch + scratch_floats_spat(e));
 
     /* CPUSoundSource.cpp:279-280 / GPUSoundSource.cu:344-346 */
     rfft_plan(&e->ph, &e->pf, q->x, X, work);
@@ -635,7 +827,8 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
 }
 
 static size_t scratch_floats(const jfo_engine *e) {
-    return (size_t)e->Nc * 8 + (size_t)e->N * 5 + 16;
+    /* the spatialiser's part + the reverb stage's: input 2B, spectrum 2(B+1), sums 2(B+1), c2r output 4B, work 2B */
+    return scratch_floats_spat(e) + (size_t)12 * (size_t)e->B + 16;
 }
 
 /* Audio.cu:94-163 */

@@ -102,6 +102,22 @@ void jfo_process_batch(jfo_engine *e, int n_blocks, const float *pos,
                        float *out_mix, float *out_partial, int n_threads);
 int jfo_num_threads(void);
 
+/*
+ * Convolution reverb ahead of the spatialiser -- the intent of the reference's offline cudaFFT
+ * (cudaPart.cu:65-205; disabled there and called with swapped arguments).
+ * jfo_reverb_set_ir: stream form.  From the next block on every source's dry signal is convolved with
+ *   gain * ir before it enters the spatialiser's window (uniformly partitioned overlap-save, partitions of
+ *   frames_per_buffer taps, float32); n_ir = 0 switches the stage off.  Resets every source.  Returns -1
+ *   for a block size that is not a power of two.
+ * jfo_reverb_offline: the reference's whole-signal form -- out[jfo_reverb_padded_size(n, n_ir)] = the
+ *   circular convolution of the zero-padded signal and impulse response (cudaPart.cu:87-153) scaled by
+ *   rms(x) / rms(x (*) ir) (:118,161-165); returns that gain.  The product path's counterpart of the gain
+ *   is jf_reverb_rms_gain.
+ */
+int jfo_reverb_set_ir(jfo_engine *e, const float *ir, int n_ir, float gain);
+int jfo_reverb_padded_size(int n, int n_ir);
+float jfo_reverb_offline(const float *x, int n, const float *ir, int n_ir, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,12 @@ def lib():
         L.jfo_source_last_block.restype = _f
         L.jfo_process_batch.argtypes = [C.c_void_p, C.c_int, _f, _f, _f, C.c_int]
         L.jfo_num_threads.restype = C.c_int
+        L.jfo_reverb_set_ir.argtypes = [C.c_void_p, _f, C.c_int, C.c_float]
+        L.jfo_reverb_set_ir.restype = C.c_int
+        L.jfo_reverb_padded_size.argtypes = [C.c_int, C.c_int]
+        L.jfo_reverb_padded_size.restype = C.c_int
+        L.jfo_reverb_offline.argtypes = [_f, C.c_int, _f, C.c_int, _f]
+        L.jfo_reverb_offline.restype = C.c_float
         _lib = L
     return _lib
 
@@ -157,6 +163,15 @@ def irfft(X, N):
     return y
 
 
+def reverb_offline(x, ir):
+    """cudaPart.cu:87-172 as jfo_reverb_offline restates it: (buf of new_size samples, rms gain)."""
+    x = np.ascontiguousarray(x, np.float32)
+    ir = np.ascontiguousarray(ir, np.float32)
+    out = np.zeros(lib().jfo_reverb_padded_size(len(x), len(ir)), np.float32)
+    g = lib().jfo_reverb_offline(fptr(x), len(x), fptr(ir), len(ir), fptr(out))
+    return out, float(g)
+
+
 class Engine:
     """Same method names as the HIP engine binding so tests read alike."""
 
@@ -191,6 +206,10 @@ class Engine:
 
     def reset(self, s):
         lib().jfo_source_reset(self.h, s)
+
+    def set_reverb(self, ir, gain=1.0):
+        ir = np.ascontiguousarray(ir, np.float32)
+        assert lib().jfo_reverb_set_ir(self.h, fptr(ir) if len(ir) else None, len(ir), gain) == 0
 
     def process_block(self):
         out = np.zeros(2 * self.B, np.float32)

@@ -167,12 +167,14 @@ def _reverb_model_blocks(hrir, B, K, ir, gain, sig, pos_s):
     return p[0]
 
 
-@pytest.mark.parametrize("S,K,form", [(16, 32, 3), (256, 32, 0)])
+@pytest.mark.parametrize("S,K,form", [(16, 32, 3), (256, 32, 0), (256, 256, 0)])
 def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K, form):
-    """BASELINE.json configs[4]: B = 128, 2.0 s impulse response = 690 partitions, 32 blocks per call as
-    bench.py --reverb runs it.  (16 sources, form 3 pinned) and (256 sources, the form the engine picks by
-    itself -- the block-tiled kernel at this size): per-source blocks of sampled sources against
-    gain * float64 convolution -> float64 spatialiser model, and the mix as the ordered sum of the blocks."""
+    """BASELINE.json configs[4]: B = 128, 2.0 s impulse response = 690 partitions.  (16 sources x 32 blocks, form 3
+    pinned), (256 sources x 32 blocks: one pass of tiles) and (256 sources x 256 blocks per call -- the shape
+    `bench.py --reverb` times: a delay-line ring of 690 + 256 slots, 16 tiles per source), each as TWO consecutive
+    calls so that the delay line, the wet ring and the windows carry over.  Per-source blocks of sampled sources
+    against the float32 C oracle with its reverb stage (jfo_reverb_set_ir) and against gain * float64 convolution ->
+    float64 spatialiser model; the mix as the ordered sum of the blocks."""
     B = 128
     ir = _ir(88200)
     assert -(-len(ir) // B) == 690
@@ -190,19 +192,71 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     for c in range(2):               # two calls: the delay line and the wet ring carry over
         e.batch_run(c * K, K)
         e.synchronize()
+        if K >= 16:
+            assert "reverb_mac_tiled_kernel<128,16>" in e.last_kernels()
         parts.append(e.read_device(e.partial_device_ptr(), (K, S, 2 * B)))
         mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
     e.close()
     part, mix = np.concatenate(parts), np.concatenate(mixes)
     assert np.array_equal(mix, _ordered_mix(part))
     tol = 2e-7 + 1e-7 * np.sqrt(690)          # float32 accumulation over 690 partitions
-    sample = range(S) if S <= 16 else (0, 3, 100, 255)
+    sample = list(range(S)) if S <= 16 else [0, 3, 100, 255]
+    # float32 C oracle: the sampled sources as an engine of their own (sources are independent until the mix)
+    ora = oracle_lib.Engine(B, 512, len(sample), hrir)
+    for j, s in enumerate(sample):
+        ora.set_signal(j, sigs[s])
+    ora.set_reverb(ir, gain)
+    _, opart = ora.process_batch(np.ascontiguousarray(pos[:, sample]), want_partial=True)
+    ora.close()
     peak = 0.0
-    for s in sample:
+    for j, s in enumerate(sample):
+        assert np.abs(part[:, s] - opart[j]).max() <= 2 * tol * max(1.0, np.abs(opart[j]).max()), s   # two float32 paths
+        if K > 64 and j > 0:
+            continue                  # the float64 convolution of 512 blocks for one source is enough
         want = _reverb_model_blocks(hrir, B, 2 * K, ir, gain, sigs[s], pos[:, s])
         peak = max(peak, np.abs(want).max())
         assert np.abs(part[:, s] - want).max() <= tol * max(1.0, np.abs(want).max()), s
     assert peak > 0.01
+
+
+def test_realtime_reverb_reaches_the_reference_offline_form(jf, hrir, castanets):
+    """The reference's reverb is a whole-signal product (cudaPart.cu:87-172): circular convolution of the zero-padded
+    input with the impulse response, scaled by rms / rms2, looped as the source's `buf`.  The engine's stream form run
+    over the same zero-padded signal on a loop, with jf_reverb_rms_gain as its gain, must equal -- from the second pass
+    on -- the engine WITHOUT reverb playing the oracle's offline result (jfo_reverb_offline): the wrap of the circular
+    product is the previous pass's tail.  Per-block calls (the fused real-time reverb kernel) and one batch call."""
+    B, n, n_ir = 128, 4 * 128 * 5, 1100
+    x = castanets[2000:2000 + n]
+    ir = (np.random.default_rng(3).standard_normal(n_ir) * np.exp(-4.0 * np.arange(n_ir) / n_ir)).astype(np.float32)
+    buf, g = oracle_lib.reverb_offline(x, ir)
+    assert jf.reverb_rms_gain(x, ir) == pytest.approx(g, rel=2e-6)
+    new_size = len(buf)
+    K = 2 * (-(-new_size // B)) + 3
+    pos = np.zeros((K, 1, 5), np.float32)
+    for b in range(K):
+        pos[b, 0] = jf.position_from_spherical(5, (3 + b) % 360, 0.7)
+    ref = jf.Engine(B, 512, 1, hrir=hrir, max_batch_blocks=K)
+    ref.set_signal(0, buf)
+    want = ref.process_batch(pos)
+    ref.close()
+    first = -(-new_size // B) + 8
+    assert np.abs(want[first:]).max() > 0.02
+    for blockwise in (False, True):
+        e = jf.Engine(B, 512, 1, hrir=hrir, max_batch_blocks=K)
+        e.set_signal(0, np.pad(x, (0, new_size - n)))
+        e.set_reverb(ir, jf.reverb_rms_gain(x, ir))
+        if blockwise:
+            got = []
+            for b in range(K):
+                e.set_spherical(0, 5, (3 + b) % 360, 0.7)
+                got.append(e.process_block())
+            got = np.array(got)
+            assert "reverb_mac_kernel<128,1,true>" in e.last_kernels()
+        else:
+            got = e.process_batch(pos)
+        e.close()
+        assert np.abs(got[first:] - want[first:]).max() <= 2e-6 * max(1.0, np.abs(want).max())
+        assert np.abs(got[:4] - want[:4]).max() > 1e-3
 
 
 # ------------------------------------------------------------- 512-tap HRIRs --

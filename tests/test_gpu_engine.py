@@ -524,18 +524,183 @@ def test_group_of_one_gpu_equals_the_engine(jf, hrir, castanets):
             assert eng.set_spherical(s, 10, (30 * s + 5 * k) % 360, 1.0) == jf.JF_OK
         assert np.array_equal(g.process_block(), eng.process_block())
     assert g.set_spherical(S, 0, 0, 1.0) == jf.JF_ERR_ARG
+    # the job-wide controls: reverb stage, nearest-HRTF mode, pause, reset -- forwarded to every engine
+    ir = (np.random.default_rng(8).standard_normal(700) * np.exp(-np.arange(700) / 150.0) * 0.1).astype(np.float32)
+    eng.set_reverb(ir, 0.9)
+    g.set_reverb(ir, 0.9)
+    for k in range(10):
+        if k in (3, 6):
+            eng.set_mode(jf.JF_MODE_FD_BASIC if k == 3 else jf.JF_MODE_FD_COMPLEX)
+            assert g.set_mode(jf.JF_MODE_FD_BASIC if k == 3 else jf.JF_MODE_FD_COMPLEX) == jf.JF_OK
+        if k in (7, 8):
+            eng.set_pause(k == 7)
+            g.set_pause(k == 7)
+        if k == 9:
+            eng.reset(5)
+            g.reset(5)
+        a, b = g.process_block(), eng.process_block()
+        assert np.array_equal(a, b)
+        assert g.last_block_peak() == eng.last_block_peak() == float(np.abs(b).max())
+        assert (np.abs(b).max() == 0) == (k == 7)
+    assert g.set_mode(5) == jf.JF_ERR_ARG and g.failed() == 0
     g.close()
     eng.close()
 
 
-@pytest.mark.parametrize("args", [["pa"], ["group", "1"]])
+@pytest.mark.parametrize("args", [["pa"], ["group", "1"], ["bench", "1", "24"]])
 def test_plain_c_boundary_checks(args):
     """jf_ctest.c (plain C, linked against the C ABI only): `pa` drives jf_pa_callback with PortAudio's argument list
     for 200 blocks -- positions and pause changed in between -- against jf_callback on a twin engine (paCallback,
-    Audio.cu:164-175); `group 1` runs jefferson_group.h over one GPU (RCCL communicator of size 1) against one engine."""
+    Audio.cu:164-175); `group 1` runs jefferson_group.h over one GPU (RCCL communicator of size 1) against one engine,
+    then again with the job-wide controls (reverb stage, mode switch, pause, reset, clip peak: Audio.cu:101,104,111-113,
+    cudaPart.cu:65-205); `bench 1` drives the bench workload (1024 moving sources, 128 blocks of 256 per run) through
+    jf_group_batch_run / _fetch and prints bench.py's metric."""
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "jefferson-2.0_amd", "jf_ctest")
-    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, (r.stdout.decode(), r.stderr.decode())
-    assert b"max" in r.stdout
+    if args[0] == "bench":
+        import re
+        m = re.search(rb"([0-9.e+]+) source-frames/s", r.stdout)
+        assert m and float(m.group(1)) > 2e10, r.stdout      # a C host gets the kernels' throughput, not a toy figure
+    else:
+        assert b"max" in r.stdout
+    if args[0] == "group":
+        assert b"group controls" in r.stdout
+
+
+def test_pair_hand_off_time_out_is_reported_not_hung():
+    """The batch kernel's waits between the two wavefronts of a pair are bounded.  With the fault-injection build of
+    the library (csrc/Makefile: libjefferson_hip_droppub.so = -DJF_EXP_DROP_PUBLISH, jf_experiments.h: one wavefront of
+    the grid stops announcing its hand-offs) the partner's wait must run out, the kernel must drain, and the engine
+    must say so: JF_ERR_DEVICE with the hand-off text from jf_synchronize, from a per-block call that takes the pair
+    kernel, and from everything afterwards; destroying the engine works.  One run, in a child process of its own
+    (the library is chosen when the binding is loaded)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "jefferson-2.0_amd", "libjefferson_hip_droppub.so")
+    assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc builds it"
+    code = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ["JF_ROOT"])
+from jf_load import jf
+hrir = np.load(os.path.join(os.environ["JF_ROOT"], "tests", "golden", "kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
+rng = np.random.default_rng(1)
+S, K, B = 64, 8, 256
+pos = np.zeros((K, S, 5), np.float32)
+for k in range(K):
+    for s in range(S):
+        pos[k, s] = jf.position_from_spherical(0, (5 * s + k) % 360, 1.0)
+# --- batch call through the pair kernel
+e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+for s in range(S):
+    e.set_signal(s, rng.uniform(-.5, .5, 5000).astype(np.float32))
+e.set_source_group(8)
+e.upload_positions(pos)
+t0 = time.perf_counter()
+e.batch_run(0, K)
+try:
+    e.synchronize()
+    print("NO_ERROR_FROM_SYNCHRONIZE")
+except jf.JfError as ex:
+    print("SYNC", ex.code, str(ex))
+print("SECONDS %.3f" % (time.perf_counter() - t0))
+assert "fused_pair_kernel" in e.last_kernels()
+for what, call in (("RUN", lambda: e.batch_run(0, K)), ("BLOCK", e.process_block), ("BATCH", lambda: e.process_batch(pos))):
+    try:
+        call()
+        print(what, "NO_ERROR")
+    except jf.JfError as ex:
+        print(what, ex.code)
+e.close()
+# --- per-block calls that take the pair kernel (more sources than the one-launch kernel is allowed)
+e = jf.Engine(B, 512, S, hrir=hrir)
+for s in range(S):
+    e.set_signal(s, rng.uniform(-.5, .5, 5000).astype(np.float32))
+e.set_rt_max_sources(0)
+e.set_source_group(8)
+try:
+    e.process_block()
+    print("COLLECT NO_ERROR")
+except jf.JfError as ex:
+    print("COLLECT", ex.code, str(ex))
+assert "fused_pair_kernel" in e.last_kernels()
+out = np.ones(2 * B, np.float32)
+rc = jf.lib().jf_pa_callback(None, out.ctypes.data_as(jf.C.c_void_p), B, None, 0, e.h)
+print("PA", rc, float(np.abs(out).max()))
+e.close()
+print("CLOSED")
+'''
+    env = dict(os.environ, JF_ROOT=ROOT, JF_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, (out, r.stderr.decode(errors="replace")[-2000:])
+    lines = dict(l.split(" ", 1) for l in out.splitlines() if " " in l)
+    assert lines["SYNC"].startswith("-3 ") and "hand-off timed out" in lines["SYNC"], out
+    assert float(lines["SECONDS"]) < 2.0, out        # one bounded wait (~0.1 s), not a hang
+    assert lines["RUN"] == "-3" and lines["BLOCK"] == "-3" and lines["BATCH"] == "-3", out   # fatal from then on
+    assert lines["COLLECT"].startswith("-3 ") and "hand-off timed out" in lines["COLLECT"], out
+    assert lines["PA"] == "0 0.0", out               # PortAudio gets silence, never garbage
+    assert "CLOSED" in out
+
+
+def test_source_order_contract_when_a_run_resolves_to_single_sources(jf, hrir, castanets):
+    """Automatic grouping sorts the sources by table row (jf_debug_source_order) for the pair kernel.  A run that
+    resolves to G = 1 -- an odd number of sources, or a small call -- goes through the per-source kernel, whose block u
+    IS source u: the reported order is then the identity, and the blocks match the oracle source by source."""
+    B = 256
+    for S, K in ((7, 6), (12, 2)):
+        pos = np.zeros((K, S, 5), np.float32)
+        for k in range(K):
+            for s in range(S):
+                pos[k, s] = jf.position_from_spherical(60 - 13 * s, (301 * s + 2 * k) % 360, 0.6 + 0.1 * s)   # rows far apart
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+        ora = oracle_lib.Engine(B, 512, S, hrir)
+        for s in range(S):
+            sig = np.roll(castanets, 3001 * s)[:15000]
+            e.set_signal(s, sig)
+            ora.set_signal(s, sig)
+        e.upload_positions(pos)
+        e.batch_run(0, K)
+        e.synchronize()
+        assert e.last_source_group() == 1
+        assert np.array_equal(e.source_order(), np.arange(S))
+        part = e.read_device(e.partial_device_ptr(), (K, S, 2 * B))
+        e.close()
+        _, opart = ora.process_batch(pos, want_partial=True)
+        ora.close()
+        for s in range(S):
+            assert np.abs(opart[s]).max() > 1e-3
+            assert np.abs(part[:, s] - opart[s]).max() <= 4e-7 * max(1.0, np.abs(opart[s]).max()), (S, s)
+
+
+def test_whole_bench_under_the_launcher_with_one_rank():
+    """bench.py exactly as the driver starts it for N > 1 -- `python -m torch.distributed.run --nproc-per-node=N
+    bench.py --gpus N` -- with N = 1, the only N this box has: the ranks are started before anything touches the GPU,
+    the process group is RCCL, the mix goes through the asynchronous reduce, and rank 0 prints the line with
+    `verified` and a CPU baseline on every host core this process may use (the launcher exports OMP_NUM_THREADS=1)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OMP_NUM_THREADS")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["verified"] is True, out.get("verification")
+    assert out["n_gpus"] == 1 and out["steps"] == 8
+    assert out["comm"]["backend"] == "RCCL"
+    n_cpu = len(os.sched_getaffinity(0))
+    assert out["cpu_baseline"]["cores"] > 1 or n_cpu == 1
+    assert out["roofline"]["frac"] > 0.05 and out["value"] > 1e10

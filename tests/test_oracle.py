@@ -270,3 +270,90 @@ def test_linearity_and_gain(hrir, castanets):
         e.set_spherical(0, 20, 123, 1.0)
         outs.append(np.array([e.process_block() for _ in range(4)]))
     assert np.abs(outs[0] * 0.5 - outs[1]).max() < 1e-7
+
+
+# ------------------------------------------------------------ convolution reverb --
+def _ir(n, seed=99, decay=4.0):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n) * np.exp(-decay * np.arange(n) / n)
+    return (h / np.sqrt((h ** 2).sum())).astype(np.float32)
+
+
+def test_reverb_offline_is_the_reference_whole_signal_form(castanets):
+    """jfo_reverb_offline against float64: circular convolution of length new_size = n + (n_ir - n_ir/2)
+    (PadData, kernels.cu:169-188; cudaPart.cu:87-153) times rms / rms2 (cudaPart.cu:118,161-165)."""
+    for n, n_ir in [(6000, 3001), (5000, 700), (2048, 2048)]:
+        x = castanets[1000:1000 + n]
+        h = _ir(n_ir)
+        got, g = oracle_lib.reverb_offline(x, h)
+        new_size = n + (n_ir - n_ir // 2)
+        assert len(got) == new_size
+        X = np.fft.rfft(np.pad(x.astype(np.float64), (0, new_size - n)))
+        H = np.fft.rfft(np.pad(h.astype(np.float64), (0, new_size - n_ir)))
+        y = np.fft.irfft(X * H, new_size)
+        want_g = np.sqrt((x.astype(np.float64) ** 2).sum() / (y ** 2).sum())
+        assert g == pytest.approx(want_g, rel=2e-6)
+        want = want_g * y
+        assert np.abs(want).max() > 0.05
+        # float32 transforms of 16 k points: ~log2(m) roundings of the largest sample
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("B,n_ir", [(128, 5 * 128 + 37), (256, 256 * 3), (64, 40), (128, 128 * 60 + 1)])
+def test_reverb_stream_form_vs_float64_convolution(hrir, castanets, B, n_ir):
+    """The stream form (jfo_reverb_set_ir) ahead of the spatialiser: the C oracle's stereo blocks against the
+    float64 model fed gain * (looped dry stream (*) ir) computed by direct float64 convolution.  Tolerance:
+    the spatialiser's 4e-7 (float32 C oracle against float64) + 1e-7 sqrt(P) for the float32 sum over P partitions."""
+    S, K = 2, 14
+    ir = _ir(n_ir)
+    gain = 4.0
+    P = -(-n_ir // B)
+    sigs = [castanets[3000:3000 + 2 * B + 77], castanets[9000:9000 + 5000]]   # the first loops inside a block
+    pos = np.zeros((K, S, 5), np.float32)
+    for b in range(K):
+        for s in range(S):
+            pos[b, s] = oracle_lib.from_spherical(10 * s - 5, (33 * s + 4 * (b // 2)) % 360, 0.5 + 0.6 * s)
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    mod = model64.Model(B, 512, S, hrir)
+    for s in range(S):
+        ora.set_signal(s, sigs[s])
+        stream = np.tile(sigs[s].astype(np.float64), -(-K * B // len(sigs[s])))[:K * B]
+        mod.src[s].buf = gain * np.convolve(stream, ir.astype(np.float64))[:K * B]   # kept in float64
+        mod.src[s].count = 0
+    ora.set_reverb(ir, gain)
+    got, part = ora.process_batch(pos, want_partial=True)
+    want, wpart = mod.process_batch(pos)
+    ora.close()
+    tol = (4e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(wpart).max())
+    assert np.abs(wpart).max() > 0.02
+    assert np.abs(part - wpart).max() <= tol
+    assert np.abs(got - want).max() <= tol * S
+
+
+def test_reverb_stream_form_reaches_the_offline_form(hrir, castanets):
+    """Ties the two forms together: the stream form run over the zero-padded signal on a loop (PadData's new_size
+    samples, what the reference loops as `buf` after cudaFFT) equals, from the second pass on, the spatialiser fed the
+    offline result -- the circular wrap of the reference's whole-signal product IS the previous pass's tail."""
+    B, n, n_ir = 128, 4 * 128 * 5, 1100
+    x = castanets[2000:2000 + n]
+    ir = _ir(n_ir)
+    buf, g = oracle_lib.reverb_offline(x, ir)
+    new_size = len(buf)
+    assert new_size == n + 550 and new_size % B != 0
+    K = 2 * (-(-new_size // B)) + 3
+    pos = np.zeros((K, 1, 5), np.float32)
+    for b in range(K):
+        pos[b, 0] = oracle_lib.from_spherical(5, (3 + b) % 360, 0.7)
+    a = oracle_lib.Engine(B, 512, 1, hrir)
+    a.set_signal(0, np.pad(x, (0, new_size - n)))
+    a.set_reverb(ir, g)
+    b_ = oracle_lib.Engine(B, 512, 1, hrir)
+    b_.set_signal(0, buf)
+    ya = a.process_batch(pos)
+    yb = b_.process_batch(pos)
+    a.close()
+    b_.close()
+    first = -(-new_size // B) + 8     # blocks whose 1024-sample window lies wholly in the second pass
+    assert np.abs(yb[first:]).max() > 0.02
+    assert np.abs(ya[first:] - yb[first:]).max() <= 2e-6 * max(1.0, np.abs(yb).max())
+    assert np.abs(ya[:4] - yb[:4]).max() > 1e-3     # the first pass has no tail wrapped onto it yet
