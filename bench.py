@@ -140,7 +140,8 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
         bound = 3e-6 * max(1.0, peak) * max(1.0, S / 1024.0)
         tol_src = TOL32
     else:
-        tol_src = 4e-7 + 2e-7 * float(np.sqrt(-(-len(reverb[0]) // B)))
+        # (measured on MI355X at 690 partitions: 8e-8 per source, 4e-7 per group of 16, 9e-7 on the mix of 256)
+        tol_src = TOL32 + 2e-8 * float(np.sqrt(-(-len(reverb[0]) // B)))
         src_peak = float(np.abs(opart[:, -KB:]).max())
         bound = tol_src * max(1.0, src_peak) * float(np.sqrt(S)) + 3e-6 * max(1.0, peak)
     ok = err_mix <= bound

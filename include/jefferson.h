@@ -255,7 +255,7 @@ int jf_debug_set_source_group(jf_engine *e, int group);
  * jf_debug_last_source_group.  With automatic grouping jf_batch_upload_positions orders the sources by the table row
  * nearest to their first position (units that run side by side then read neighbouring rows of the table); with a
  * pinned group size, and whenever the last run resolved to G = 1 (per-source blocks: block u of
- * jf_batch_partial_device is source u), the identity. */
+ * jf_batch_partial_device is source u), the identity.  Before the first run: the order a grouped run will take. */
 int jf_debug_source_order(const jf_engine *e, int *order);
 /* Form of the reverb's multiply-accumulate stage: 0 = by call size (default); 1 = one workgroup per
  * (block, source) -- what real-time calls use; 2 = groups of sources share each IR partition spectrum;

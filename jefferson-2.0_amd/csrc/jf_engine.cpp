@@ -1080,7 +1080,7 @@ int jf_debug_set_source_group(jf_engine *e, int group) {
 int jf_debug_source_order(const jf_engine *e, int *order) {
     if (!e || !order) return JF_ERR_ARG;
     // the per-source kernel (a run that resolved to G = 1) does not go through the order: its block u is source u
-    for (int s = 0; s < e->S; s++) order[s] = e->last_group > 1 ? e->order[s] : s;
+    for (int s = 0; s < e->S; s++) order[s] = e->last_group == 1 ? s : e->order[s];  // (no run yet: what a grouped run takes)
     return JF_OK;
 }
 

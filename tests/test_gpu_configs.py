@@ -256,7 +256,7 @@ def test_realtime_reverb_reaches_the_reference_offline_form(jf, hrir, castanets)
             got = e.process_batch(pos)
         e.close()
         assert np.abs(got[first:] - want[first:]).max() <= 2e-6 * max(1.0, np.abs(want).max())
-        assert np.abs(got[:4] - want[:4]).max() > 1e-3
+        assert np.abs(got[:4] - want[:4]).max() > 1e-4     # the first pass has no tail wrapped onto it yet
 
 
 # ------------------------------------------------------------- 512-tap HRIRs --

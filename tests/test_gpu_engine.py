@@ -608,7 +608,7 @@ try:
 except jf.JfError as ex:
     print("SYNC", ex.code, str(ex))
 print("SECONDS %.3f" % (time.perf_counter() - t0))
-assert "fused_pair_kernel" in e.last_kernels()
+assert any("fused_pair_kernel" in k for k in e.last_kernels())
 for what, call in (("RUN", lambda: e.batch_run(0, K)), ("BLOCK", e.process_block), ("BATCH", lambda: e.process_batch(pos))):
     try:
         call()
@@ -627,7 +627,7 @@ try:
     print("COLLECT NO_ERROR")
 except jf.JfError as ex:
     print("COLLECT", ex.code, str(ex))
-assert "fused_pair_kernel" in e.last_kernels()
+assert any("fused_pair_kernel" in k for k in e.last_kernels())
 out = np.ones(2 * B, np.float32)
 rc = jf.lib().jf_pa_callback(None, out.ctypes.data_as(jf.C.c_void_p), B, None, 0, e.h)
 print("PA", rc, float(np.abs(out).max()))
@@ -656,11 +656,11 @@ def test_source_order_contract_when_a_run_resolves_to_single_sources(jf, hrir, c
         pos = np.zeros((K, S, 5), np.float32)
         for k in range(K):
             for s in range(S):
-                pos[k, s] = jf.position_from_spherical(60 - 13 * s, (301 * s + 2 * k) % 360, 0.6 + 0.1 * s)   # rows far apart
+                pos[k, s] = jf.position_from_spherical(60 - 9 * s, (301 * s + 2 * k) % 360, 0.6 + 0.1 * s)   # rows far apart
         e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
         ora = oracle_lib.Engine(B, 512, S, hrir)
         for s in range(S):
-            sig = np.roll(castanets, 3001 * s)[:15000]
+            sig = np.random.default_rng(s).uniform(-0.5, 0.5, 15000).astype(np.float32)
             e.set_signal(s, sig)
             ora.set_signal(s, sig)
         e.upload_positions(pos)
