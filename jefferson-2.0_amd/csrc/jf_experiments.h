@@ -13,6 +13,7 @@
 //   JF_EXP_NOROWLOAD     the half-filter's arithmetic without its table-row loads
 //   JF_EXP_NOWAIT        no hand-off waits between the waves of a pair
 //   JF_EXP_NOFILTER      fronts and hand-offs only
+//   JF_EXP_PHASES        per-wave cycle counters of the pair kernel's phases (correct results): profiles/phases.py
 //   JF_EXP_STAMPS        per-pair time stamps (correct results): profiles/stamps.py
 //   JF_EXP_DROP_PUBLISH  fault injection: one wave of the grid stops announcing its hand-offs, so its partner's bounded
 //                        wait must time out and raise the host-visible error word (tests/test_gpu_engine.py)
@@ -103,6 +104,32 @@
 #define JF_EXP_STAMP_SETUP(P, pair, half, lane)
 #define JF_EXP_STAMP_ROUND(round)
 #define JF_EXP_STAMP_END()
+#endif
+
+// ---- fused_pair_kernel: where does a wave's TIME go?  JF_EXP_PHASES: every wave keeps eight cycle counters in LDS (no
+// registers besides the last time stamp); JF_EXP_PHASE(k) adds the shader-clock cycles since the previous marker to
+// counter k.  At the end the counters go behind the error word: [workgroup][wave][8] unsigned (profiles/phases.py).
+// Correct results; the markers cost an s_memtime and its wait each.
+#ifdef JF_EXP_PHASES
+#define JF_EXP_PHASE_SETUP()                                                                    \
+    __shared__ unsigned s_phase[kWavesPerWg][8];                                                \
+    if (lane < 8) s_phase[wave][lane] = 0;                                                      \
+    unsigned long long t_phase_ = __builtin_amdgcn_s_memtime()
+#define JF_EXP_PHASE(k)                                                                         \
+    do {                                                                                        \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();                         \
+        if (lane == 0) atomicAdd(&s_phase[wave][k], (unsigned)(t_now_ - t_phase_));             \
+        t_phase_ = t_now_;                                                                      \
+    } while (0)
+#define JF_EXP_PHASE_END(P)                                                                     \
+    do {                                                                                        \
+        unsigned *o_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>((P).err) + 16);    \
+        if (lane < 8 && blockIdx.x < 64) o_[(blockIdx.x * kWavesPerWg + wave) * 8 + lane] = s_phase[wave][lane]; \
+    } while (0)
+#else
+#define JF_EXP_PHASE_SETUP()
+#define JF_EXP_PHASE(k)
+#define JF_EXP_PHASE_END(P)
 #endif
 
 // ---- reverb_mac_tiled_kernel

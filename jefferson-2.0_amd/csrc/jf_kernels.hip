@@ -990,6 +990,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     const int pair = wave >> 1, half = wave & 1;
 #endif
     JF_EXP_STAMP_SETUP(P, pair, half, lane);
+    JF_EXP_PHASE_SETUP();
     float2 *base = s_pair + pair * kPairLds;
     float2 *buf = base + half * kPairWave;  // my FFT work space
     float2 *mail = buf + kPairWork;         // my two mailbox slots
@@ -1063,6 +1064,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             any_xfade = any_xfade || ((d->flags & 2) != 0 && d->n_new > 0);
         }
         mail_free(npub);  // the last unit's final hand-offs used both slots
+        JF_EXP_PHASE(6);  // unit start: descriptor scan, waiting for the partner's last reads
         // sums over the unit's sources of Z[k] and Z[N-k], k = lane + 64 (qb + q), old and new sets
         c2 zko[4], zkn[4], zmo[4], zmn[4];
 #pragma unroll
@@ -1111,7 +1113,9 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             const ItemDesc *dp = &dl;
             if (dp->n_new <= 0) return;  // silent: he published nothing
             accumulate(dp, [&](float2 (&xh)[4]) {
+                JF_EXP_PHASE(4);  // partner's source: descriptor, first row requests
                 await_partner();
+                JF_EXP_PHASE(7);  // ... waiting for his hand-off
                 const float2 *m = pmail + (nseen & 1) * kPairMail + lane;
 #pragma unroll
                 for (int q = 0; q < 4; q++) xh[q] = m[64 * q];
@@ -1142,6 +1146,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             float2 z[8];
             int count0, L;
             item_gather<NOUT>(P, b, src, opaque(lane), z, count0, L);
+            JF_EXP_PHASE(0);  // own source: descriptor and signal records, window requests
 #if JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
 #endif
@@ -1150,6 +1155,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                                                         count0, L, xd)) {
                 // (requesting my filter's first row loads before this hand-off would hold X D, 16 registers, across
                 // them: it spills)
+                JF_EXP_PHASE(1);  // window arrival, forward transform, distance factors
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
                 float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
@@ -1159,17 +1165,25 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
                     m[64 * q] = half ? xd[q] : xd[4 + q];
                 }
                 publish();
+                JF_EXP_PHASE(2);  // hand-off (waiting for a free slot, mailbox stores)
                 accumulate(dp, [&](float2 (&x)[4]) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) x[q] = xh[q];
                 });
+                JF_EXP_PHASE(3);  // own source's two half-filters
             }
 #if !JF_PAIR_OVERLAP
-            if (jp < j && jp < n_his) take_partner_source(jp++);
+            if (jp < j && jp < n_his) {
+                take_partner_source(jp++);
+                JF_EXP_PHASE(4);  // the partner's source's two half-filters (after the hand-off arrived)
+            }
 #endif
         }
 #pragma unroll 1
-        for (; jp < n_his; jp++) take_partner_source(jp);
+        for (; jp < n_his; jp++) {
+            take_partner_source(jp);
+            JF_EXP_PHASE(4);
+        }
 
         // ---- the two inverse transforms: wave 0 takes the old sum, wave 1 the new one
         const bool give = half == 0 || any_xfade;  // my bins of the sum the partner inverts
@@ -1241,8 +1255,10 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             for (int j = 0; j < NOUT; j++) out[fi + 16 * (NOUT * af + j)] = fr[j];
         }
         JF_EXP_STAMP_ROUND(round);
+        JF_EXP_PHASE(5);  // end of the unit: exchange of the sums, inverse transform, crossfade, store
     }
     JF_EXP_STAMP_END();
+    JF_EXP_PHASE_END(P);
 }
 
 // ---------------------------------------------------------------- mixing --
