@@ -13,4 +13,4 @@ for f in sys.argv[1:]:
     print(f"{f}: value {d['value']:.4g}  step {d['ms_per_step']:.4f} ms  kernel {r['kernel']} {r['avg_launch_ms']:.4f} ms  "
           f"frac {r['frac']:.3f}  verified {d.get('verified')}  valu/item {iss.get('valu_insts_per_source_block', 0):.0f}  "
           f"valu-pipe {iss.get('valu_pipe_busy_share_at_2_cycles_per_inst', 0):.2f}  vmem/item {iss.get('vmem_loads_per_source_block', 0):.1f}  "
-          f"wait {iss.get('wave_time_waiting_share', 0):.2f}  hbm {r['hbm'].get('frac')}")
+          f"wait {iss.get('wave_time_waiting_share', 0):.2f}  hbm {(r.get('hbm') or {}).get('frac')}")
