@@ -275,10 +275,11 @@ int jf_debug_last_source_group(const jf_engine *e);
 /* Caps the persistent grid of the fused kernel at `workgroups` (0 = what the device holds): with a small cap every
  * wavefront loops over several work units, which full-size calls do only beyond 4096 units. */
 int jf_debug_set_grid_limit(jf_engine *e, int workgroups);
-/* jf_batch_run prepares the descriptors of the window that FOLLOWS its own in the uploaded trajectory inside its mix
- * launch (mix_prep_kernel), and the next jf_batch_run uses them if it asks for exactly that window; anything else
- * that runs or changes the engine's state in between discards them.  on = 0 switches this off (every run launches
- * prep_kernel and mix_kernel); default on.  Results are bit-identical either way. */
+/* jf_batch_run prepares the descriptors of the window that FOLLOWS its own in the uploaded trajectory -- in trailing
+ * workgroups of the pair kernel's own launch ("fused_pair_kernel<n>+prep" in jf_debug_last_kernels), or for single
+ * sources inside its mix launch (mix_prep_kernel) -- and the next jf_batch_run uses them if it asks for exactly that
+ * window; anything else that runs or changes the engine's state in between discards them.  on = 0 switches this off
+ * (every run launches prep_kernel and mix_kernel); default on.  Results are bit-identical either way. */
 int jf_debug_set_prep_ahead(jf_engine *e, int on);
 /*
  * Stage taps the reference's own tests compare (precision_test.cu:60-75 distance factor, :225-241 and :374-404

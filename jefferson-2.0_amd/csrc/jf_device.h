@@ -127,6 +127,13 @@ struct FusedParams {
     int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
     const int *order;  // [S] pair kernel: unit u works on sources order[G u .. G u + G - 1] (identity unless the engine sorted)
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
+    // fused_pair_kernel only: workgroups n_pair_wgs .. gridDim.x - 1 prepare the descriptors of the window that FOLLOWS this
+    // run in the uploaded trajectory (prep_kernel's work, 512 items per workgroup) while the last pairs finish
+    int n_pair_wgs = 0;                // workgroups that work on units (set by launch_fused)
+    const float *prep_pos = nullptr;   // [prep_K][S][5] the following window's positions (null: nothing to prepare)
+    ItemDesc *prep_desc = nullptr;     // [prep_K][S] where its descriptors go
+    int prep_K = 0, prep_canon = 0;
+    RingTable rt = {};
 };
 
 // Convolution reverb stage (jf_reverb.hip): uniformly partitioned overlap-save with a

@@ -69,8 +69,8 @@ struct jf_engine {
     SrcState *d_state[2] = {nullptr, nullptr};
     float *d_hist[2] = {nullptr, nullptr};
     ItemDesc *d_desc = nullptr;
-    // Descriptors of the window that follows the last jf_batch_run, written by that run's mix launch (mix_prep_kernel)
-    // into the second buffer; the next run takes them instead of launching prep_kernel if it asks for exactly that window
+    // Descriptors of the window that follows the last jf_batch_run, written by that run itself (trailing workgroups of the
+    // pair kernel's launch, or mix_prep_kernel) into the second buffer; the next run takes them instead of launching prep_kernel if it asks for exactly that window
     // of the same trajectory in the same mode and layout -- anything else that runs or touches the state in between
     // clears `ahead.valid`.
     ItemDesc *d_desc_ahead = nullptr;
@@ -81,7 +81,7 @@ struct jf_engine {
     } ahead;
     unsigned long traj_gen = 0;  // bumped by every jf_batch_upload_positions
     bool prep_ahead = true;      // jf_debug_set_prep_ahead
-    bool last_prep_skipped = false, last_mix_prep = false;  // what the last run launched (jf_debug_last_kernels)
+    bool last_prep_skipped = false, last_mix_prep = false, last_fused_prep = false;  // what the last run launched (jf_debug_last_kernels)
     float *d_partial = nullptr;
     float *d_mix = nullptr;
     float *d_pos_rt = nullptr;  // [S][5]
@@ -291,18 +291,30 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     P.mode = mode_now;
     P.err = e->hd_err;
     P.order = e->d_order;
+    // the window that follows in the trajectory, if there is a whole one: its descriptors are prepared by this run --
+    // inside the pair kernel's own launch (trailing workgroups, in the kernel's tail), else inside the mix launch
+    const bool ahead_ok = e->prep_ahead && e->profiling < 2 && first_block >= 0 && first_block + 2 * K <= e->traj_blocks;
+    const bool ahead_in_fused = ahead_ok && P.G > 1;
+    P.n_pair_wgs = 0;
+    P.prep_pos = ahead_in_fused ? d_pos + (size_t)K * e->S * 5 : nullptr;
+    P.prep_desc = e->d_desc_ahead;
+    P.prep_K = K;
+    P.prep_canon = canon;
+    P.rt = e->rt;
     int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
     if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, max_wgs, e->stream));
     if (ef) JF_HIP(e, hipEventRecord(ef->b, e->stream));
     if (em) JF_HIP(e, hipEventRecord(em->a, e->stream));
-    // the window that follows in the trajectory, if there is a whole one: its descriptors ride along with the mix
-    const bool ahead_ok = e->prep_ahead && e->profiling < 2 && first_block >= 0 && first_block + 2 * K <= e->traj_blocks;
-    e->last_mix_prep = ahead_ok;
+    e->last_mix_prep = ahead_ok && !ahead_in_fused;
+    e->last_fused_prep = ahead_in_fused;
     if (ahead_ok) {
-        JF_HIP(e, launch_mix_prep(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->rt, mode_now,
-                                  d_pos + (size_t)K * e->S * 5, e->d_desc_ahead, e->S, K, canon, e->stream));
+        if (ahead_in_fused)
+            JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
+        else
+            JF_HIP(e, launch_mix_prep(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->rt, mode_now,
+                                      d_pos + (size_t)K * e->S * 5, e->d_desc_ahead, e->S, K, canon, e->stream));
         e->ahead.valid = true;
         e->ahead.first = first_block + K;
         e->ahead.K = K;
@@ -1194,7 +1206,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         }
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
         else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb +
-                  (e->last_mix_prep ? ">;mix_prep_kernel" : ">;mix_kernel");
+                  (e->last_fused_prep ? ">+prep" : ">") + (e->last_mix_prep ? ";mix_prep_kernel" : ";mix_kernel");
         e->kernels = k;
         return e->kernels.c_str();
     } catch (...) {

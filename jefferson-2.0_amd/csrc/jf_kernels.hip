@@ -962,11 +962,23 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
                            // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
 #endif
 
+JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ pos, const SrcState *__restrict__ st,
+                      ItemDesc *__restrict__ desc, int S, int K, int canon, int tid, ItemDesc *stage);
+
 template <int NOUT>
 __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_pair[kPairsPerWg * kPairLds];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= P.n_pair_wgs) {
+        // The trailing workgroups of the grid: the descriptors of the window that follows this run (prep_kernel's work).
+        // They are dispatched as compute units come free, i.e. while the slowest pairs are still on their last unit: the
+        // 10 us chain of the index/weight rule hides in the kernel's tail instead of standing behind it as a launch.
+        static_assert(sizeof(s_pair) >= sizeof(ItemDesc) * 32 * kWavesPerWg, "staging of 32 records per wave");
+        prep_body(P.rt, P.mode, P.prep_pos, nullptr, P.prep_desc, P.S, P.prep_K, P.prep_canon,
+                  ((int)blockIdx.x - P.n_pair_wgs) * (64 * kWavesPerWg) + tid, reinterpret_cast<ItemDesc *>(s_pair));
+        return;
+    }
     for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
     if (tid < kPairsPerWg) {
         int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWave);
@@ -1033,7 +1045,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
     // pair -> unit map is rotated by one workgroup, so the expensive units (slots 0..2 of a group's blocks) always go to
     // pairs 0..2 of a workgroup, and to another workgroup every round; 1: every other round in reverse (the expensive
     // units then alternate between the first and the LAST pairs of a workgroup: 1.3 % slower); 0: plain.
-    const int n_pairs = gridDim.x * kPairsPerWg, my_pair = blockIdx.x * kPairsPerWg + pair;
+    const int n_pairs = P.n_pair_wgs * kPairsPerWg, my_pair = blockIdx.x * kPairsPerWg + pair;
 #pragma unroll 1
     for (int round = 0; round * n_pairs < n_units; round++) {
 #if JF_UNIT_ZIGZAG == 2
@@ -1970,19 +1982,25 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
     const int per_wg = P.G > 1 ? kPairsPerWg : kWavesPerWg;  // units a workgroup works on at a time
     int wgs = (n_items + per_wg - 1) / per_wg;
     if (wgs > max_wgs) wgs = max_wgs;
-    const dim3 grid(wgs), block(64 * kWavesPerWg);
+    const dim3 block(64 * kWavesPerWg);
     // groups of sources are summed as spectra by wave pairs (two inverse transforms per group); single sources
     // keep the per-source kernel, whose blocks are the reference's per-source `intermediate`
     if (P.G > 1) {
+        FusedParams Q = P;
+        Q.n_pair_wgs = wgs;
+        // + the workgroups that prepare the following window's descriptors (two lanes per item)
+        const int n_prep = Q.prep_pos != nullptr ? (2 * Q.S * Q.prep_K + 64 * kWavesPerWg - 1) / (64 * kWavesPerWg) : 0;
+        const dim3 grid(wgs + n_prep);
         switch (P.B / 64) {
-        case 1: hipLaunchKernelGGL(fused_pair_kernel<1>, grid, block, 0, st, P); break;
-        case 2: hipLaunchKernelGGL(fused_pair_kernel<2>, grid, block, 0, st, P); break;
-        case 3: hipLaunchKernelGGL(fused_pair_kernel<3>, grid, block, 0, st, P); break;
-        case 4: hipLaunchKernelGGL(fused_pair_kernel<4>, grid, block, 0, st, P); break;
+        case 1: hipLaunchKernelGGL(fused_pair_kernel<1>, grid, block, 0, st, Q); break;
+        case 2: hipLaunchKernelGGL(fused_pair_kernel<2>, grid, block, 0, st, Q); break;
+        case 3: hipLaunchKernelGGL(fused_pair_kernel<3>, grid, block, 0, st, Q); break;
+        case 4: hipLaunchKernelGGL(fused_pair_kernel<4>, grid, block, 0, st, Q); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
+    const dim3 grid(wgs);
     switch (P.B / 64) {
     case 1: hipLaunchKernelGGL(fused_block_kernel<1>, grid, block, 0, st, P); break;
     case 2: hipLaunchKernelGGL(fused_block_kernel<2>, grid, block, 0, st, P); break;

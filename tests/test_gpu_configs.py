@@ -438,7 +438,8 @@ def test_pair_kernel_odd_group_sizes(jf, hrir, castanets, B, G):
 
 
 def test_descriptors_prepared_ahead_change_nothing(jf, hrir, castanets):
-    """jf_batch_run writes the descriptors of the window that follows its own inside its mix launch (mix_prep_kernel) and
+    """jf_batch_run prepares the descriptors of the window that follows its own -- in trailing workgroups of the pair
+    kernel's own launch ("fused_pair_kernel<2>+prep"; the per-source kernel: inside the mix launch, mix_prep_kernel) -- and
     the next run uses them if it asks for exactly that window.  Two engines, one with that switched off, through
     sequential windows, a jump, another window size, a mode switch, a source reset and a new trajectory: every block
     bit-identical, and the kernel lists say when the shortcut was taken."""
@@ -466,9 +467,9 @@ def test_descriptors_prepared_ahead_change_nothing(jf, hrir, castanets):
         return a.last_kernels(), b.last_kernels()
 
     ka, kb = run(0, K)
-    assert ka[0] == "prep_kernel" and ka[-1] == "mix_prep_kernel" and kb == ["prep_kernel", "fused_pair_kernel<2>", "mix_kernel"]
+    assert ka == ["prep_kernel", "fused_pair_kernel<2>+prep", "mix_kernel"] and kb == ["prep_kernel", "fused_pair_kernel<2>", "mix_kernel"]
     ka, kb = run(K, K)            # the window prepared ahead
-    assert ka == ["fused_pair_kernel<2>", "mix_prep_kernel"] and kb[0] == "prep_kernel"
+    assert ka == ["fused_pair_kernel<2>+prep", "mix_kernel"] and kb[0] == "prep_kernel"
     ka, _ = run(2 * K, K)
     assert "prep_kernel" not in ka
     ka, _ = run(5 * K, K)         # a jump: the prepared window is not the one asked for
