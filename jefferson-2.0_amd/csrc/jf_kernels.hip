@@ -1428,34 +1428,26 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
     return dev_flatten_terms(h0, h1, h2, h3, omegaA, omegaB, omegaC, omegaD, omegaE, omegaF, rows, w);
 }
 
-// GPUSoundSource.cu:301-316: the case by index equality, flattened to <= 4 (row, weight) terms
+// GPUSoundSource.cu:301-316: the case by index equality, flattened to <= 4 (row, weight) terms.  Written with selects, not
+// branches: the compiler merges the branches' stores `w[i] = ..` into one store at a run-time index, which puts the
+// arrays into scratch memory (24 bytes that every kernel with this code inlined then carries).  The same values: the four
+// products are formed whether or not case 4 uses them.
 JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float omegaB, float omegaC, float omegaD,
                              float omegaE, float omegaF, int rows[4], float w[4]) {
-    if (h0 == h1 && h1 == h2 && h2 == h3) {
-        rows[0] = h0; w[0] = 1.0f;
-        rows[1] = rows[2] = rows[3] = h0;
-        w[1] = w[2] = w[3] = 0.0f;
-        return 1;
-    }
-    if (h0 == h2 && h1 == h3) {
-        rows[0] = h0; w[0] = omegaB;
-        rows[1] = h1; w[1] = omegaA;
-        rows[2] = rows[3] = h0;
-        w[2] = w[3] = 0.0f;
-        return 2;
-    }
-    if (h0 == h1 && h0 != h2) {
-        rows[0] = h0; w[0] = omegaF;
-        rows[1] = h2; w[1] = omegaE;
-        rows[2] = rows[3] = h0;
-        w[2] = w[3] = 0.0f;
-        return 2;
-    }
-    rows[0] = h0; w[0] = omegaF * omegaB;
-    rows[1] = h1; w[1] = omegaF * omegaA;
-    rows[2] = h2; w[2] = omegaE * omegaD;
-    rows[3] = h3; w[3] = omegaE * omegaC;
-    return 4;
+    const bool c1 = h0 == h1 && h1 == h2 && h2 == h3;    // one row
+    const bool c2 = !c1 && h0 == h2 && h1 == h3;          // elevation on a ring: two azimuths
+    const bool c3 = !c1 && !c2 && h0 == h1 && h0 != h2;   // azimuth on the grid: two rings
+    const bool c4 = !c1 && !c2 && !c3;
+    const float fb = omegaF * omegaB, fa = omegaF * omegaA, ed = omegaE * omegaD, ec = omegaE * omegaC;
+    rows[0] = h0;
+    w[0] = c1 ? 1.0f : c2 ? omegaB : c3 ? omegaF : fb;
+    rows[1] = c1 ? h0 : c3 ? h2 : h1;
+    w[1] = c1 ? 0.0f : c2 ? omegaA : c3 ? omegaE : fa;
+    rows[2] = c4 ? h2 : h0;
+    w[2] = c4 ? ed : 0.0f;
+    rows[3] = c4 ? h3 : h0;
+    w[3] = c4 ? ec : 0.0f;
+    return c1 ? 1 : c4 ? 4 : 2;
 }
 
 // Descriptor of one work item from its latched position record and the position of the block
@@ -1642,18 +1634,20 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool live_i = i < n_small && share;
-            int at = -1;
+            // the first row of the big set, from `from` on, that is the small set's row i takes its weight (written without
+            // an index variable: the compiler turns `ex_w[k] = k == at ? .. : ex_w[k]` back into a store at a run-time index)
+            bool found = false;
+            int next_from = from;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (at < 0 && k >= from && k < n_big && big_rows[k] == small_rows[i]) at = k;
+            for (int k = 0; k < 4; k++) {
+                const bool hit = !found && k >= from && k < n_big && big_rows[k] == small_rows[i];
+                ex_w[k] = (live_i && hit) ? small_w[i] : ex_w[k];
+                next_from = hit ? k + 1 : next_from;
+                found = found || hit;
+            }
             if (live_i) {
-                if (at < 0) {
-                    share = false;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) ex_w[k] = k == at ? small_w[i] : ex_w[k];
-                    from = at + 1;
-                }
+                if (!found) share = false;
+                else from = next_from;
             }
         }
         if (share) {
