@@ -1204,9 +1204,13 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             else if (e->last_rv_form == 4) k += "reverb_mac_kernel<" + bs + ",1,true>;";
             else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
         }
+        // launch_mix: few partial blocks per audio block (16, 32 or 64 groups) take the one-thread-per-float form
+        const int n_part = e->last_group > 0 ? e->S / e->last_group : e->S;
+        const std::string mix_name = (n_part == 16 || n_part == 32 || n_part == 64)
+                                         ? ";mix_few_kernel<" + std::to_string(n_part / 16) + ">" : std::string(";mix_kernel");
         if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
         else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb +
-                  (e->last_fused_prep ? ">+prep" : ">") + (e->last_mix_prep ? ";mix_prep_kernel" : ";mix_kernel");
+                  (e->last_fused_prep ? ">+prep" : ">") + (e->last_mix_prep ? ";mix_prep_kernel" : mix_name);
         e->kernels = k;
         return e->kernels.c_str();
     } catch (...) {

@@ -1305,6 +1305,32 @@ __global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__res
     mix_body(partial, mix, S, blk, blockIdx.x, red);
 }
 
+// The same sum in the same association for the pair kernel's few partial blocks per audio block (16, 32 or 64 groups of
+// sources): one thread per output float, all of its 16 PER loads in flight at once -- mix_kernel's 16 waves per 64 floats
+// and its LDS round are a 4 us latency chain for what is 8 MB of reads (1.6 us this way).
+template <int PER>
+__global__ __launch_bounds__(256) void mix_few_kernel(const float *__restrict__ partial, float *__restrict__ mix, int blk,
+                                                      int total /* K * blk */) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / blk, n = t - b * blk;
+    const float *p = partial + (size_t)b * (kMixGroups * PER) * blk + n;
+    float v[kMixGroups][PER];
+#pragma unroll
+    for (int g = 0; g < kMixGroups; g++)
+#pragma unroll
+        for (int j = 0; j < PER; j++) v[g][j] = p[(size_t)(g * PER + j) * blk];
+    float tot = 0.0f;
+#pragma unroll
+    for (int g = 0; g < kMixGroups; g++) {
+        float acc = 0.0f;  // as mix_body: every group's sum starts from 0
+#pragma unroll
+        for (int j = 0; j < PER; j++) acc += v[g][j];
+        tot = g == 0 ? acc : tot + acc;
+    }
+    mix[t] = tot;
+}
+
 // ----------------------------------------------- indices and weights (a2,a3)
 // SoundSource.cu:65-105 and hrtf_signals.cu:20-51, float32 exactly as written
 // (no contraction), the nearest-azimuth search done locally instead of over the
@@ -2033,6 +2059,14 @@ hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, i
 
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st) {
     const int blk = 2 * B;  // multiple of 64 because B is
+    if (S == kMixGroups || S == 2 * kMixGroups || S == 4 * kMixGroups) {  // the pair kernel's large calls
+        const int total = K * blk;
+        const dim3 grid((total + 255) / 256), block(256);
+        if (S == kMixGroups) hipLaunchKernelGGL(mix_few_kernel<1>, grid, block, 0, st, d_partial, d_mix, blk, total);
+        else if (S == 2 * kMixGroups) hipLaunchKernelGGL(mix_few_kernel<2>, grid, block, 0, st, d_partial, d_mix, blk, total);
+        else hipLaunchKernelGGL(mix_few_kernel<4>, grid, block, 0, st, d_partial, d_mix, blk, total);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(mix_kernel, dim3(K * (blk / 64)), dim3(64 * kMixGroups), 0, st, d_partial, d_mix, S, K,
                        blk);
     return hipGetLastError();
