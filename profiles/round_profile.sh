@@ -13,6 +13,9 @@ timeout -k 10 300 python3 bench.py --reverb --realtime --steps 2000 --warmup 500
 # the same kernel with a delay line larger than the 256 MiB Infinity Cache: the HBM-bound measurement
 timeout -k 10 300 python3 bench.py --reverb --realtime --rv-sources 512 --steps 2000 --warmup 500 > $OUT/bench_reverb_realtime_512src_hbm.json 2>> $OUT/bench.err; echo "bench reverb realtime 512 sources rc=$?"
 timeout -k 10 300 python3 bench.py --reverb --realtime --rv-ir-seconds 4.0 --steps 2000 --warmup 500 > $OUT/bench_reverb_realtime_4s_hbm.json 2>> $OUT/bench.err; echo "bench reverb realtime 4 s IR rc=$?"
+# a long run (5.1e6 blocks x 1024 sources, verified at its end) and the N > 1 code path rehearsed with two gloo ranks on this one GPU
+timeout -k 10 300 python3 bench.py --steps 20000 --warmup 256 --no-pmc > $OUT/bench_soak_20000_steps.json 2>> $OUT/bench.err; echo "bench soak rc=$?"
+JF_DIST_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 64 --warmup 16 > $OUT/bench_2rank_gloo_rehearsal.json 2>> $OUT/bench.err; echo "bench 2-rank gloo rehearsal rc=$?"
 # the C host's number (jefferson_group.h, one GPU) and configs[0]/[1] through the plain-C offline driver
 timeout -k 10 120 ./jefferson-2.0_amd/jf_ctest bench 1 512 > $OUT/ctest_bench.txt 2>> $OUT/bench.err; echo "jf_ctest bench rc=$?"
 timeout -k 10 300 python3 profiles/render_config1.py > $OUT/render_config1.txt 2>> $OUT/bench.err; echo "render config1 rc=$?"
