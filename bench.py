@@ -435,9 +435,16 @@ def main():
         flops_ex, flops_ref = wl.flops_cyclic(jf, pos, KB, B, G, first_step, K, old_sets_spectral=pair)
         tf = flops_ex / fused_s / 1e12 if fused_s > 0 else 0.0
         fused_name = next((k for k in kernels if k.startswith("fused_")), kernels[-1])
+        # "fused_pair_kernel<4>+prep": the launch's trailing workgroups prepare the next window's descriptors (same kernel
+        # symbol in rocprofv3: fused_pair_kernel<4>); its duration and its counters include them
+        fused_has_prep = fused_name.endswith("+prep")
+        fused_name = fused_name.split("+")[0]
         roof = {"bound": "valu-fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / FP32_VECTOR_PEAK_TF, "traffic": None, "kernel": fused_name,
                 "avg_launch_ms": prof["fused_ms"] / launches,
+                "launch_includes": ("the next window's descriptors (index/weight rule for 131 072 items in trailing "
+                                    "workgroups, ~2.5 us of the launch, ~20 of the VALU instructions per source-block)"
+                                    if fused_has_prep else None),
                 "flops_per_launch_executed": flops_ex / launches,
                 "flops_per_launch_reference_algorithm": flops_ref / launches,
                 # the same output priced with the reference's own algorithm (an unpruned inverse pair per filter set and

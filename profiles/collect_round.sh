@@ -9,8 +9,8 @@ for f in bench bench_stationary bench_reverb bench_reverb_realtime bench_reverb_
 done
 sed -i "/^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl/d" $S/ctest_bench.txt 2>/dev/null
 cp $S/latency.txt $S/latency_reverb.txt $S/ctest_bench.txt $S/render_config1.txt $S/pmc_summary.txt $D/ 2>/dev/null
-cat $S/trace/*/*kernel_stats.csv > $D/kernel_stats.csv 2>/dev/null
-cat $S/trace_reverb/*/*kernel_stats.csv > $D/kernel_stats_reverb.csv 2>/dev/null
-cat $S/trace_reverb_rt/*/*kernel_stats.csv > $D/kernel_stats_reverb_realtime.csv 2>/dev/null
-cat $S/trace_reverb_rt512/*/*kernel_stats.csv > $D/kernel_stats_reverb_realtime_512src_hbm.csv 2>/dev/null
+cp "$(ls -t $S/trace/*/*kernel_stats.csv | head -n 1)" $D/kernel_stats.csv 2>/dev/null   # the newest run's
+cp "$(ls -t $S/trace_reverb/*/*kernel_stats.csv | head -n 1)" $D/kernel_stats_reverb.csv 2>/dev/null   # the newest run's
+cp "$(ls -t $S/trace_reverb_rt/*/*kernel_stats.csv | head -n 1)" $D/kernel_stats_reverb_realtime.csv 2>/dev/null   # the newest run's
+cp "$(ls -t $S/trace_reverb_rt512/*/*kernel_stats.csv | head -n 1)" $D/kernel_stats_reverb_realtime_512src_hbm.csv 2>/dev/null   # the newest run's
 ls -la $D
