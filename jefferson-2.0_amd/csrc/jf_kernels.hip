@@ -1306,8 +1306,10 @@ __global__ __launch_bounds__(64 * kMixGroups) void mix_kernel(const float *__res
 }
 
 // The same sum in the same association for the pair kernel's few partial blocks per audio block (16, 32 or 64 groups of
-// sources): one thread per output float, all of its 16 PER loads in flight at once -- mix_kernel's 16 waves per 64 floats
-// and its LDS round are a 4 us latency chain for what is 8 MB of reads (1.6 us this way).
+// sources): one thread per output float, all of its 16 PER loads in flight at once, no LDS round.  Both forms are a few
+// memory latencies long (4.7 us against mix_kernel's 4.2 under rocprofv3, where every launch is drained); back to back
+// behind the fused kernel this one makes a step 0.5 us shorter (7.1 against 7.6 us outside the fused launch, four runs
+// each).
 template <int PER>
 __global__ __launch_bounds__(256) void mix_few_kernel(const float *__restrict__ partial, float *__restrict__ mix, int blk,
                                                       int total /* K * blk */) {
