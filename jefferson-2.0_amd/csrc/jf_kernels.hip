@@ -23,8 +23,10 @@
 // filter sets of G consecutive sources summed as spectra and inverted once; rt_block_kernel: one launch per audio
 // block for the per-block calls.
 //
-// mix_kernel sums the per-source (per-group) blocks in source order (a12), prep_kernel computes indices/weights
-// (a2, a3) for every item; mix_prep_kernel is both in one launch (this run's mix, the next window's descriptors).
+// mix_kernel / mix_few_kernel sum the per-source (per-group) blocks in source order (a12), prep_kernel computes
+// indices/weights (a2, a3) for every item.  A run prepares the NEXT window's descriptors itself: the pair kernel in
+// trailing workgroups of its own launch (they run in the kernel's tail), the per-source kernel inside its mix launch
+// (mix_prep_kernel).
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
