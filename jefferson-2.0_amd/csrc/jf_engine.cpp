@@ -32,8 +32,8 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
 hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, int K, int B, const RingTable &rt, int mode,
                            const float *d_pos_next, ItemDesc *d_desc_next, int S, int K_next, int canon, hipStream_t st);
-hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
-                           hipStream_t st);
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
+                           int n_wgs, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used);
@@ -117,6 +117,10 @@ struct jf_engine {
     float *h_out_pinned = nullptr;  // [kRtMaxWgs][2B] pinned + mapped: ... and writes its workgroups' stereo blocks in place
     int rt_wgs = 0;                 // partial blocks the block in flight left there (0: one finished block)
     float *hd_pos = nullptr, *hd_out = nullptr;  // their device addresses
+    // The real-time kernel's workgroups each store a sequence number into their word of h_done (pinned + mapped) when their
+    // block lies in h_out_pinned; jf_collect_block polls the words instead of synchronising the stream.
+    int *h_done = nullptr, *hd_done = nullptr;
+    int rt_seq = 0;
     int *h_err = nullptr, *hd_err = nullptr;     // pinned + mapped error word of the fused kernels
     int rt_max_sources = 8192;      // per-block calls with at most this many sources take the one-launch path
                                     // (profiles/latency_rt_sweep.py: 32 against 54 us at 1024 sources, 75 against 105 at 8192)
@@ -406,6 +410,7 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_pick);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
+    if (e->h_done) (void)hipHostFree(e->h_done);
     if (e->h_err) (void)hipHostFree(e->h_err);
     for (auto *pool : {&e->ev_prep, &e->ev_fused, &e->ev_mix, &e->ev_reverb})
         for (auto &p : *pool) {
@@ -481,6 +486,9 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
+        JF_HIP(e, hipHostMalloc(&e->h_done, sizeof(int) * kRtMaxWgs, hipHostMallocMapped));
+        memset(e->h_done, 0, sizeof(int) * kRtMaxWgs);
+        JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_done, e->h_done, 0));
         // the error word, followed by 64 KB that timing experiments of the kernels may fill (JF_EXP_STAMPS)
         JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int) * 4 + 65536, hipHostMallocMapped));
         memset(e->h_err, 0, sizeof(int) * 4 + 65536);
@@ -756,7 +764,8 @@ int jf_submit_block(jf_engine *e) {
             // one 16-wave workgroup per 16 sources (at most kRtMaxWgs = 2048 sources: beyond that a wave takes several)
             int wgs = (e->S + 15) / 16;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
-            JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, wgs, e->stream));
+            e->rt_seq = e->rt_seq == 0x7fffffff ? 1 : e->rt_seq + 1;
+            JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, e->hd_done, e->rt_seq, wgs, e->stream));
             e->cur = p ^ 1;
             e->last_rt = true;
             e->rt_wgs = wgs;
@@ -780,7 +789,20 @@ int jf_collect_block(jf_engine *e, float *out) {
     DeviceGuard bind(e);
     if (!e || !out) return JF_ERR_ARG;
     if (!e->in_flight) return fail(e, JF_ERR_STATE, "no block in flight");
-    JF_HIP(e, hipStreamSynchronize(e->stream));
+    bool landed = false;
+    if (e->rt_wgs > 0) {
+        // The real-time kernel says when its blocks are in host memory: poll its words (a few microseconds of spinning on the
+        // audio thread, as cudaStreamSynchronize does in the reference, Audio.cu:107) -- and fall back to the stream if they
+        // do not come (a faulting kernel must surface as an error, not as a spin).
+        const volatile int *done = e->h_done;
+        for (long spins = 0; spins < 4000000 && !landed; spins++) {
+            landed = true;
+            for (int g = 0; g < e->rt_wgs; g++) landed = landed && done[g] == e->rt_seq;
+            if (!landed) __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!landed) JF_HIP(e, hipStreamSynchronize(e->stream));
     if (device_fault(e)) {  // per-block calls with more than rt_max_sources sources run the pair kernel too
         e->in_flight = false;
         return fail(e, JF_ERR_DEVICE, kHandOffMsg);

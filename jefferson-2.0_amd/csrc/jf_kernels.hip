@@ -1768,9 +1768,12 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
 // the caller adds the n partial blocks (n = 1 for up to 16 sources).
 constexpr int kRtWaves = 16;
 template <int NOUT>
+// done (may be null): host-mapped words, one per workgroup; workgroup g stores `seq` into done[g] once its block lies in
+// `out` -- the host then polls these words instead of synchronising the stream (the runtime's completion path costs more
+// than the kernel's arithmetic at one source).
 __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedParams P, const RingTable rt,
                                                                  const float *__restrict__ pos,
-                                                                 float2 *__restrict__ out) {
+                                                                 float2 *__restrict__ out, int *__restrict__ done, int seq) {
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[kRtWaves * kWaveLds];
     __shared__ ItemDesc s_desc[kRtWaves];
@@ -1806,6 +1809,10 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
 #pragma unroll
         for (int w = 1; w < kRtWaves; w++) t = cadd(t, s_buf[w * kWaveLds + n]);
         out[(size_t)blockIdx.x * B + n] = t;
+    }
+    if (done != nullptr) {
+        __syncthreads();  // every wave's stores of the block have been issued and waited for (vmcnt(0) ahead of the barrier)
+        if (tid == 0) __hip_atomic_store(done + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2035,16 +2042,16 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int n_wgs,
-                           hipStream_t st) {
+hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
+                           int n_wgs, hipStream_t st) {
     if (P.K != 1 || n_wgs < 1) return hipErrorInvalidValue;
     const dim3 grid(n_wgs), block(64 * kRtWaves);
     float2 *o = reinterpret_cast<float2 *>(out);
     switch (P.B / 64) {
-    case 1: hipLaunchKernelGGL(rt_block_kernel<1>, grid, block, 0, st, P, rt, pos, o); break;
-    case 2: hipLaunchKernelGGL(rt_block_kernel<2>, grid, block, 0, st, P, rt, pos, o); break;
-    case 3: hipLaunchKernelGGL(rt_block_kernel<3>, grid, block, 0, st, P, rt, pos, o); break;
-    case 4: hipLaunchKernelGGL(rt_block_kernel<4>, grid, block, 0, st, P, rt, pos, o); break;
+    case 1: hipLaunchKernelGGL(rt_block_kernel<1>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
+    case 2: hipLaunchKernelGGL(rt_block_kernel<2>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
+    case 3: hipLaunchKernelGGL(rt_block_kernel<3>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
+    case 4: hipLaunchKernelGGL(rt_block_kernel<4>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
