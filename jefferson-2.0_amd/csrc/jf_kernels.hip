@@ -853,13 +853,17 @@ JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
 }
 
 // Bins qb .. qb + 3 (lofs = 64 qb + lane) of one filter set, or of two sets that read the same rows with different
-// weights (BOTH).  use(q, zk_a, zm_a, zk_b, zm_b), q = 0..3.  Row addresses stay scalar (table + row, wave-uniform)
+// weights (BOTH): sLa[q] += X D * H_left, sRa[q] += X D * H_right with set a's weights (and sLb, sRb with set b's).
+// The sums are kept PER EAR, not as Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R: a product that is added to a
+// sum is two packed FMAs, whereas forming Z[k] and Z[N-k] of every source and adding those took a multiply, an FMA and
+// two packed adds per ear (8 packed instructions per bin and source fewer with two sets: a quarter of the filter's);
+// the caller forms Z[k] and Z[N-k] once per unit (ear_sums_to_z).  Row addresses stay scalar (table + row, wave-uniform)
 // with ONE per-lane offset register for all rows: loads in the saddr form, no 64-bit pointer pair per row.
 // fetch(xh) delivers the source's X D for these bins; it is called AFTER the first two stages of row loads have been
 // requested, so whatever it waits for (the partner's hand-off flag, the mailbox read) overlaps with their latency.
-template <int NT, bool BOTH, class X, class F>
+template <int NT, bool BOTH, class X>
 JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa, const float *wb,
-                          X &&fetch, bool special, F &&use) {
+                          X &&fetch, bool special, c2 (&sLa)[4], c2 (&sRa)[4], c2 (&sLb)[4], c2 (&sRb)[4]) {
     const float4 *hp[NT];
     c2 a[NT], b[NT];  // (w, w): a weight as a scalar-register pair feeds both halves of a packed operation
     unsigned boff = 16u * lofs;  // byte offset of this lane's first bin inside a row
@@ -875,18 +879,19 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
         a[t] = c2{fa, fa};
         b[t] = c2{fb, fb};
     }
-    // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  Y_ear = x * he_ear as two packed
-    // instructions each; Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R one packed add each.
-    auto ztwo = [&](int q, float2 x, c2 heL, c2 heR, c2 &zk, c2 &zm) {
+    // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  s_ear += x * he_ear, two packed FMAs each.
+    auto mac2 = [&](int q, float2 x, c2 heL, c2 heR, c2 &sL, c2 &sR) {
         const c2 xc = c2_of(x);
-        const c2 yl = pcmul(xc, heL), yr = pcmul(xc, heR);
-        zk = padd_i(yl, yr);
-        zm = pcadd_ic(yl, yr);
-        if (q == 0) {  // lane 0 of the lower half: bins 0 and 512 (real spectra; c2r drops their imaginary parts)
-            const c2 z0 = c2{x.x * heL.x, x.x * heR.x};
-            const c2 z512 = c2{x.y * heL.y, x.y * heR.y};
-            zk = special ? z0 : zk;
-            zm = special ? z512 : zm;
+        const c2 nl = pcmac(xc, heL, sL), nr = pcmac(xc, heR, sR);
+        if (q == 0) {
+            // lane 0 of the lower half: bins 0 and 512 travel as the two halves of one entry (real spectra; c2r drops
+            // their imaginary parts): the product is element by element
+            const c2 el = xc * heL + sL, er = xc * heR + sR;
+            sL = special ? el : nl;
+            sR = special ? er : nr;
+        } else {
+            sL = nl;
+            sR = nr;
         }
     };
     // The four bins in stages of JF_STAGE_LOADS row loads (16 B per lane each), two stages in flight: while one
@@ -932,25 +937,38 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
                     hbR = pfma_s(c2{hq[t].z, hq[t].w}, b[t], hbR);
                 }
             }
-            c2 zka, zma, zkb = c2{0.f, 0.f}, zmb = c2{0.f, 0.f};
             const int qq = QC * st + q;
-            ztwo(qq, xh[qq], haL, haR, zka, zma);
-            if (BOTH) ztwo(qq, xh[qq], hbL, hbR, zkb, zmb);
-            use(qq, zka, zma, zkb, zmb);
+            mac2(qq, xh[qq], haL, haR, sLa[qq], sRa[qq]);
+            if (BOTH) mac2(qq, xh[qq], hbL, hbR, sLb[qq], sRb[qq]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <bool BOTH, class X, class F>
+template <bool BOTH, class X>
 JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa,
-                             const float *wb, X &&fetch, bool special, F &&use) {
+                             const float *wb, X &&fetch, bool special, c2 (&sLa)[4], c2 (&sRa)[4], c2 (&sLb)[4],
+                             c2 (&sRb)[4]) {
     if (nt == 4)
-        filtered_half<4, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
+        filtered_half<4, BOTH>(htab, lofs, rows, wa, wb, fetch, special, sLa, sRa, sLb, sRb);
     else if (nt == 2)
-        filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
+        filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, fetch, special, sLa, sRa, sLb, sRb);
     else
-        filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, fetch, special, use);
+        filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, fetch, special, sLa, sRa, sLb, sRb);
+}
+
+// The per-ear sums of a unit -> Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R, the inverse transform's input
+// (one c2r transform yields both ears: Y_L in the real parts, Y_R in the imaginary parts of the frames).
+JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2 (&zk)[4], c2 (&zm)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        zk[q] = padd_i(sL[q], sR[q]);
+        zm[q] = pcadd_ic(sL[q], sR[q]);
+    }
+    // lane 0 of the lower half holds bins 0 and 512 in the halves of its first entry
+    const c2 z0 = c2{sL[0].x, sR[0].x}, z512 = c2{sL[0].y, sR[0].y};
+    zk[0] = special ? z0 : zk[0];
+    zm[0] = special ? z512 : zm[0];
 }
 
 #ifndef JF_PAIR_MIX_AGES
@@ -1079,29 +1097,21 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         }
         mail_free(npub);  // the last unit's final hand-offs used both slots
         JF_EXP_PHASE(6);  // unit start: descriptor scan, waiting for the partner's last reads
-        // sums over the unit's sources of Z[k] and Z[N-k], k = lane + 64 (qb + q), old and new sets
-        c2 zko[4], zkn[4], zmo[4], zmn[4];
+        // sums over the unit's sources of X D H_left and X D H_right, bins k = lane + 64 (qb + q), old and new sets
+        c2 sLo[4], sRo[4], sLn[4], sRn[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) zko[q] = zkn[q] = zmo[q] = zmn[q] = c2{0.f, 0.f};
+        for (int q = 0; q < 4; q++) sLo[q] = sRo[q] = sLn[q] = sRn[q] = c2{0.f, 0.f};
         // fetch(xh): see filtered_half.  A source with two filters (its sets do not share rows) fetches once.
         auto accumulate = [&](const ItemDesc *dp, auto &&fetch) {
-            JF_EXP_FILTER_SHORTCUT(fetch, zkn);
+            JF_EXP_FILTER_SHORTCUT(fetch, sLn);
             const int nn = dp->n_new;
-            auto add_new = [&](int q, c2 zk, c2 zmv, c2, c2) {
-                zkn[q] += zk;
-                zmn[q] += zmv;
-            };
             if (!any_xfade) {
-                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, fetch, special, add_new);
+                filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, fetch, special, sLn, sRn, sLn,
+                                        sRn);
             } else if (dp->flags & 1) {
                 // both sets read the same rows (prep_kernel laid them out so): one round of loads
-                filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, fetch, special,
-                                       [&](int q, c2 zka, c2 zma, c2 zkb, c2 zmb) {
-                                           zko[q] += zka;
-                                           zmo[q] += zma;
-                                           zkn[q] += zkb;
-                                           zmn[q] += zmb;
-                                       });
+                filtered_half_nt<true>(nn, P.htab, lofs, dp->rows_new, dp->w_old, dp->w_new, fetch, special, sLo, sRo, sLn,
+                                       sRn);
             } else {
                 float2 keep[4];
                 filtered_half_nt<false>(dp->n_old, P.htab, lofs, dp->rows_old, dp->w_old, dp->w_old,
@@ -1110,16 +1120,13 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
 #pragma unroll
                                             for (int q = 0; q < 4; q++) keep[q] = xh[q];
                                         },
-                                        special, [&](int q, c2 zk, c2 zmv, c2, c2) {
-                                            zko[q] += zk;
-                                            zmo[q] += zmv;
-                                        });
+                                        special, sLo, sRo, sLo, sRo);
                 filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new,
                                         [&](float2 (&xh)[4]) {
 #pragma unroll
                                             for (int q = 0; q < 4; q++) xh[q] = keep[q];
                                         },
-                                        special, add_new);
+                                        special, sLn, sRn, sLn, sRn);
             }
         };
         auto take_partner_source = [&](int jp) {  // his j-th source: my bins of its X D are in his mailbox
@@ -1200,6 +1207,9 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         }
 
         // ---- the two inverse transforms: wave 0 takes the old sum, wave 1 the new one
+        c2 zko[4], zkn[4], zmo[4], zmn[4];
+        ear_sums_to_z(sLo, sRo, special, zko, zmo);
+        ear_sums_to_z(sLn, sRn, special, zkn, zmn);
         const bool give = half == 0 || any_xfade;  // my bins of the sum the partner inverts
         const bool take = half == 1 || any_xfade;  // I invert a sum
         if (give) {
