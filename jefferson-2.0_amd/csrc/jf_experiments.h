@@ -58,6 +58,11 @@
 // ---- filtered_half: one table-row load
 #ifdef JF_EXP_NOROWLOAD
 #define JF_EXP_ROW_LOAD(ptr, st, q, boff, t) make_float4((float)((st) + (q)), 1.0f, (float)(boff), (float)(t))
+#elif defined(JF_EXP_HALFROWLOAD)
+// every other row of a filter is not loaded: the row traffic a kernel would have that loads a source's rows once for
+// two consecutive blocks (an upper bound for what sharing them can gain; results are wrong)
+#define JF_EXP_ROW_LOAD(ptr, st, q, boff, t) \
+    (((t) & 1) ? make_float4((float)((st) + (q)), 1.0f, (float)(boff), (float)(t)) : *(ptr))
 #else
 #define JF_EXP_ROW_LOAD(ptr, st, q, boff, t) (*(ptr))
 #endif
