@@ -1821,8 +1821,17 @@ __global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedPara
         out[(size_t)blockIdx.x * B + n] = t;
     }
     if (done != nullptr) {
-        __syncthreads();  // every wave's stores of the block have been issued and waited for (vmcnt(0) ahead of the barrier)
-        if (tid == 0) __hip_atomic_store(done + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // Every storing wave waits for its own stores of the block (a barrier alone does not: the compiler puts no
+        // s_waitcnt vmcnt(0) in front of s_barrier, and the word below could overtake another wave's stores), then the
+        // barrier, then ONE lane releases at system scope and stores the word.  The second wait is spelled out because the
+        // compiler may drop the one behind the write-back when it thinks nothing is outstanding.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(done + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
