@@ -147,3 +147,40 @@ def test_setters_from_another_thread(jf, hrir, castanets):
     assert np.array_equal(ref.process_block(), y)
     e.close()
     ref.close()
+
+
+def test_completion_words_under_load_every_block_checked(jf, hrir, castanets):
+    """Per-block calls learn that a block has landed from words the kernel stores into host memory behind the
+    block (no stream synchronisation).  A word that overtook a workgroup's stores would hand out the previous
+    block's frames: 1500 consecutive blocks of 300 sources (several workgroups, four storing waves each), with a
+    second engine's batch launches keeping the GPU busy meanwhile, every block compared with an engine that takes
+    the three-launch pipeline (a stream synchronisation per block)."""
+    S, B, K = 300, 128, 1500
+    rt = _setup(jf, hrir, castanets, S, B, 8192)
+    ref = _setup(jf, hrir, castanets, S, B, 0)
+    for e in (rt, ref):
+        for s in range(S):
+            e.set_spherical(s, -35 + (6 * s) % 120, (11 * s) % 360, 0.4 + 0.2 * (s % 5))
+    Sb, Kb = 512, 64
+    bg = jf.Engine(256, 512, Sb, hrir=hrir, max_batch_blocks=Kb)
+    for s in range(Sb):
+        bg.set_signal(s, 0.3 * np.roll(castanets, 311 * s)[:20000])
+    ele = np.broadcast_to(10.0 * (np.arange(Sb) % 9), (Kb, Sb)).astype(np.float32)
+    azi = ((7.0 * np.arange(Sb)[None, :] + np.arange(Kb)[:, None]) % 360).astype(np.float32)
+    bg.upload_positions(jf.positions_from_spherical(ele, azi, np.ones((Kb, Sb), np.float32)))
+    worst, loud = 0.0, 0.0
+    for b in range(K):
+        if b % 4 == 0:
+            bg.batch_run(0, Kb)  # asynchronous: queued on the other engine's stream
+        got = rt.process_block()
+        want = ref.process_block()
+        worst = max(worst, float(np.abs(got - want).max()))
+        loud = max(loud, float(np.abs(want).max()))
+    bg.synchronize()
+    assert any("rt_block_kernel" in k for k in rt.last_kernels())
+    assert not any("rt_block_kernel" in k for k in ref.last_kernels())
+    bg.close()
+    rt.close()
+    ref.close()
+    assert loud > 0.05
+    assert worst <= TOL32 * 16 * max(1.0, loud)
