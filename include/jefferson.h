@@ -150,7 +150,11 @@ int jf_process_block(jf_engine *e, float *out);
 /*
  * The CUDA path's pipelining (Audio.cu:104-117): jf_submit_block enqueues
  * block k (chunkProcess, GPUSoundSource.cu:463-471) and returns at once;
- * jf_collect_block waits (cudaStreamSynchronize, Audio.cu:107) and returns it.
+ * jf_collect_block waits for it (where the reference calls cudaStreamSynchronize,
+ * Audio.cu:107) and returns it.  With the one-launch kernel the wait is a poll
+ * of completion words the kernel stores into host memory behind the block; the
+ * calling thread spins for the ~10 us the block takes, as it would inside the
+ * runtime's synchronisation.
  */
 int jf_submit_block(jf_engine *e);
 int jf_collect_block(jf_engine *e, float *out);
