@@ -974,6 +974,9 @@ JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2
 #ifndef JF_PAIR_MIX_AGES
 #define JF_PAIR_MIX_AGES 1  // which two waves of a workgroup form a pair: 1 = w and 15 - w, 2 = same SIMD, 0 = 2i and 2i + 1
 #endif
+#ifndef JF_PAIR_RELOAD_PARAMS
+#define JF_PAIR_RELOAD_PARAMS 1
+#endif
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
@@ -986,20 +989,41 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
                       ItemDesc *__restrict__ desc, int S, int K, int canon, int tid, ItemDesc *stage);
 
 template <int NOUT>
-__global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
+__global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_pair[kPairsPerWg * kPairLds];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= P.n_pair_wgs) {
+#if JF_PAIR_RELOAD_PARAMS
+    // The launch parameters are read again from the kernel-argument segment (scalar loads, scalar cache) wherever the
+    // source loop needs them, instead of being held in scalar registers from kernel entry: with ~30 parameter registers
+    // live across the whole persistent loop the compiler ran out of scalar registers and kept 49 of them in the lanes of
+    // a vector register -- every use a v_readlane, i.e. a VECTOR instruction (~40 per source-block).
+    FusedParams P;
+    const FusedParams JF_CONST_AS *const kernarg =
+        (const FusedParams JF_CONST_AS *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto reload_params = [&]() {
+        const FusedParams JF_CONST_AS *q = kernarg;
+        asm volatile("" : "+s"(q));
+        P.htab = q->htab, P.desc = q->desc, P.sigs = q->sigs, P.st_in = q->st_in, P.st_out = q->st_out;
+        P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
+        P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
+        P.n_pair_wgs = q->n_pair_wgs;
+    };
+#else
+    const FusedParams &P = Pin;
+    auto reload_params = []() {};
+#endif
+    if ((int)blockIdx.x >= Pin.n_pair_wgs) {
         // The trailing workgroups of the grid: the descriptors of the window that follows this run (prep_kernel's work).
         // They are dispatched as compute units come free, i.e. while the slowest pairs are still on their last unit: the
         // 10 us chain of the index/weight rule hides in the kernel's tail instead of standing behind it as a launch.
         static_assert(sizeof(s_pair) >= sizeof(ItemDesc) * 32 * kWavesPerWg, "staging of 32 records per wave");
-        prep_body(P.rt, P.mode, P.prep_pos, nullptr, P.prep_desc, P.S, P.prep_K, P.prep_canon,
-                  ((int)blockIdx.x - P.n_pair_wgs) * (64 * kWavesPerWg) + tid, reinterpret_cast<ItemDesc *>(s_pair));
+        prep_body(Pin.rt, Pin.mode, Pin.prep_pos, nullptr, Pin.prep_desc, Pin.S, Pin.prep_K, Pin.prep_canon,
+                  ((int)blockIdx.x - Pin.n_pair_wgs) * (64 * kWavesPerWg) + tid, reinterpret_cast<ItemDesc *>(s_pair));
         return;
     }
-    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = P.tw[j];
+    for (int j = tid; j < kTwPack; j += 64 * kWavesPerWg) s_tw[j] = Pin.tw[j];
+    reload_params();
     if (tid < kPairsPerWg) {
         int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWave);
         f[0] = f[1] = f[2] = f[3] = 0;
@@ -1077,6 +1101,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         const int unit = round * n_pairs + my_pair;
 #endif
         if (unit >= n_units) continue;
+        reload_params();
 #if JF_UNIT_ORDER
         const int sg = unit / P.K;
         const int b = unit - sg * P.K;
@@ -1130,6 +1155,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             }
         };
         auto take_partner_source = [&](int jp) {  // his j-th source: my bins of its X D are in his mailbox
+            reload_params();
             const ItemDesc dl = load_desc(db + ord[2 * jp + (half ^ 1)]);
             const ItemDesc *dp = &dl;
             if (dp->n_new <= 0) return;  // silent: he published nothing
@@ -1158,6 +1184,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
             default: __builtin_amdgcn_s_setprio(3); break;
             }
 #endif
+            reload_params();
             const int src = ord[2 * j + half];
             const ItemDesc dl = load_desc(db + src);
             const ItemDesc *dp = &dl;
@@ -1207,6 +1234,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams P) {
         }
 
         // ---- the two inverse transforms: wave 0 takes the old sum, wave 1 the new one
+        reload_params();
         c2 zko[4], zkn[4], zmo[4], zmn[4];
         ear_sums_to_z(sLo, sRo, special, zko, zmo);
         ear_sums_to_z(sLn, sRn, special, zkn, zmn);
