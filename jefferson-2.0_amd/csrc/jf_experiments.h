@@ -67,6 +67,12 @@
 #define JF_EXP_ROW_LOAD(ptr, st, q, boff, t) (*(ptr))
 #endif
 
+// ---- fused_pair_kernel: what the selects on the wave's half cost (which four bins it keeps, lane 0's packed bins 0/512).
+// 1: both waves of a pair run the code of wave 0 -- wrong results, timing only
+#ifndef JF_EXP_NO_SELECTS
+#define JF_EXP_NO_SELECTS 0
+#endif
+
 // ---- pair_wait
 #ifdef JF_EXP_NOWAIT
 #define JF_EXP_WAIT_SHORTCUT() return

@@ -29,6 +29,8 @@
 // (mix_prep_kernel).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jf_device.h"
 #include "jf_experiments.h"
 #include "jf_packed.h"
@@ -881,17 +883,22 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
     }
     // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  s_ear += x * he_ear, two packed FMAs each.
     auto mac2 = [&](int q, float2 x, c2 heL, c2 heR, c2 &sL, c2 &sR) {
-        const c2 xc = c2_of(x);
-        const c2 nl = pcmac(xc, heL, sL), nr = pcmac(xc, heR, sR);
         if (q == 0) {
             // lane 0 of the lower half: bins 0 and 512 travel as the two halves of one entry (real spectra; c2r drops
-            // their imaginary parts): the product is element by element
-            const c2 el = xc * heL + sL, er = xc * heR + sR;
-            sL = special ? el : nl;
-            sR = special ? er : nr;
+            // their imaginary parts): there the product is element by element.  Both products are the same two packed
+            // FMAs on different first operands -- (re, re) then (im, .) for a complex product, (re, im) then (0, .) for
+            // the element-wise one -- so the exception costs two selects per bin 0, shared by the ears and sets, instead
+            // of a second product and four selects per ear and set (the selects measured 3 % of the kernel's time).
+            const c2 xa = c2{x.x, special ? x.y : x.x};
+            c2 xb;
+            xb.x = special ? 0.0f : x.y;
+            xb.y = xb.x;
+            sL = pfma_lo_rot(xb, heL, pfma_each(xa, heL, sL));
+            sR = pfma_lo_rot(xb, heR, pfma_each(xa, heR, sR));
         } else {
-            sL = nl;
-            sR = nr;
+            const c2 xc = c2_of(x);
+            sL = pcmac(xc, heL, sL);
+            sR = pcmac(xc, heR, sR);
         }
     };
     // The four bins in stages of JF_STAGE_LOADS row loads (16 B per lane each), two stages in flight: while one
@@ -1080,7 +1087,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     const int G = P.G, SG = P.S / G;
     const int n_units = P.K * SG;
     const int qb = 4 * half;
-    const bool special = lane == 0 && half == 0;
+    const bool special = JF_EXP_NO_SELECTS ? false : lane == 0 && half == 0;
     const unsigned lofs = 64u * qb + lane;
     const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
     // Rounds of units over the persistent pairs.  Units differ in cost -- the first blocks of a call gather their windows
@@ -1207,10 +1214,27 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
                 float2 xh[4];
                 mail_free(npub - 1);  // the slot of this hand-off was last used two hand-offs ago
                 float2 *m = mail + ((npub + 1) & 1) * kPairMail + lane;
+                // Which four bins stay and which go to the partner is wave-uniform: a branch, not sixteen selects (3 % of
+                // the kernel's time went into selects on the wave's half and on lane 0's packed bins).  The asm comments
+                // keep the compiler from merging the two sides into selects again or sinking the stores below the join.
+                // (Two copies of the half-filters behind the branch, each reading X D where it is, save the eight moves of
+                // the upper half too but spill: 16 B of scratch, slower.)
+                if (!JF_EXP_NO_SELECTS && half) {
+                    asm volatile("; upper half keeps bins 4..7" ::: "memory");
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    xh[q] = half ? xd[4 + q] : xd[q];
-                    m[64 * q] = half ? xd[q] : xd[4 + q];
+                    for (int q = 0; q < 4; q++) {
+                        m[64 * q] = xd[q];
+                        xh[q] = xd[4 + q];
+                    }
+                    asm volatile("; upper half: stored" ::: "memory");
+                } else {
+                    asm volatile("; lower half keeps bins 0..3" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        m[64 * q] = xd[4 + q];
+                        xh[q] = xd[q];
+                    }
+                    asm volatile("; lower half: stored" ::: "memory");
                 }
                 publish();
                 JF_EXP_PHASE(2);  // hand-off (waiting for a free slot, mailbox stores)

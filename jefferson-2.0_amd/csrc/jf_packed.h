@@ -81,6 +81,11 @@ JF_DEV c2 pcmac(c2 a, c2 w, c2 acc) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(a), "v"(w));  // + (-a.im w.im, a.im w.re)
     return acc;
 }
+// acc + (a.lo w.lo, a.hi w.hi) and acc + a.lo (-w.hi, w.lo): the two halves of pcmac with the first operand's halves
+// given separately -- a complex product when a = (x.re, x.re) then (x.im, .), an element-by-element product when
+// a = (x.re, x.im) then (0, .) (two real bins that travel as one complex entry)
+JF_PK3(pfma_each, "v_pk_fma_f32 %0, %1, %2, %0")
+JF_PK3(pfma_lo_rot, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]")
 // a * conj(w)
 JF_DEV c2 pcmulc(c2 a, c2 w) {
     c2 r;
