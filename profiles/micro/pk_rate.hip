@@ -74,6 +74,21 @@ __global__ __launch_bounds__(256) void probe(float *out, float s) {
             } else if (MODE == 21) {  // cndmask e64 sgpr mask, false operand not the destination
                 asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(a[i].x) : "v"(b.x), "v"(b.y), "s"(mask));
                 asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(a[i].y) : "v"(b.y), "v"(b.x), "s"(mask));
+            } else if (MODE == 22) {  // packed FMA, second source a scalar-register pair (the filters' weights)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "s"(b));
+            } else if (MODE == 23) {  // packed multiply by a scalar-register pair
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(b));
+            } else if (MODE == 24) {  // packed FMA, weight in ONE vector register broadcast by op_sel
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(b), "v"(b));
+            } else if (MODE == 25) {  // fma with an SGPR source
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(b.x), "s"(s));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].y) : "v"(b.y), "s"(s));
+            } else if (MODE == 26) {  // mul with an SGPR source
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i].x) : "s"(s));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i].y) : "s"(s));
+            } else if (MODE == 27) {  // fma with a literal constant (v_fmamk_f32)
+                asm volatile("v_fmamk_f32 %0, %1, 0x3f3504f3, %0" : "+v"(a[i].x) : "v"(b.x));
+                asm volatile("v_fmamk_f32 %0, %1, 0x3f3504f3, %0" : "+v"(a[i].y) : "v"(b.y));
             } else if (MODE == 6) {  // packed add, destination different from sources (3 distinct pairs)
                 asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(b));
             }
@@ -129,6 +144,12 @@ int main() {
     run<19>("2 x v_cndmask_b32_e64 vcc (16)", 16);
     run<20>("2 x v_cndmask_b32 vcc, dst not a source (16)", 16);
     run<21>("2 x v_cndmask_b32_e64 sgpr, dst not a source (16)", 16);
+    run<22>("v_pk_fma_f32, sgpr-pair source (8)", 8);
+    run<23>("v_pk_mul_f32, sgpr-pair source (8)", 8);
+    run<24>("v_pk_fma_f32, vgpr weight via op_sel (8)", 8);
+    run<25>("2 x v_fma_f32 sgpr src (16)", 16);
+    run<26>("2 x v_mul_f32 sgpr src (16)", 16);
+    run<27>("2 x v_fmamk_f32 literal (16)", 16);
     run<0>("2 x v_fma_f32 again (16)", 16);
     return 0;
 }
