@@ -35,11 +35,15 @@ JF_DEV float2 f2_of(c2 v) { return make_float2(v.x, v.y); }
         asm(text : "=v"(r) : "v"(a), "v"(b));         \
         return r;                                     \
     }
-// acc <- acc + (selected halves of a) * (selected halves of b)
-#define JF_PK3(name, text)                            \
-    JF_DEV c2 name(c2 a, c2 b, c2 acc) {              \
-        asm(text : "+v"(acc) : "v"(a), "v"(b));       \
-        return acc;                                   \
+// acc + (selected halves of a) * (selected halves of b).  Three-address form (the result is its own operand, not tied
+// to the addend): with the addend tied ("+v") every accumulator that is carried around a loop through a branchy body was
+// copied once per use -- 16 v_mov_b64 per half-filter of the pair kernel -- because the register allocator could not put
+// the loop's incoming and outgoing value into one register; a free destination lets it write where the value is wanted.
+#define JF_PK3(name, text)                                          \
+    JF_DEV c2 name(c2 a, c2 b, c2 acc) {                            \
+        c2 r;                                                       \
+        asm(text : "=v"(r) : "v"(a), "v"(b), "v"(acc));             \
+        return r;                                                   \
     }
 
 // ---- additions with a rotated or conjugated second operand
@@ -53,8 +57,8 @@ JF_PK2(pcadd_ic, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1
 JF_PK2(pmul_re, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]")                 // (a.re b.re, a.re b.im)
 JF_PK2(pmul_blo, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]")                // a * b.lo (both halves)
 JF_PK2(pmul_bhi, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]")                   // a * b.hi (both halves)
-JF_PK3(pfma_blo, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]")          // acc + a * b.lo
-JF_PK3(pfma_bhi, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]")             // acc + a * b.hi
+JF_PK3(pfma_blo, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]")          // acc + a * b.lo
+JF_PK3(pfma_bhi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]")             // acc + a * b.hi
 
 // ---- a pair times / plus-times a wave-uniform scalar held as a scalar-register pair (w, w)
 JF_DEV c2 pmul_s(c2 a, c2 w) {
@@ -63,8 +67,9 @@ JF_DEV c2 pmul_s(c2 a, c2 w) {
     return r;
 }
 JF_DEV c2 pfma_s(c2 a, c2 w, c2 acc) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(w));
-    return acc;
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(w), "v"(acc));
+    return r;
 }
 
 // ---- complex products: first a packed multiply by a.re, then a packed FMA by a.im
@@ -77,15 +82,16 @@ JF_DEV c2 pcmul(c2 a, c2 w) {
 }
 // acc + a * w
 JF_DEV c2 pcmac(c2 a, c2 w, c2 acc) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(w));                                 // + (a.re w.re, a.re w.im)
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(a), "v"(w));  // + (-a.im w.im, a.im w.re)
-    return acc;
+    c2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));                               // + (a.re w.re, a.re w.im)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));  // + (-a.im w.im, a.im w.re)
+    return r;
 }
 // acc + (a.lo w.lo, a.hi w.hi) and acc + a.lo (-w.hi, w.lo): the two halves of pcmac with the first operand's halves
 // given separately -- a complex product when a = (x.re, x.re) then (x.im, .), an element-by-element product when
 // a = (x.re, x.im) then (0, .) (two real bins that travel as one complex entry)
-JF_PK3(pfma_each, "v_pk_fma_f32 %0, %1, %2, %0")
-JF_PK3(pfma_lo_rot, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]")
+JF_PK3(pfma_each, "v_pk_fma_f32 %0, %1, %2, %3")
+JF_PK3(pfma_lo_rot, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]")
 // a * conj(w)
 JF_DEV c2 pcmulc(c2 a, c2 w) {
     c2 r;
