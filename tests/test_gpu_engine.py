@@ -138,11 +138,21 @@ def test_distance_sweep_gain_and_delay(jf, hrir):
         for x in (e, m):
             x.set_signal(0, sig)
             x.set_spherical(0, 0, 45, r)
-        for _ in range(4):
+        sq = n = 0
+        for _ in range(8):
             y, y64 = e.process_block(), m.process_block()
-            # the 2e-7 bound is for |y| < 1 (the reference flags > 1.0 as clipping, Audio.cu:111);
-            # at r = 0.05 the gain is ~1 and the noise input drives |y| to ~1.3
-            assert np.abs(y - y64).max() <= TOL64 * max(1.0, np.abs(y64).max())
+            # The 2e-7 bound is for |y| < 1 (the reference flags > 1.0 as clipping, Audio.cu:111) and the reference's own
+            # signals; it holds here with a factor two to spare from r = 0.5 on (|y| <= 0.6: 0.9-1.15e-7 over six seeds).
+            # At r = 0.05 the gain is ~1 and FULL-SCALE NOISE drives |y| to 0.9-1.3: float32 transforms of 1024 points
+            # leave an rms error of 4.2e-8 there, and the largest of a few thousand samples is 5-6 sigma -- 2.0-2.8e-7
+            # over six seeds, the same with the complex products written as scalar or as packed instructions
+            # (profiles/accuracy_seeds.py, profiles/r03/accuracy_seeds.txt).  So that case is held to its rms error and
+            # to 3e-7 at the worst sample; a test at 2e-7 passed or failed by the seed.
+            loud = r < 0.1
+            assert np.abs(y - y64).max() <= (3e-7 if loud else TOL64) * max(1.0, np.abs(y64).max())
+            sq += float(np.sum((y - y64) ** 2))
+            n += y.size
+        assert np.sqrt(sq / n) <= (6e-8 if r < 0.1 else 3e-8), r
         e.close()
 
 
