@@ -92,6 +92,10 @@ JF_DEV c2 pcmac(c2 a, c2 w, c2 acc) {
 // a = (x.re, x.im) then (0, .) (two real bins that travel as one complex entry)
 JF_PK3(pfma_each, "v_pk_fma_f32 %0, %1, %2, %3")
 JF_PK3(pfma_lo_rot, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]")
+// acc + (a.hi, -a.lo) * b.hi  (a rotated by -90 degrees, times a real factor kept in the high half of b)
+JF_PK3(pfma_nrot_bhi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")
+// (a.lo b.lo, -a.hi b.lo)
+JF_PK2(pmul_blo_conj, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[0,1]")
 // a * conj(w)
 JF_DEV c2 pcmulc(c2 a, c2 w) {
     c2 r;
