@@ -625,9 +625,28 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     constexpr int B = 64 * NOUT;
     const SrcSignal JF_CONST_AS *sgc = as_const(P.sigs + s);
     SrcSignal sg;
+#ifdef JF_EXP_NOCHAIN
+    // Timing only (wrong results; batch calls of >= 128 sources with signals <= 65536 samples only: the reads then stay
+    // inside the history buffer).  1: no signal record and no play position from memory, every wave reads the same
+    // 240 KB;  2: only the length is a constant (no division);  3: only the pointer is replaced: windows out of the caches
+#if JF_EXP_NOCHAIN == 1
+    sg.ptr = P.S >= 128 ? P.hist_in : sgc->ptr;
+    sg.length = P.S >= 128 ? 61440 : sgc->length;
+    const int count0 = P.S >= 128 ? (s * 977) % 60000 : as_const(P.st_in + s)->count;
+#elif JF_EXP_NOCHAIN == 2
+    sg.ptr = sgc->ptr;
+    sg.length = 44100;
+    const int count0 = as_const(P.st_in + s)->count;
+#else
+    sg.length = sgc->length;
+    sg.ptr = (P.S >= 128 && sg.length <= 65536) ? P.hist_in : sgc->ptr;
+    const int count0 = as_const(P.st_in + s)->count;
+#endif
+#else
     sg.ptr = sgc->ptr;
     sg.length = sgc->length;
     const int count0 = as_const(P.st_in + s)->count;
+#endif
     const float *hist = P.hist_in + (size_t)s * kN;
     // the pointer comes out of a table in memory: tell the compiler it is global memory, or every window load is a
     // flat load that also ties up the LDS counter
