@@ -55,6 +55,14 @@
 #define JF_EXP_FRONT_SHORTCUT(xd, z)
 #endif
 
+// ---- filtered_half: which table row.  JF_EXP_HALFTABLE: every row index folded into the first 355 rows -- what a table
+// half the size (2.9 MB: inside an XCD's 4 MB L2) would do to the row loads (timing only, wrong results)
+#ifdef JF_EXP_HALFTABLE
+#define JF_EXP_TABLE_ROW(r) ((r) % 355)
+#else
+#define JF_EXP_TABLE_ROW(r) (r)
+#endif
+
 // ---- filtered_half: one table-row load
 #ifdef JF_EXP_NOROWLOAD
 #define JF_EXP_ROW_LOAD(ptr, st, q, boff, t) make_float4((float)((st) + (q)), 1.0f, (float)(boff), (float)(t))

@@ -933,7 +933,7 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // rows and weights are wave-uniform: pin them to scalar registers
-        hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512;
+        hp[t] = htab + (size_t)JF_EXP_TABLE_ROW(__builtin_amdgcn_readfirstlane(rows[t])) * 512;
         const float fa = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wa[t])));
         const float fb = BOTH ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wb[t]))) : 0.0f;
         a[t] = c2{fa, fa};
