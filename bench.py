@@ -262,6 +262,8 @@ def main():
                     help="with --reverb: length of the impulse response (4.0 = media/s1_r1_b_441_mono.wav's: 1379 partitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="HIP events around every n-th fused launch of the timed region (1: around every one)")
     ap.add_argument("--cpu-sample-blocks", type=int, default=256)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -390,6 +392,11 @@ def main():
     fence()
     if not os.environ.get("JF_NO_EVENTS"):  # tuning runs: how much do the event records cost?
         eng.profile_enable(2 if ir is not None else 1)  # level 1: two events around the fused kernel
+        # A pair of event records costs ~7 us of stream time -- 2.7 % of a 0.25 ms step (1.30e11 against 1.33e11 with
+        # JF_NO_EVENTS=1, profiles/r03_experiments.md): the fused launch is timed at every EVENT_STRIDE-th step of the timed
+        # region, and its average is over those launches ("launches_timed").  (With the reverb every kernel is timed.)
+        if ir is None:
+            eng.profile_set_stride(args.event_stride)
     t0 = time.perf_counter()
     for i in range(prewarm + W, prewarm + W + K):
         step(i)
@@ -432,8 +439,11 @@ def main():
     if rank == 0:
         frames = world * S * KB * K * B
         value = frames / dt
-        launches = max(prof["launches"], 1)
-        fused_s = prof["fused_ms"] * 1e-3
+        # the launches that were timed (every --event-stride-th step); the workload totals below are over all K steps, so
+        # the timed launches' time is scaled to K launches: fused_s = K x the average timed launch
+        timed = max(prof["launches"], 1)
+        launches = K
+        fused_s = prof["fused_ms"] * 1e-3 / timed * K
         first_step = prewarm + W
         # the run walks the uploaded period cyclically: price each step of the period once (its predecessor block is
         # the one before it on the circle) and count how often each was timed
@@ -448,7 +458,11 @@ def main():
         fused_name = fused_name.split("+")[0]
         roof = {"bound": "valu-fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / FP32_VECTOR_PEAK_TF, "traffic": None, "kernel": fused_name,
-                "avg_launch_ms": prof["fused_ms"] / launches,
+                "avg_launch_ms": prof["fused_ms"] / timed,
+                "launches_timed": timed,
+                "launch_timing": ("HIP events on the engine's stream around every %d-th fused launch of the timed region (%d of %d"
+                                  " launches; a pair of event records costs ~7 us of stream time)" % (args.event_stride, timed, K)
+                                  if ir is None else "HIP events around every kernel of every step"),
                 "launch_includes": ("the next window's descriptors (index/weight rule for 131 072 items in trailing "
                                     "workgroups, ~2.5 us of the launch, ~20 of the VALU instructions per source-block)"
                                     if fused_has_prep else None),

@@ -78,6 +78,7 @@ _SIGS = {
     "jf_reverb_set_ir": (C.c_int, [C.c_void_p, _f, C.c_size_t, C.c_float]),
     "jf_reverb_rms_gain": (C.c_float, [_f, C.c_size_t, _f, C.c_size_t]),
     "jf_profile_read_reverb": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "jf_profile_set_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_source_group": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "jf_debug_source_order": (C.c_int, [C.c_void_p, _i]),
@@ -297,6 +298,9 @@ class Engine:
 
     def profile_enable(self, on):
         self._chk(lib().jf_profile_enable(self.h, int(on)))
+
+    def profile_set_stride(self, every):
+        self._chk(lib().jf_profile_set_stride(self.h, int(every)))
 
     def profile_read(self):
         f, p, m = C.c_double(), C.c_double(), C.c_double()

@@ -128,6 +128,8 @@ struct jf_engine {
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
     int profiling = 0;  // 0 off, 1 = time the fused kernel only (2 events per call), 2 = every kernel
+    int profile_stride = 1;    // level 1: events around every n-th batch run only (jf_profile_set_stride)
+    long profile_calls = 0;
     std::vector<EventPair> ev_prep, ev_fused, ev_mix, ev_reverb;
     size_t ev_used = 0;
 
@@ -240,7 +242,10 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);  // fatal: see device_fault
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
-    if (e->profiling) {
+    // a pair of event records costs ~7 us of stream time: at level 1 they may be put around every n-th run only
+    const bool timed = e->profiling >= 2 ||
+                       (e->profiling == 1 && (e->profile_stride <= 1 || e->profile_calls++ % e->profile_stride == 0));
+    if (timed) {
         ef = next_events(e, e->ev_fused);
         if (!ef) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
@@ -329,7 +334,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
         JF_HIP(e, launch_mix(e->d_partial, d_mix_out, e->S / P.G, K, e->B, e->stream));
     }
     if (em) JF_HIP(e, hipEventRecord(em->b, e->stream));
-    if (e->profiling) e->ev_used++;
+    if (timed) e->ev_used++;
     e->cur = p ^ 1;
     e->last_rt = false;
     return JF_OK;
@@ -1048,6 +1053,16 @@ int jf_profile_enable(jf_engine *e, int enable) {
     JF_HIP(e, hipStreamSynchronize(e->stream));
     e->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     e->ev_used = 0;
+    e->profile_calls = 0;
+    return JF_OK;
+    });
+}
+
+int jf_profile_set_stride(jf_engine *e, int every) {
+    return jf_guard([&]() -> int {
+    if (!e || every < 1) return JF_ERR_ARG;
+    e->profile_stride = every;
+    e->profile_calls = 0;
     return JF_OK;
     });
 }
