@@ -558,3 +558,39 @@ def test_descriptors_prepared_ahead_change_nothing(jf, hrir, castanets):
     assert "prep_kernel" not in ka
     a.close()
     b.close()
+
+
+def test_profile_stride_times_every_nth_run(jf, hrir, castanets):
+    """jf_profile_set_stride: at level 1 the two event records go around every n-th batch run only (a pair costs ~7 us of
+    stream time, which bench.py does not want in every step); `launches` counts the timed runs, the average is a run's."""
+    wl = _workload()
+    S, B, K, T = 32, 128, 8, 64
+    ids = np.arange(S)
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    for s in ids:
+        e.set_signal(int(s), castanets[1000 * s: 1000 * s + 30000])
+    e.upload_positions(wl.trajectories(jf, ids, T))
+    e.profile_enable(1)
+    e.profile_set_stride(3)
+    for i in range(8):            # runs 0, 3, 6 are timed
+        e.batch_run((i * K) % T, K)
+    e.synchronize()
+    p = e.profile_read()
+    assert p["launches"] == 3
+    per_run = p["fused_ms"] / 3
+    e.profile_enable(1)           # a new measurement, every run timed
+    e.profile_set_stride(1)
+    for i in range(8):
+        e.batch_run((i * K) % T, K)
+    e.synchronize()
+    q = e.profile_read()
+    e.profile_enable(False)
+    e.close()
+    assert q["launches"] == 8
+    assert 0.2 * per_run < q["fused_ms"] / 8 < 5.0 * per_run   # the same kernel, microseconds either way
+    with pytest.raises(jf.JfError):
+        e2 = jf.Engine(B, 512, 2, hrir=hrir)
+        try:
+            e2.profile_set_stride(0)
+        finally:
+            e2.close()
