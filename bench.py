@@ -394,9 +394,9 @@ def main():
         eng.profile_enable(2 if ir is not None else 1)  # level 1: two events around the fused kernel
         # A pair of event records costs ~7 us of stream time -- 2.7 % of a 0.25 ms step (1.30e11 against 1.33e11 with
         # JF_NO_EVENTS=1, profiles/r03_experiments.md): the fused launch is timed at every EVENT_STRIDE-th step of the timed
-        # region, and its average is over those launches ("launches_timed").  (With the reverb every kernel is timed.)
-        if ir is None:
-            eng.profile_set_stride(args.event_stride)
+        # region, and its average is over those launches ("launches_timed").  With the reverb every kernel of such a step
+        # is timed (eight records).
+        eng.profile_set_stride(args.event_stride)
     t0 = time.perf_counter()
     for i in range(prewarm + W, prewarm + W + K):
         step(i)
@@ -462,7 +462,9 @@ def main():
                 "launches_timed": timed,
                 "launch_timing": ("HIP events on the engine's stream around every %d-th fused launch of the timed region (%d of %d"
                                   " launches; a pair of event records costs ~7 us of stream time)" % (args.event_stride, timed, K)
-                                  if ir is None else "HIP events around every kernel of every step"),
+                                  if ir is None else
+                                  "HIP events around every kernel of every %d-th step of the timed region (%d of %d steps)"
+                                  % (args.event_stride, timed, K)),
                 "launch_includes": ("the next window's descriptors (index/weight rule for 131 072 items in trailing "
                                     "workgroups, ~2.5 us of the launch, ~20 of the VALU instructions per source-block)"
                                     if fused_has_prep else None),
@@ -549,7 +551,7 @@ def main():
             # 690*129*8 B of IR spectra once per block (shared by all sources)
             P = -(-len(ir) // B)
             rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
-            t = reverb_ms / launches * 1e-3
+            t = reverb_ms / timed * 1e-3  # average over the steps whose kernels were timed
             mac_name = next((k for k in kernels if k.startswith("reverb_mac")), "reverb_mac")
             std = S == 256 and len(ir) == 88200
             out["config"]["workload"] = (("configs[4]: " if std else "configs[4] scaled: ")

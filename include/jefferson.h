@@ -246,8 +246,9 @@ void *jf_engine_stream(jf_engine *e);
  * milliseconds and launch count since arming (prep/mix are 0 at level 1). */
 int jf_profile_enable(jf_engine *e, int enable);
 int jf_profile_read(jf_engine *e, double *fused_ms, double *prep_ms, double *mix_ms, long *launches);
-/* Level 1 only: put the two event records around every `every`-th batch run (default 1: around all).  A pair of records
- * costs ~7 us of stream time, 2.7 % of a 0.25 ms run; jf_profile_read's `launches` counts the runs that were timed. */
+/* Put the event records around every `every`-th batch run only (default 1: around all; the runs in between launch the
+ * same kernels).  A pair of records costs ~7 us of stream time, 2.7 % of a 0.25 ms run; jf_profile_read's `launches`
+ * counts the runs that were timed. */
 int jf_profile_set_stride(jf_engine *e, int every);
 int jf_profile_read_reverb(jf_engine *e, double *reverb_ms); /* the two reverb kernels, same launches */
 

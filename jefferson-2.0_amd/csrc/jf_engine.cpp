@@ -128,8 +128,9 @@ struct jf_engine {
     bool have_prev = false;         // jf_callback: a block is pending from the previous call
 
     int profiling = 0;  // 0 off, 1 = time the fused kernel only (2 events per call), 2 = every kernel
-    int profile_stride = 1;    // level 1: events around every n-th batch run only (jf_profile_set_stride)
+    int profile_stride = 1;    // events around every n-th batch run only (jf_profile_set_stride)
     long profile_calls = 0;
+    bool timed_now = false;    // this batch run carries event records
     std::vector<EventPair> ev_prep, ev_fused, ev_mix, ev_reverb;
     size_t ev_used = 0;
 
@@ -206,7 +207,7 @@ EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
 static int run_reverb_stage(jf_engine *e, int p, int K) {
     if (e->rv_P <= 0) return JF_OK;
     EventPair *er = nullptr;
-    if (e->profiling >= 2) {
+    if (e->profiling >= 2 && e->timed_now) {
         er = next_events(e, e->ev_reverb);
         if (!er) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
         JF_HIP(e, hipEventRecord(er->a, e->stream));
@@ -242,14 +243,15 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);  // fatal: see device_fault
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
-    // a pair of event records costs ~7 us of stream time: at level 1 they may be put around every n-th run only
-    const bool timed = e->profiling >= 2 ||
-                       (e->profiling == 1 && (e->profile_stride <= 1 || e->profile_calls++ % e->profile_stride == 0));
+    // a pair of event records costs ~7 us of stream time: they may be put around every n-th run only (the runs in
+    // between launch the same kernels, untimed)
+    const bool timed = e->profiling && (e->profile_stride <= 1 || e->profile_calls++ % e->profile_stride == 0);
+    e->timed_now = timed;
     if (timed) {
         ef = next_events(e, e->ev_fused);
         if (!ef) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
     }
-    if (e->profiling >= 2) {
+    if (e->profiling >= 2 && timed) {
         ep = next_events(e, e->ev_prep);
         em = next_events(e, e->ev_mix);
         if (!ep || !em) return fail(e, JF_ERR_DEVICE, "hipEventCreate failed");
