@@ -470,6 +470,9 @@ JF_DEV float2 distance_from_phase_tab(unsigned p, float inv_frac, const float2 *
 
 // D of this lane's bins lane + 64 q, q = 0..7, and Re D[512].  Phase words by 64-bit accumulation (two adds per bin
 // instead of two quarter-rate 32-bit multiplies): hi32(k c mod 2^64), k = lane + 64 q; every bin evaluated on its own.
+// Bin 512's factor is wave-uniform and was a ninth evaluation by all lanes; bin 0's is 1/frac exactly and needs none: LANE 0
+// EVALUATES D[512] IN ITS SLOT OF BIN 0 (one select on the phase word), so dq[0] on lane 0 is D[512], not D[0] -- its
+// callers take X[0] D[0] = X[0].x inv_frac and d512x there (distance_factor_bin0 restores the slot where D itself is wanted).
 // JF_FAST_DISTANCE (off): D[lane + 64 q] = D[lane] E^q with the wave-uniform step E = exp(-2 pi i 64 c), whose
 // powers lanes 0..8 evaluate and broadcast through scalar registers -- 135 fewer instructions per source-block, 4.5 %
 // of the batch kernel's time, but one more rounding per factor: on a full-scale signal (|y| ~ 1.2) the output error
@@ -482,19 +485,17 @@ JF_DEV void distance_factors(unsigned c_hi, unsigned c_lo, float inv_frac, int l
     const unsigned long long step = c64 << 6;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
+        unsigned p = (unsigned)(ph >> 32);
+        if (q == 0) p = lane == 0 ? (unsigned)((c64 << 9) >> 32) : p;
 #if JF_TABLE_DISTANCE
-        dq[q] = distance_from_phase_tab((unsigned)(ph >> 32), inv_frac, tw);
+        dq[q] = distance_from_phase_tab(p, inv_frac, tw);
         if (q & 1) __builtin_amdgcn_sched_barrier(0);  // two table reads in flight, not eight (registers)
 #else
-        dq[q] = distance_from_phase((unsigned)(ph >> 32), inv_frac);
+        dq[q] = distance_from_phase(p, inv_frac);
 #endif
         ph += step;
     }
-#if JF_TABLE_DISTANCE
-    d512x = distance_from_phase_tab((unsigned)((c64 << 9) >> 32), inv_frac, tw).x;
-#else
-    d512x = distance_from_phase((unsigned)((c64 << 9) >> 32), inv_frac).x;
-#endif
+    d512x = dq[0].x;  // on lane 0 (the only lane that uses it)
 #else
     const float2 d0 = distance_from_phase((unsigned)(((unsigned long long)(unsigned)lane * c64) >> 32), inv_frac);
     const float2 e = distance_from_phase((unsigned)(((unsigned long long)(unsigned)(lane & 15) * (c64 << 6)) >> 32), 1.0f);
@@ -2028,6 +2029,7 @@ __global__ __launch_bounds__(64) void stage_debug_kernel(const RingTable rt, int
     float2 dq[8];
     float d512x;
     distance_factors(c_hi, c_lo, dp->inv_frac, lane, dq, d512x, s_tw);
+    dq[0] = lane == 0 ? make_float2(dp->inv_frac, -0.0f) : dq[0];  // D[0] = 1/frac exactly (see distance_factors)
     float2 *dout = dist + (size_t)blockIdx.x * kNc;
 #pragma unroll
     for (int q = 0; q < 8; q++) dout[lane + 64 * q] = dq[q];
