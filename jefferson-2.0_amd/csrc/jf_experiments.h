@@ -81,6 +81,17 @@
 #define JF_EXP_NO_SELECTS 0
 #endif
 
+// ---- fused_pair_kernel: do the waves of a SIMD (w, w + 4, w + 8, w + 12) lose by starting a launch in the same phase?
+// JF_EXP_STAGGER_US = n: wave w starts (w / 4) * n / 4 microseconds late (s_sleep counts 64 cycles: ~0.03 us)
+#ifdef JF_EXP_STAGGER_US
+#define JF_EXP_STAGGER(wave)                                                          \
+    do {                                                                              \
+        for (int i_ = 0; i_ < ((wave) >> 2) * (JF_EXP_STAGGER_US) * 8; i_++) __builtin_amdgcn_s_sleep(1); \
+    } while (0)
+#else
+#define JF_EXP_STAGGER(wave)
+#endif
+
 // ---- pair_wait
 #ifdef JF_EXP_NOWAIT
 #define JF_EXP_WAIT_SHORTCUT() return

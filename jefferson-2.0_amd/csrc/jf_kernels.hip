@@ -1113,6 +1113,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
 #endif
     JF_EXP_STAMP_SETUP(P, pair, half, lane);
     JF_EXP_PHASE_SETUP();
+    JF_EXP_STAGGER(wave);
     float2 *base = s_pair + pair * kPairLds;
     float2 *buf = base + half * kPairWave;  // my FFT work space
     float2 *mail = buf + kPairWork;         // my two mailbox slots
