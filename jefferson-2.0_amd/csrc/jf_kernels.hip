@@ -20,8 +20,8 @@
 //   store the B stereo frames of this source                            a11
 //
 // fused_block_kernel: one stereo block per source (the reference's `intermediate`); fused_pair_kernel: BOTH
-// filter sets of G consecutive sources summed as spectra and inverted once; rt_block_kernel: one launch per audio
-// block for the per-block calls.
+// filter sets of G consecutive sources summed as spectra (per ear: sum X D H_left, sum X D H_right, turned into Z once
+// per unit) and inverted once; rt_block_kernel: one launch per audio block for the per-block calls.
 //
 // mix_kernel / mix_few_kernel sum the per-source (per-group) blocks in source order (a12), prep_kernel computes
 // indices/weights (a2, a3) for every item.  A run prepares the NEXT window's descriptors itself: the pair kernel in
