@@ -59,6 +59,16 @@ typedef struct jf_engine jf_engine;
  * wrap, weights that sum to 1, elevations below -40 clamped to the lowest ring.  Not in the reference.
  */
 #define JF_FLAG_CORRECTED_INTERPOLATION 1u
+/*
+ * The setters round elevation and azimuth to whole degrees (SoundSource.cu:33-34,42-43), so every position they latch is
+ * one of 131 x 360.  By default an engine therefore also holds, behind the 710 measured rows, the weighted filter
+ * sum_t w_t H[row_t] of each of those positions (386 MB of HBM, built once at creation by the same operations in the same
+ * order as the per-block weighting: results are bit-identical) and batch calls read ONE row per filter set instead of up
+ * to four rows and their weights (what GPUSoundSource.cu:118-292 recomputes for every block).  Positions that are not
+ * whole degrees inside -40..90 x 0..359 keep the per-block weighting.  JF_FLAG_NO_INTERP_TABLE: do not build it
+ * (the environment variable JF_INTERP_TABLE=0 does the same for every engine of a process).
+ */
+#define JF_FLAG_NO_INTERP_TABLE 2u
 
 typedef struct jf_config {
     int frames_per_buffer; /* FRAMES_PER_BUFFER (Universal.cuh:10): 128 or 256 (any multiple of 64 up to 256) */
@@ -303,6 +313,19 @@ int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
+/* Whether batch calls use the pre-interpolated rows (JF_FLAG_NO_INTERP_TABLE above; default on when they were built).
+ * on = 1 for an engine that did not build them: JF_ERR_STATE.  Results are bit-identical either way. */
+int jf_debug_set_interp_table(jf_engine *e, int on);
+/* 1 if the engine holds the pre-interpolated rows and uses them, 0 if not. */
+int jf_debug_interp_table(const jf_engine *e);
+/* How many of the first n_items descriptors of the last batch run (items b * n_sources + s) carry any bit of `mask` in
+ * their flags (pair-kernel layout: 1 = both sets on one row list, 2 = crossfade, 4 = both sets are pre-interpolated
+ * rows); < 0: error. */
+int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask);
+/* n rows of the device table in the DEVICE layout (512 x {L.re, L.im, R.re, R.im} per row, bin 0 = {L[0], L[512], R[0],
+ * R[512]}), starting at `first_row`: rows 0..709 are the measured ones, row 710 + (ele + 40) * 360 + azi the
+ * pre-interpolated filter of the whole-degree position (ele, azi). */
+int jf_debug_read_table_rows(jf_engine *e, int first_row, int n, float *out /* n*512*4 */);
 /* Copy of the device HRTF spectrum table in the REFERENCE layout
  * fft_hrtf[(j*2 + ear)*Nc + k] (hrtf_signals.cu:90-98), complex64 -> 2 floats. */
 int jf_debug_read_table(jf_engine *e, float *out /* 710*2*Nc*2 */);

@@ -17,6 +17,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
 
 JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 JF_FLAG_CORRECTED_INTERPOLATION = 1
+JF_FLAG_NO_INTERP_TABLE = 2
+INTERP_ROWS = 131 * 360
 JF_MODE_FD_COMPLEX, JF_MODE_FD_BASIC = 0, 1
 NUM_HRTF = 710
 PAD_LEN = 1024
@@ -92,6 +94,10 @@ _SIGS = {
     "jf_debug_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "jf_debug_set_rt_max_sources": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
+    "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
+    "jf_debug_count_desc_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "jf_debug_read_table_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f]),
     "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
     "jf_debug_rfft_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f]),
     "jf_wav_read_mono": (C.c_int, [C.c_char_p, C.POINTER(_f), C.POINTER(C.c_size_t), _i]),
@@ -375,6 +381,24 @@ class Engine:
         t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)
         self._chk(lib().jf_debug_read_table(self.h, _fp(t)))
         return t.view(np.complex64)[..., 0]
+
+    def set_interp_table(self, on):
+        self._chk(lib().jf_debug_set_interp_table(self.h, int(bool(on))))
+
+    def interp_table(self):
+        return bool(lib().jf_debug_interp_table(self.h))
+
+    def count_desc_flags(self, n_items, mask):
+        n = lib().jf_debug_count_desc_flags(self.h, int(n_items), int(mask))
+        if n < 0:
+            self._chk(n)
+        return n
+
+    def read_table_rows(self, first_row, n):
+        """n rows in the device layout: [n][512][4] = {L.re, L.im, R.re, R.im} (bin 0: {L[0], L[512], R[0], R[512]})."""
+        t = np.zeros((n, 512, 4), np.float32)
+        self._chk(lib().jf_debug_read_table_rows(self.h, int(first_row), int(n), _fp(t)))
+        return t
 
     def interp_device(self, ele, azi):
         ele = np.ascontiguousarray(ele, np.float32)

@@ -8,6 +8,11 @@
 //                             16-byte load per lane fetches both ears and a row
 //                             is exactly 8 KiB.  Same numbers as the reference's
 //                             fft_hrtf[(j*2+ear)*513+k] (hrtf_signals.cu:90-98).
+//                             Rows 710 .. 710 + 47159 (optional, 386 MB): the PRE-INTERPOLATED filters of every whole-degree
+//                             position the setters can latch (SoundSource.cu:33-34,42-43 round to whole degrees):
+//                             row 710 + (ele + 40) * 360 + azi = sum_t w_t H[row_t] for (ele, azi), ele -40..90,
+//                             azi 0..359, by the same operations in the same order as the filters' own weighting
+//                             (table_interp_build_kernel).  A filter set is then ONE row with weight 1.
 //   tw     float2[1024]       exp(+2*pi*i*j/1024), from double (reverb kernels).
 //   twpack float2[2368]       the same values re-laid per FFT pass (see kTw* below), staged in LDS.
 //   sig    float[len_s]       one device buffer per source (looped playback).
@@ -28,6 +33,10 @@ constexpr int kN = 1024;       // PAD_LEN (Universal.cuh:12)
 constexpr int kNc = 513;       // PAD_LEN / 2 + 1
 constexpr int kNumHrtf = 710;  // NUM_HRTF (Universal.cuh:4)
 constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
+// pre-interpolated rows behind the 710 measured ones (see htab above)
+constexpr int kInterpEleMin = -40, kInterpEleMax = 90, kInterpAzi = 360;
+constexpr int kInterpRows = (kInterpEleMax - kInterpEleMin + 1) * kInterpAzi;  // 47 160
+constexpr int kModeBasic = 1, kModeCorrected = 2, kModeInterpRows = 4;  // bits of the kernels' `mode`
 // Tuning knobs of the fused kernel (overridable at build time for A/B runs):
 // waves (= work items) per workgroup, and the minimum waves per SIMD the register
 // allocator must leave room for (__launch_bounds__ second argument; 0 = unconstrained).
@@ -84,7 +93,8 @@ struct ItemDesc {
     int n_old;       // 0 = no crossfade
     int flags;       // pair-kernel layout (prep_kernel with canon = 1): bit 0 = both sets read rows_new[] (w_old[] / w_new[]
                      // are their weights on those rows, 0 where a set does not use a row; n_old == n_new), bit 1 = the
-                     // source moved (crossfade); a source that did not move carries its new set as old set too
+                     // source moved (crossfade); a source that did not move carries its new set as old set too;
+                     // bit 2 = rows_new[0] and rows_old[0] are pre-interpolated rows: whole filters, weight 1
 };
 static_assert(sizeof(ItemDesc) == 88, "ItemDesc layout");
 
@@ -124,7 +134,8 @@ struct FusedParams {
     float *partial;         // [K][S/G][2B]
     int S, K, B;
     int G;  // consecutive sources summed in registers by one wavefront (S % G == 0)
-    int mode;  // 0 = FD_COMPLEX, 1 = FD_BASIC: used where descriptors are built in-kernel (real-time kernel)
+    int mode;  // bit 0 = FD_BASIC, bit 1 = corrected index/weight rule, bit 2 = htab holds the pre-interpolated rows: used
+               // where descriptors are built in-kernel (real-time kernel, the pair kernel's trailing workgroups)
     const int *order;  // [S] pair kernel: unit u works on sources order[G u .. G u + G - 1] (identity unless the engine sorted)
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
     // fused_pair_kernel only: workgroups n_pair_wgs .. gridDim.x - 1 prepare the descriptors of the window that FOLLOWS this

@@ -19,6 +19,7 @@
 
 namespace jf {
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
+hipError_t launch_table_interp_build(const RingTable &rt, int corrected, float4 *d_htab, hipStream_t st);
 hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
                                float *d_w, int *d_nt, int n, int corrected, hipStream_t st);
@@ -37,6 +38,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used);
+int kernels_build_kind();
 }  // namespace jf
 
 using namespace jf;
@@ -62,6 +64,8 @@ struct jf_engine {
     std::string err;
 
     float4 *d_htab = nullptr;
+    bool interp_built = false;  // d_htab also holds the kInterpRows pre-interpolated rows (jf_device.h)
+    bool interp_use = false;    // ... and batch calls use them (jf_debug_set_interp_table)
     float2 *d_tw = nullptr;
     float2 *d_twpack = nullptr;
     SrcSignal *d_sigs = nullptr;
@@ -270,7 +274,8 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     FusedParams P;
     P.G = (e->S % G == 0) ? G : 1;
     const int canon = P.G > 1;  // descriptors in the pair-kernel layout
-    const int mode_now = kernel_mode(e);
+    // whole-degree positions as pre-interpolated rows: the pair kernel's descriptors only
+    const int mode_now = kernel_mode(e) | ((canon && e->interp_built && e->interp_use) ? kModeInterpRows : 0);
     // per-kernel timing (profiling >= 2) keeps prep and mix as launches of their own
     const bool have = e->ahead.valid && e->profiling < 2 && first_block >= 0 && e->ahead.first == first_block &&
                       e->ahead.K == K && e->ahead.mode == mode_now && e->ahead.canon == canon &&
@@ -440,7 +445,16 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     if (pad != kN) return fail(nullptr, JF_ERR_ARG, "frames_per_buffer + hrtf_len - 1 must pad to 1024");
     if (cfg->n_sources <= 0) return fail(nullptr, JF_ERR_ARG, "n_sources must be positive");
     if (cfg->max_batch_blocks <= 0) return fail(nullptr, JF_ERR_ARG, "max_batch_blocks must be positive");
-    if (cfg->flags & ~JF_FLAG_CORRECTED_INTERPOLATION) return fail(nullptr, JF_ERR_ARG, "unknown bits in flags");
+    if (cfg->flags & ~(JF_FLAG_CORRECTED_INTERPOLATION | JF_FLAG_NO_INTERP_TABLE))
+        return fail(nullptr, JF_ERR_ARG, "unknown bits in flags");
+    if (kernels_build_kind() != 0) {
+        // a fault-injection or timing-only build of the kernels (jf_experiments.h): wrong results by design
+        const char *allow = getenv("JF_ALLOW_EXPERIMENT");
+        if (!allow || strcmp(allow, "1") != 0)
+            return fail(nullptr, JF_ERR_STATE,
+                        "this library was built with an experiment switch that gives wrong results by design "
+                        "(set JF_ALLOW_EXPERIMENT=1 to use it in a test)");
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -460,7 +474,12 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipSetDevice(cfg->device));
         JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int kind = 0; kind < 2; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
-        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
+        {
+            const char *env = getenv("JF_INTERP_TABLE");
+            e->interp_built = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
+            e->interp_use = e->interp_built;
+        }
+        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + (e->interp_built ? kInterpRows : 0)) * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
         for (int i = 0; i < 2; i++) {
@@ -536,6 +555,9 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&d_hrir, hb));
         hipError_t s1 = hipMemcpy(d_hrir, hrir, hb, hipMemcpyHostToDevice);
         hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_twpack, e->d_htab, e->stream) : s1;
+        // ... and the weighted sums of every whole-degree position behind them (same stream: after the rows they read)
+        if (s2 == hipSuccess && e->interp_built)
+            s2 = launch_table_interp_build(e->rt, (cfg->flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->d_htab, e->stream);
         hipError_t s3 = s2 == hipSuccess ? hipStreamSynchronize(e->stream) : s2;
         (void)hipFree(d_hrir);
         JF_HIP(e, s3);
@@ -1139,6 +1161,41 @@ int jf_debug_set_reverb_form(jf_engine *e, int form) {
     return jf_guard([&]() -> int {
     if (!e || form < 0 || form > 3) return JF_ERR_ARG;
     e->rv_form = form;
+    return JF_OK;
+    });
+}
+
+int jf_debug_set_interp_table(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    if (on && !e->interp_built) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
+    e->interp_use = on != 0;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
+    return JF_OK;
+    });
+}
+
+int jf_debug_interp_table(const jf_engine *e) { return e && e->interp_built && e->interp_use ? 1 : 0; }
+
+int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask) {
+    return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
+    if (!e || n_items <= 0 || (size_t)n_items > (size_t)e->S * e->maxK) return JF_ERR_ARG;
+    std::vector<ItemDesc> d((size_t)n_items);
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    JF_HIP(e, hipMemcpy(d.data(), e->d_desc, sizeof(ItemDesc) * d.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (const ItemDesc &x : d) n += (x.flags & mask) != 0;
+    return n;
+    });
+}
+
+int jf_debug_read_table_rows(jf_engine *e, int first_row, int n, float *out) {
+    return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
+    const int total = kNumHrtf + (e && e->interp_built ? kInterpRows : 0);
+    if (!e || !out || n <= 0 || first_row < 0 || first_row > total - n) return fail(e, JF_ERR_ARG, "rows outside the table");
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    JF_HIP(e, hipMemcpy(out, e->d_htab + (size_t)first_row * 512, sizeof(float4) * 512 * (size_t)n, hipMemcpyDeviceToHost));
     return JF_OK;
     });
 }

@@ -626,28 +626,9 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     constexpr int B = 64 * NOUT;
     const SrcSignal JF_CONST_AS *sgc = as_const(P.sigs + s);
     SrcSignal sg;
-#ifdef JF_EXP_NOCHAIN
-    // Timing only (wrong results; batch calls of >= 128 sources with signals <= 65536 samples only: the reads then stay
-    // inside the history buffer).  1: no signal record and no play position from memory, every wave reads the same
-    // 240 KB;  2: only the length is a constant (no division);  3: only the pointer is replaced: windows out of the caches
-#if JF_EXP_NOCHAIN == 1
-    sg.ptr = P.S >= 128 ? P.hist_in : sgc->ptr;
-    sg.length = P.S >= 128 ? 61440 : sgc->length;
-    const int count0 = P.S >= 128 ? (s * 977) % 60000 : as_const(P.st_in + s)->count;
-#elif JF_EXP_NOCHAIN == 2
-    sg.ptr = sgc->ptr;
-    sg.length = 44100;
-    const int count0 = as_const(P.st_in + s)->count;
-#else
-    sg.length = sgc->length;
-    sg.ptr = (P.S >= 128 && sg.length <= 65536) ? P.hist_in : sgc->ptr;
-    const int count0 = as_const(P.st_in + s)->count;
-#endif
-#else
     sg.ptr = sgc->ptr;
     sg.length = sgc->length;
     const int count0 = as_const(P.st_in + s)->count;
-#endif
     const float *hist = P.hist_in + (size_t)s * kN;
     // the pointer comes out of a table in memory: tell the compiler it is global memory, or every window load is a
     // flat load that also ties up the LDS counter
@@ -665,12 +646,11 @@ JF_DEV void item_gather(const FusedParams &P, int b, int s, int lane, float2 (&z
     // the signal) every lane works out where its samples are; all loads are in flight together either way.
     int start0 = base + q0;  // signal index of the window's first sample (meaningful for q0 >= 0), < L + N
     start0 = start0 >= L ? start0 - L : start0;
-    bool one_stretch = q0 >= 0 && start0 + kN <= L;
-    JF_EXP_GATHER_PATH(one_stretch, start0);
+    const bool one_stretch = q0 >= 0 && start0 + kN <= L;
     if (one_stretch) {
-        [[maybe_unused]] const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
+        const gpair *p = reinterpret_cast<const gpair *>(sigp + start0 + 2u * lane);
 #pragma unroll
-        for (int r = 0; r < 8; r++) z[r] = JF_EXP_WINDOW_PAIR(p, r, start0, lane);
+        for (int r = 0; r < 8; r++) z[r] = make_float2(p[64 * r].x, p[64 * r].y);
     } else {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -735,7 +715,6 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     }
 
     if (n_new <= 0) return false;
-    JF_EXP_FRONT_SHORTCUT(xd, z);
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
@@ -901,7 +880,6 @@ JF_DEV void lds_flag_write(unsigned addr, int v) {
 // Every wait is bounded (about a tenth of a second): a hand-off that never arrives -- impossible by the protocol
 // above -- raises the host-visible error word and lets the grid drain instead of hanging the GPU.
 JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
-    JF_EXP_WAIT_SHORTCUT();
     if (dead) return;  // after one time-out this wave no longer waits for anything
     for (int spins = 0; lds_flag_read(flag) < v; spins++) {
         __builtin_amdgcn_s_sleep(1);
@@ -922,6 +900,41 @@ JF_DEV void pair_wait(unsigned flag, int v, int *err, bool &dead) {
 // with ONE per-lane offset register for all rows: loads in the saddr form, no 64-bit pointer pair per row.
 // fetch(xh) delivers the source's X D for these bins; it is called AFTER the first two stages of row loads have been
 // requested, so whatever it waits for (the partner's hand-off flag, the mailbox read) overlaps with their latency.
+// he_ear = sum_t w_t H[row_t]: a packed multiply by the first weight, then one packed FMA per further row, in the rows'
+// order.  The ONE place this sum is written: the half-filters below and table_interp_build_kernel (the pre-interpolated
+// rows) both call it, so a pre-interpolated row holds bit for bit what a half-filter forms from the measured rows.
+template <int NT>
+JF_DEV void weighted_ears(const float4 (&hq)[NT], const c2 (&w)[NT], c2 &heL, c2 &heR) {
+    heL = pmul_s(c2{hq[0].x, hq[0].y}, w[0]);
+    heR = pmul_s(c2{hq[0].z, hq[0].w}, w[0]);
+#pragma unroll
+    for (int t = 1; t < NT; t++) {
+        heL = pfma_s(c2{hq[t].x, hq[t].y}, w[t], heL);
+        heR = pfma_s(c2{hq[t].z, hq[t].w}, w[t], heR);
+    }
+}
+
+// s_ear += x * he_ear, two packed FMAs per ear (jf_packed.h).  q == 0 && special: lane 0 of the lower half, where bins 0
+// and 512 travel as the two halves of one entry (real spectra; c2r drops their imaginary parts) and the product is
+// element by element.  Both products are the same two packed FMAs on different first operands -- (re, re) then (im, .)
+// for a complex product, (re, im) then (0, .) for the element-wise one -- so the exception costs two selects per bin 0,
+// shared by the ears and sets, instead of a second product and four selects per ear and set (the selects measured 3 % of
+// the kernel's time).
+JF_DEV void mac_ears(int q, bool special, float2 x, c2 heL, c2 heR, c2 &sL, c2 &sR) {
+    if (q == 0) {
+        const c2 xa = c2{x.x, special ? x.y : x.x};
+        c2 xb;
+        xb.x = special ? 0.0f : x.y;
+        xb.y = xb.x;
+        sL = pfma_lo_rot(xb, heL, pfma_each(xa, heL, sL));
+        sR = pfma_lo_rot(xb, heR, pfma_each(xa, heR, sR));
+    } else {
+        const c2 xc = c2_of(x);
+        sL = pcmac(xc, heL, sL);
+        sR = pcmac(xc, heR, sR);
+    }
+}
+
 template <int NT, bool BOTH, class X>
 JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const int *rows, const float *wa, const float *wb,
                           X &&fetch, bool special, c2 (&sLa)[4], c2 (&sRa)[4], c2 (&sLb)[4], c2 (&sRb)[4]) {
@@ -934,32 +947,14 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         // rows and weights are wave-uniform: pin them to scalar registers
-        hp[t] = htab + (size_t)JF_EXP_TABLE_ROW(__builtin_amdgcn_readfirstlane(rows[t])) * 512;
+        hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512;
         const float fa = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wa[t])));
         const float fb = BOTH ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wb[t]))) : 0.0f;
         a[t] = c2{fa, fa};
         b[t] = c2{fb, fb};
     }
-    // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.  s_ear += x * he_ear, two packed FMAs each.
-    auto mac2 = [&](int q, float2 x, c2 heL, c2 heR, c2 &sL, c2 &sR) {
-        if (q == 0) {
-            // lane 0 of the lower half: bins 0 and 512 travel as the two halves of one entry (real spectra; c2r drops
-            // their imaginary parts): there the product is element by element.  Both products are the same two packed
-            // FMAs on different first operands -- (re, re) then (im, .) for a complex product, (re, im) then (0, .) for
-            // the element-wise one -- so the exception costs two selects per bin 0, shared by the ears and sets, instead
-            // of a second product and four selects per ear and set (the selects measured 3 % of the kernel's time).
-            const c2 xa = c2{x.x, special ? x.y : x.x};
-            c2 xb;
-            xb.x = special ? 0.0f : x.y;
-            xb.y = xb.x;
-            sL = pfma_lo_rot(xb, heL, pfma_each(xa, heL, sL));
-            sR = pfma_lo_rot(xb, heR, pfma_each(xa, heR, sR));
-        } else {
-            const c2 xc = c2_of(x);
-            sL = pcmac(xc, heL, sL);
-            sR = pcmac(xc, heR, sR);
-        }
-    };
+    // Packed f32 throughout (jf_packed.h): this is multiply-accumulate work.
+    auto mac2 = [&](int q, float2 x, c2 heL, c2 heR, c2 &sL, c2 &sR) { mac_ears(q, special, x, heL, heR, sL, sR); };
     // The four bins in stages of JF_STAGE_LOADS row loads (16 B per lane each), two stages in flight: while one
     // stage's rows are weighted and multiplied, the next stage's loads are already under way -- the load latency is
     // paid once per call, not once per stage (the loads are L2 hits; it is their latency, not their bandwidth, that
@@ -972,9 +967,8 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
         for (int q = 0; q < QC; q++)
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                h[st & 1][q][t] = JF_EXP_ROW_LOAD(
-                    reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff), st, q,
-                    boff, t);
+                h[st & 1][q][t] =
+                    *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff);
     };
     load_stage(0);
     if (NS > 1) load_stage(1);
@@ -988,21 +982,9 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
 #pragma unroll
         for (int q = 0; q < QC; q++) {
             const float4(&hq)[NT] = h[st & 1][q];
-            c2 haL = pmul_s(c2{hq[0].x, hq[0].y}, a[0]), haR = pmul_s(c2{hq[0].z, hq[0].w}, a[0]);
-            c2 hbL = c2{0.f, 0.f}, hbR = c2{0.f, 0.f};
-            if (BOTH) {
-                hbL = pmul_s(c2{hq[0].x, hq[0].y}, b[0]);
-                hbR = pmul_s(c2{hq[0].z, hq[0].w}, b[0]);
-            }
-#pragma unroll
-            for (int t = 1; t < NT; t++) {
-                haL = pfma_s(c2{hq[t].x, hq[t].y}, a[t], haL);
-                haR = pfma_s(c2{hq[t].z, hq[t].w}, a[t], haR);
-                if (BOTH) {
-                    hbL = pfma_s(c2{hq[t].x, hq[t].y}, b[t], hbL);
-                    hbR = pfma_s(c2{hq[t].z, hq[t].w}, b[t], hbR);
-                }
-            }
+            c2 haL, haR, hbL = c2{0.f, 0.f}, hbR = c2{0.f, 0.f};
+            weighted_ears<NT>(hq, a, haL, haR);
+            if (BOTH) weighted_ears<NT>(hq, b, hbL, hbR);
             const int qq = QC * st + q;
             mac2(qq, xh[qq], haL, haR, sLa[qq], sRa[qq]);
             if (BOTH) mac2(qq, xh[qq], hbL, hbR, sLb[qq], sRb[qq]);
@@ -1021,6 +1003,35 @@ JF_DEV void filtered_half_nt(int nt, const float4 *__restrict__ htab, unsigned l
         filtered_half<2, BOTH>(htab, lofs, rows, wa, wb, fetch, special, sLa, sRa, sLb, sRb);
     else
         filtered_half<1, BOTH>(htab, lofs, rows, wa, wb, fetch, special, sLa, sRa, sLb, sRb);
+}
+
+// The same for sets that are PRE-INTERPOLATED rows (ItemDesc flags bit 2: a whole-degree position, whose weighted sum
+// table_interp_build_kernel has formed once and for all): one row per set, no weighting -- per bin one 16-byte load and
+// four packed FMAs per set instead of four loads and twelve packed instructions.  row_a feeds sLa / sRa; with BOTH row_b
+// feeds sLb / sRb (old and new set of a moving source: different rows).  All eight loads are in flight before fetch().
+template <bool BOTH, class X>
+JF_DEV void filtered_half_pre(const float4 *__restrict__ htab, unsigned lofs, int row_a, int row_b, X &&fetch, bool special,
+                              c2 (&sLa)[4], c2 (&sRa)[4], c2 (&sLb)[4], c2 (&sRb)[4]) {
+    unsigned boff = 16u * lofs;
+    asm("" : "+v"(boff));  // see filtered_half
+    const float4 *ha = htab + (size_t)__builtin_amdgcn_readfirstlane(row_a) * 512;
+    const float4 *hb = htab + (size_t)__builtin_amdgcn_readfirstlane(row_b) * 512;
+    float4 h[BOTH ? 2 : 1][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        h[0][q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ha + 64 * q) + boff);
+        if (BOTH) h[1][q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hb + 64 * q) + boff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float2 xh[4];
+    fetch(xh);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        mac_ears(q, special, xh[q], c2{h[0][q].x, h[0][q].y}, c2{h[0][q].z, h[0][q].w}, sLa[q], sRa[q]);
+        if (BOTH) mac_ears(q, special, xh[q], c2{h[1][q].x, h[1][q].y}, c2{h[1][q].z, h[1][q].w}, sLb[q], sRb[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // The per-ear sums of a unit -> Z[k] = Y_L + i Y_R and Z[N-k] = conj Y_L + i conj Y_R, the inverse transform's input
@@ -1045,6 +1056,9 @@ JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2
 #endif
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
+#endif
+#ifndef JF_PRE_TOUCH
+#define JF_PRE_TOUCH 0  // 1: the pre-interpolated rows of the next two half-filters are touched a source ahead (see there)
 #endif
 #ifndef JF_PAIR_OVERLAP
 #define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
@@ -1113,7 +1127,6 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
 #endif
     JF_EXP_STAMP_SETUP(P, pair, half, lane);
     JF_EXP_PHASE_SETUP();
-    JF_EXP_STAGGER(wave);
     float2 *base = s_pair + pair * kPairLds;
     float2 *buf = base + half * kPairWave;  // my FFT work space
     float2 *mail = buf + kPairWork;         // my two mailbox slots
@@ -1147,7 +1160,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     const int G = P.G, SG = P.S / G;
     const int n_units = P.K * SG;
     const int qb = 4 * half;
-    const bool special = JF_EXP_NO_SELECTS ? false : lane == 0 && half == 0;
+    const bool special = lane == 0 && half == 0;
     const unsigned lofs = 64u * qb + lane;
     const int n_own = (G - half + 1) / 2, n_his = (G - (half ^ 1) + 1) / 2;  // sources g = 2 j + half / + (half ^ 1)
     // Rounds of units over the persistent pairs.  Units differ in cost -- the first blocks of a call gather their windows
@@ -1195,9 +1208,15 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         for (int q = 0; q < 4; q++) sLo[q] = sRo[q] = sLn[q] = sRn[q] = c2{0.f, 0.f};
         // fetch(xh): see filtered_half.  A source with two filters (its sets do not share rows) fetches once.
         auto accumulate = [&](const ItemDesc *dp, auto &&fetch) {
-            JF_EXP_FILTER_SHORTCUT(fetch, sLn);
             const int nn = dp->n_new;
-            if (!any_xfade) {
+            if (dp->flags & 4) {
+                // both sets are pre-interpolated rows (whole-degree positions): one row each, no weights
+                if (!any_xfade)
+                    filtered_half_pre<false>(P.htab, lofs, dp->rows_new[0], dp->rows_new[0], fetch, special, sLn, sRn, sLn, sRn);
+                else
+                    filtered_half_pre<true>(P.htab, lofs, dp->rows_old[0], dp->rows_new[0], fetch, special, sLo, sRo, sLn,
+                                            sRn);
+            } else if (!any_xfade) {
                 filtered_half_nt<false>(nn, P.htab, lofs, dp->rows_new, dp->w_new, dp->w_new, fetch, special, sLn, sRn, sLn,
                                         sRn);
             } else if (dp->flags & 1) {
@@ -1262,6 +1281,30 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
             int count0, L;
             item_gather<NOUT>(P, b, src, opaque(lane), z, count0, L);
             JF_EXP_PHASE(0);  // own source: descriptor and signal records, window requests
+#if JF_PRE_TOUCH
+            // Pre-interpolated rows come from HBM (386 MB: no cache holds them), and a half-filter asks for them only when
+            // it needs them.  One lane per 128-byte line, this wave's half of the two rows of MY source (filtered a forward
+            // transform from now) and of the source the PARTNER is starting on (filtered a whole source from now) are
+            // touched here, behind the window requests: the filters then find them in the L2.  The loaded words are kept
+            // until the own filter's loads have returned (younger requests: no extra wait).
+            float touch_a = 0.0f, touch_b = 0.0f;
+            {
+                const int ln = opaque(lane);
+                const unsigned sub = (unsigned)qb * 1024u + (unsigned)(ln & 31) * 128u;
+                const char *tab = reinterpret_cast<const char *>(P.htab);
+                if (dp->flags & 4) {
+                    const unsigned row = ln < 32 ? (unsigned)dp->rows_old[0] : (unsigned)dp->rows_new[0];
+                    touch_a = *reinterpret_cast<const float *>(tab + ((size_t)row * 8192u + sub));
+                }
+                if (2 * j + (half ^ 1) < G) {
+                    const ItemDesc JF_CONST_AS *pd = as_const(db + ord[2 * j + (half ^ 1)]);
+                    if (pd->flags & 4) {
+                        const unsigned row = ln < 32 ? (unsigned)pd->rows_old[0] : (unsigned)pd->rows_new[0];
+                        touch_b = *reinterpret_cast<const float *>(tab + ((size_t)row * 8192u + sub));
+                    }
+                }
+            }
+#endif
 #if JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
 #endif
@@ -1279,7 +1322,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
                 // keep the compiler from merging the two sides into selects again or sinking the stores below the join.
                 // (Two copies of the half-filters behind the branch, each reading X D where it is, save the eight moves of
                 // the upper half too but spill: 16 B of scratch, slower.)
-                if (!JF_EXP_NO_SELECTS && half) {
+                if (half) {
                     asm volatile("; upper half keeps bins 4..7" ::: "memory");
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -1304,6 +1347,9 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
                 });
                 JF_EXP_PHASE(3);  // own source's two half-filters
             }
+#if JF_PRE_TOUCH
+            asm volatile("; touched rows" ::"v"(touch_a), "v"(touch_b));
+#endif
 #if !JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) {
                 take_partner_source(jp++);
@@ -1690,6 +1736,7 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
     int n = 0;
     const bool moved = old_azi != azi || old_ele != ele;  // GPUSoundSource.cu:331-335
     const bool corrected = (mode & 2) != 0;
+    bool pre = false;  // this lane's set is a pre-interpolated row
     if (mode & 1) {
         // *_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): the nearest table row, weight 1, no
         // distance factor (D = 1), no crossfade
@@ -1704,7 +1751,18 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         // ONE call for both lanes of a pair, each with its own position: as two calls under `old_half` the wave ran the
         // rule twice, once with the even and once with the odd lanes masked off
         const float e_in = old_half ? old_ele : ele, a_in = old_half ? old_azi : azi;
-        const int n_in = dev_interp_terms(rt, e_in, a_in, rows, w, corrected);
+        // A whole-degree position inside the pre-interpolated part of the table (jf_device.h: htab) is ONE row with weight 1:
+        // the row holds the weighted sum the rule below would ask for, formed by the same operations in the same order.
+        pre = canon && (mode & kModeInterpRows) != 0 && e_in >= (float)kInterpEleMin && e_in <= (float)kInterpEleMax &&
+              a_in >= 0.0f && a_in < (float)kInterpAzi && floorf(e_in) == e_in && floorf(a_in) == a_in;
+        int n_in;
+        if (pre) {
+            rows[0] = rows[1] = rows[2] = rows[3] = kNumHrtf + ((int)e_in - kInterpEleMin) * kInterpAzi + (int)a_in;
+            w[0] = 1.0f;
+            n_in = 1;
+        } else {
+            n_in = dev_interp_terms(rt, e_in, a_in, rows, w, corrected);
+        }
         const bool used = !old_half || moved;  // a source that did not move has no old set
         n = used ? n_in : 0;
 #pragma unroll
@@ -1715,6 +1773,7 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
     }
     // the other half's result (the even lane needs the old set for the pair-kernel layout)
     const int n_other = __shfl_xor(n, 1);
+    const bool pre_other = __shfl_xor((int)pre, 1) != 0;
     int orow[4];
     float ow[4];
 #pragma unroll
@@ -1761,6 +1820,9 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         // bit-identical to the sum over its own rows.
         const bool xf = moved && !(mode & 1) && n > 0;
         flags = xf ? 2 : 0;
+        // both sets are whole rows (a source that did not move carries its new set as its old set): the kernel's short path.
+        // One pre-interpolated set beside an ordinary one goes through the general path (a row with weight 1).
+        if (pre && n > 0 && (!xf || pre_other)) flags |= 4;
         int n_o = xf ? n_other : n;
         if (!xf) {
 #pragma unroll
@@ -1978,6 +2040,46 @@ __global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict
             make_float4(0.5f * Xe[0][q].x, 0.5f * Xe[0][q].y, 0.5f * Xe[1][q].x, 0.5f * Xe[1][q].y);
 }
 
+// The pre-interpolated rows (jf_device.h: htab): row 710 + (ele + 40) 360 + azi = sum_t w_t H[row_t] for the whole-degree
+// position (ele, azi) -- the index/weight rule itself (dev_interp_terms, SoundSource.cu:65-105) and the half-filters' own
+// weighting (weighted_ears), one wave per row.  What GPUSoundSource.cu:118-292 recomputes for every block and source
+// (four scaled products summed by atomicAdd) is computed here once per position the setters can latch.
+__global__ __launch_bounds__(64) void table_interp_build_kernel(const RingTable rt, int corrected, float4 *__restrict__ htab) {
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;  // 0 .. kInterpRows - 1
+    const int ei = r / kInterpAzi, azi = r - ei * kInterpAzi;
+    int rows[4] = {0, 0, 0, 0};
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = __builtin_amdgcn_readfirstlane(
+        dev_interp_terms(rt, (float)(ei + kInterpEleMin), (float)azi, rows, w, corrected != 0));
+    const float4 *hp[4];
+    c2 wv[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        hp[t] = htab + (size_t)__builtin_amdgcn_readfirstlane(rows[t]) * 512 + lane;
+        const float f = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[t])));
+        wv[t] = c2{f, f};
+    }
+    float4 *out = htab + (size_t)(kNumHrtf + r) * 512 + lane;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        c2 heL = c2{0.f, 0.f}, heR = c2{0.f, 0.f};  // n == 0 (no such position inside the table's range: tested): zeros
+        if (n == 4) {
+            const float4 hq[4] = {hp[0][64 * q], hp[1][64 * q], hp[2][64 * q], hp[3][64 * q]};
+            weighted_ears<4>(hq, wv, heL, heR);
+        } else if (n == 2) {
+            const float4 hq[2] = {hp[0][64 * q], hp[1][64 * q]};
+            const c2 w2[2] = {wv[0], wv[1]};
+            weighted_ears<2>(hq, w2, heL, heR);
+        } else if (n == 1) {
+            const float4 hq[1] = {hp[0][64 * q]};
+            const c2 w1[1] = {wv[0]};
+            weighted_ears<1>(hq, w1, heL, heR);
+        }
+        out[64 * q] = make_float4(heL.x, heL.y, heR.x, heR.y);
+    }
+}
+
 // parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
 __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict__ win,
                                                        const float2 *__restrict__ twg,
@@ -2066,6 +2168,10 @@ __global__ __launch_bounds__(64) void stage_debug_kernel(const RingTable rt, int
 }
 
 // ---------------------------------------------------------------- launchers --
+// 0 = product build; bit 0 = built with a switch that makes results wrong by design (jf_experiments.h): jf_engine_create
+// refuses such a library unless JF_ALLOW_EXPERIMENT=1
+int kernels_build_kind() { return JF_EXP_BUILD_KIND; }
+
 hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos, const float *d_win, int n,
                               const float4 *d_htab, const float2 *d_tw, float2 *d_dist, float2 *d_spec,
                               hipStream_t st) {
@@ -2077,6 +2183,11 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
                               hipStream_t st) {
     hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_interp_build(const RingTable &rt, int corrected, float4 *d_htab, hipStream_t st) {
+    hipLaunchKernelGGL(table_interp_build_kernel, dim3(kInterpRows), dim3(64), 0, st, rt, corrected, d_htab);
     return hipGetLastError();
 }
 

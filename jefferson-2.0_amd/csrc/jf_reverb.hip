@@ -14,7 +14,6 @@
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
-#include "jf_experiments.h"
 #include "jf_packed.h"
 
 namespace jf {
@@ -396,14 +395,14 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
     // window before the chunk's first partition: X(i - pa), i = 1..KB-1, kept at xr[(i - pa) mod KB] = xr[i]
 #pragma unroll
     for (int i = 1; i < KB; i++) {
-        xr[i] = JF_RV_EXP_X_LOAD(load_at(fdl0 + (size_t)slot_of(i - pa) * (B * 8)), i, lane);
+        xr[i] = load_at(fdl0 + (size_t)slot_of(i - pa) * (B * 8));
     }
     int xslot = slot_of(-pa);                     // slot of X(-p), p = pa
     const char *hp = hsp + (size_t)pa * (B * 8);  // H_p
     auto step = [&](int j) {  // j = p mod KB, a constant after unrolling
-        const rv_v2 h = JF_RV_EXP_H_LOAD(load_at(hp), xslot, lane);
+        const rv_v2 h = load_at(hp);
         // X(-p) replaces X(KB - p), last used by block KB-1 at p-1
-        xr[(KB - j) % KB] = JF_RV_EXP_X_LOAD(load_at(fdl0 + (size_t)(unsigned)xslot * (B * 8)), xslot, lane);
+        xr[(KB - j) % KB] = load_at(fdl0 + (size_t)(unsigned)xslot * (B * 8));
         xslot = xslot == 0 ? P.Rg - 1 : xslot - 1;
         hp += B * 8;
         // acc[i] += X(i - p) * h.  The four FMAs of a product as two sweeps over the blocks -- the real parts of X first,
@@ -455,7 +454,6 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
 #pragma unroll
     for (int i = 0; i < KB; i++) s_red[c][i][64 * bh + lane] = make_float2(acc[i].x, acc[i].y);
     __syncthreads();
-    JF_RV_EXP_FINISH_SHORTCUT(if (wave == 0) (mac_finish<B, NC, true>(&s_red[0][0][0], KB * B, s_fft[wave], P, s, k0, lane)));
 #pragma unroll 1
     for (int i = wave; i < KB; i += kTileWaves)
         if (k0 + i < P.K) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);

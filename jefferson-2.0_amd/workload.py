@@ -30,10 +30,13 @@ def source_signal_and_start(src, n_samples=FS):
     return sig, ele, azi, r
 
 
-def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0):
-    """Latched position records [n_blocks][len(src_ids)][5] for blocks first_block.."""
+def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0, ele_override=None):
+    """Latched position records [n_blocks][len(src_ids)][5] for blocks first_block..
+    ele_override: every source at this elevation (tuning runs: 360 distinct positions instead of 43 560)."""
     src_ids = np.asarray(src_ids)
     ele = np.array([-40 + (int(s) * 7) % 121 for s in src_ids], np.float32)
+    if ele_override is not None:
+        ele[:] = ele_override
     azi0 = np.array([(int(s) * 37) % 360 for s in src_ids], np.int64)
     r = np.array([source_signal_and_start(s, 1)[3] for s in src_ids], np.float32)
     b = np.arange(first_block, first_block + n_blocks, dtype=np.int64)[:, None]

@@ -582,7 +582,8 @@ def test_plain_c_boundary_checks(args):
 
 def test_pair_hand_off_time_out_is_reported_not_hung():
     """The batch kernel's waits between the two wavefronts of a pair are bounded.  With the fault-injection build of
-    the library (csrc/Makefile: libjefferson_hip_droppub.so = -DJF_EXP_DROP_PUBLISH, jf_experiments.h: one wavefront of
+    the library (`make -C jefferson-2.0_amd/csrc faultlib`: tests/build/libjefferson_hip_droppub.so = -DJF_EXP_DROP_PUBLISH,
+    not part of the product build and refused by jf_engine_create unless JF_ALLOW_EXPERIMENT=1; jf_experiments.h: one wavefront of
     the grid stops announcing its hand-offs) the partner's wait must run out, the kernel must drain, and the engine
     must say so: JF_ERR_DEVICE with the hand-off text from jf_synchronize, from a per-block call that takes the pair
     kernel, and from everything afterwards; destroying the engine works.  One run, in a child process of its own
@@ -590,8 +591,16 @@ def test_pair_hand_off_time_out_is_reported_not_hung():
     import subprocess
     import sys
     from conftest import ROOT
-    lib = os.path.join(ROOT, "jefferson-2.0_amd", "libjefferson_hip_droppub.so")
-    assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc builds it"
+    lib = os.path.join(ROOT, "tests", "build", "libjefferson_hip_droppub.so")
+    assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc faultlib builds it (__graft_entry__.build() does)"
+    # without the permission the library must refuse to make an engine at all
+    refuse = ('import os, sys\nsys.path.insert(0, os.environ["JF_ROOT"])\nfrom jf_load import jf\nimport numpy as np\n'
+              'try:\n    jf.Engine(256, 512, 1, hrir=np.zeros((710, 2, 128), np.float32))\n    print("CREATED")\n'
+              'except jf.JfError as ex:\n    print("REFUSED", ex.code, ex)\n')
+    env0 = {k: v for k, v in os.environ.items() if k != "JF_ALLOW_EXPERIMENT"}
+    r0 = subprocess.run([sys.executable, "-c", refuse], env=dict(env0, JF_ROOT=ROOT, JF_LIB=lib), stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=300)
+    assert r0.returncode == 0 and b"REFUSED -5" in r0.stdout and b"JF_ALLOW_EXPERIMENT" in r0.stdout, (r0.stdout, r0.stderr[-1000:])
     code = r'''
 import os, sys, time
 import numpy as np
@@ -644,7 +653,7 @@ print("PA", rc, float(np.abs(out).max()))
 e.close()
 print("CLOSED")
 '''
-    env = dict(os.environ, JF_ROOT=ROOT, JF_LIB=lib)
+    env = dict(os.environ, JF_ROOT=ROOT, JF_LIB=lib, JF_ALLOW_EXPERIMENT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     out = r.stdout.decode()
     assert r.returncode == 0, (out, r.stderr.decode(errors="replace")[-2000:])
