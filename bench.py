@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
+    ap.add_argument("--move-every", type=int, default=1,
+                    help="the sources' azimuth advances every n-th block (default 1 = configs[2]'s moving sources; 172 = the "
+                         "dwell of the reference's benchmarkTesting): variants, not the default bench line")
     ap.add_argument("--reverb", action="store_true",
                     help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
                          "(partitioned FDL convolution ahead of the spatialiser); not the default bench line")
@@ -284,6 +287,7 @@ def main():
                            "share the GPUs with the measurement)" if world > 1 else "not collected (--no-pmc / --pmc-child)")
     if world == 1 and not args.pmc_child and not args.no_pmc:
         extra = ((["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
+                 + (["--move-every", str(args.move_every)] if args.move_every != 1 else [])
                  + (["--realtime"] if args.realtime else [])
                  + (["--rv-sources", str(args.rv_sources), "--rv-ir-seconds", str(args.rv_ir_seconds)] if args.reverb else []))
         pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
@@ -338,11 +342,14 @@ def main():
     # The trajectories are periodic (azimuth + 1 degree per block: 360 blocks), so a long run walks one
     # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
     # costs the same 20 B x sources x lcm(360, blocks per step) of host and device memory.
-    n_pos = int(np.lcm(360, KB))
+    n_pos = int(np.lcm(360 * args.move_every, KB))
+    if n_pos > 360 * 128:  # (--move-every with a long period: one pass through a shorter stretch, walked cyclically: the seam
+        n_pos = KB * max(1, (360 * 128) // KB)   # is one more move)
     # tuning runs only (profiles/r04_interp_ab.sh): every source at elevation 5 -- 360 distinct positions, mostly four-row interpolations, whose
     # pre-interpolated rows (2.9 MB) stay in the caches; the line then says so in config.workload
     narrow = os.environ.get("JF_BENCH_NARROW") is not None
-    pos = wl.trajectories(jf, src_ids, n_pos, moving=not args.stationary, ele_override=5 if narrow else None)
+    pos = wl.trajectories(jf, src_ids, n_pos, moving=not args.stationary, ele_override=5 if narrow else None,
+                          move_every=args.move_every)
     eng.upload_positions(pos)
 
     if args.pmc_child:  # a few launches for the counters, no torch, no timing
@@ -450,9 +457,10 @@ def main():
         first_step = prewarm + W
         # the run walks the uploaded period cyclically: price each step of the period once (its predecessor block is
         # the one before it on the circle) and count how often each was timed
-        abytes, rows, items = wl.algorithmic_bytes_cyclic(jf, pos, KB, B, first_step, K)
+        pre_rows = bool(eng.last_run_used_rows())   # the timed runs read pre-interpolated rows (include/jefferson.h)
+        abytes, rows, items = wl.algorithmic_bytes_cyclic(jf, pos, KB, B, first_step, K, pre_rows=pre_rows)
         pair = any("pair" in k for k in kernels)
-        flops_ex, flops_ref = wl.flops_cyclic(jf, pos, KB, B, G, first_step, K, old_sets_spectral=pair)
+        flops_ex, flops_ref = wl.flops_cyclic(jf, pos, KB, B, G, first_step, K, old_sets_spectral=pair, pre_rows=pre_rows)
         tf = flops_ex / fused_s / 1e12 if fused_s > 0 else 0.0
         fused_name = next((k for k in kernels if k.startswith("fused_")), kernels[-1])
         # "fused_pair_kernel<4>+prep": the launch's trailing workgroups prepare the next window's descriptors (same kernel
@@ -530,8 +538,10 @@ def main():
             "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
                                    "N=1024 overlap-save, KEMAR 710x2 table"
                                    + (" (stationary variant)" if args.stationary else "")
+                                   + (f" (VARIANT: the sources move every {args.move_every}-th block)" if args.move_every != 1 else "")
                                    + (" (TUNING VARIANT: every source at elevation 5)" if narrow else ""),
-                       "interp_table": bool(eng.interp_table()),
+                       "interp_table": {"setting": ["off", "always", "per run"][eng.interp_table()],
+                                        "rows_read_by_the_timed_runs": eng.last_run_used_rows()},
                        "sources_per_gpu": S, "block": B, "blocks_per_step": KB, "source_group": G,
                        "source_order": "by table row of the first position" if not np.array_equal(order, np.arange(S))
                        else "as given",
@@ -623,7 +633,7 @@ def main():
                 # the block index: absolute indices work as they are)
                 first = i_last * KB + KB - nb
                 all_pos = wl.trajectories(jf, all_ids, nb, moving=not args.stationary, first_block=first,
-                                          ele_override=5 if narrow else None)
+                                          ele_override=5 if narrow else None, move_every=args.move_every)
                 all_n = None
             base, ok, check = cpu_baseline_and_check(jf, wl, hrir, all_ids, all_pos, all_n, i_last * KB, KB, nb,
                                                      last_mix, groups, G, order,

@@ -65,8 +65,9 @@ typedef struct jf_engine jf_engine;
  * sum_t w_t H[row_t] of each of those positions (386 MB of HBM, built once at creation by the same operations in the same
  * order as the per-block weighting: results are bit-identical) and batch calls read ONE row per filter set instead of up
  * to four rows and their weights (what GPUSoundSource.cu:118-292 recomputes for every block).  Positions that are not
- * whole degrees inside -40..90 x 0..359 keep the per-block weighting.  JF_FLAG_NO_INTERP_TABLE: do not build it
- * (the environment variable JF_INTERP_TABLE=0 does the same for every engine of a process).
+ * whole degrees inside -40..90 x 0..359 keep the per-block weighting, and so do runs in which most sources move every
+ * block (jf_debug_set_interp_table).  JF_FLAG_NO_INTERP_TABLE: do not build it (the environment variable
+ * JF_INTERP_TABLE=0 does the same for every engine of a process).
  */
 #define JF_FLAG_NO_INTERP_TABLE 2u
 
@@ -313,10 +314,21 @@ int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
-/* Whether batch calls use the pre-interpolated rows (JF_FLAG_NO_INTERP_TABLE above; default on when they were built).
- * on = 1 for an engine that did not build them: JF_ERR_STATE.  Results are bit-identical either way. */
+/* Which batch calls use the pre-interpolated rows (JF_FLAG_NO_INTERP_TABLE above): 0 = none, 1 = all, 2 = decided per run
+ * (the default when the rows were built): a run of an uploaded trajectory takes them unless more than 30 % of its items
+ * move -- a source that stays reads its row out of the caches (12-18 % faster), one that moves streams 8 KB per block from
+ * HBM, and a run in which every source moves every block is 2-5 % slower with the rows than with the weighting of the
+ * cached measured rows; measured crossover: a third of the items moving --; calls without a trajectory take them.
+ * on != 0 for an engine that did not build them: JF_ERR_STATE.  Results are bit-identical whatever the choice
+ * (JF_INTERP_TABLE=0/1/2 in the environment sets it for every engine of a process). */
 int jf_debug_set_interp_table(jf_engine *e, int on);
-/* 1 if the engine holds the pre-interpolated rows and uses them, 0 if not. */
+/* 1 if the last batch run's descriptors could name pre-interpolated rows (the kernel instantiation that reads them ran). */
+int jf_debug_last_run_used_rows(const jf_engine *e);
+/* Of 16 sources that MOVE in a block, how many read pre-interpolated rows (0..16; sources that do not move always do).
+ * A moving source's rows stream from HBM while the measured rows stay in the caches but cost the weighting: the share
+ * balances memory bandwidth against vector instructions.  Results are bit-identical whatever it is. */
+int jf_debug_set_interp_share(jf_engine *e, int sixteenths);
+/* The setting above (0, 1 or 2); 0 for an engine without the rows. */
 int jf_debug_interp_table(const jf_engine *e);
 /* How many of the first n_items descriptors of the last batch run (items b * n_sources + s) carry any bit of `mask` in
  * their flags (pair-kernel layout: 1 = both sets on one row list, 2 = crossfade, 4 = both sets are pre-interpolated

@@ -96,6 +96,8 @@ _SIGS = {
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
+    "jf_debug_set_interp_share": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
     "jf_debug_count_desc_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jf_debug_read_table_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f]),
     "jf_debug_interp_device": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _i, _f, _i]),
@@ -383,10 +385,18 @@ class Engine:
         return t.view(np.complex64)[..., 0]
 
     def set_interp_table(self, on):
-        self._chk(lib().jf_debug_set_interp_table(self.h, int(bool(on))))
+        """0 / False = never, 1 / True = always, 2 = decided per run (default)"""
+        self._chk(lib().jf_debug_set_interp_table(self.h, int(on)))
+
+    def last_run_used_rows(self):
+        return bool(lib().jf_debug_last_run_used_rows(self.h))
+
+    def set_interp_share(self, sixteenths):
+        self._chk(lib().jf_debug_set_interp_share(self.h, int(sixteenths)))
 
     def interp_table(self):
-        return bool(lib().jf_debug_interp_table(self.h))
+        """0 = off / not built, 1 = always, 2 = decided per run"""
+        return lib().jf_debug_interp_table(self.h)
 
     def count_desc_flags(self, n_items, mask):
         n = lib().jf_debug_count_desc_flags(self.h, int(n_items), int(mask))

@@ -55,6 +55,7 @@ struct EventPair {
 };
 }  // namespace
 
+constexpr double kInterpMovedMax = 0.30;  // jf_engine::interp_use == 2: largest share of moving items a run may have to take the rows
 constexpr int kRtMaxWgs = 128;  // workgroups (16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
 
 struct jf_engine {
@@ -65,7 +66,16 @@ struct jf_engine {
 
     float4 *d_htab = nullptr;
     bool interp_built = false;  // d_htab also holds the kInterpRows pre-interpolated rows (jf_device.h)
-    bool interp_use = false;    // ... and batch calls use them (jf_debug_set_interp_table)
+    // ... and which batch calls use them (jf_debug_set_interp_table): 0 none, 1 all, 2 (default) decided per run.  A source
+    // that stays where it is reads its one row out of the caches block after block (12-18 % faster than weighting four
+    // measured rows); a source that moves streams a new 8 KB row from HBM, and when every source moves every block the
+    // kernel is bound by that stream (5.8 TB/s) and 2-5 % SLOWER than the weighting.  Measured crossover: a third of the
+    // items moving (profiles/r04/interp_table.md).  Runs of an uploaded trajectory take the rows unless more than
+    // kInterpMovedMax of their items move; calls without a trajectory take them.
+    int interp_use = 0;
+    int interp_share = 16;      // of 16 moving sources, how many read them (jf_debug_set_interp_share; tuning)
+    std::vector<unsigned> traj_moved;  // [traj_blocks + 1] prefix counts of the uploaded trajectory's items that move
+    bool last_rows = false;     // the last batch run's descriptors could name pre-interpolated rows
     float2 *d_tw = nullptr;
     float2 *d_twpack = nullptr;
     SrcSignal *d_sigs = nullptr;
@@ -275,7 +285,13 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     P.G = (e->S % G == 0) ? G : 1;
     const int canon = P.G > 1;  // descriptors in the pair-kernel layout
     // whole-degree positions as pre-interpolated rows: the pair kernel's descriptors only
-    const int mode_now = kernel_mode(e) | ((canon && e->interp_built && e->interp_use) ? kModeInterpRows : 0);
+    bool rows = canon && e->interp_built && e->interp_use != 0;
+    if (rows && e->interp_use == 2 && first_block >= 0 && (size_t)(first_block + K) < e->traj_moved.size()) {
+        const double moved = (double)(e->traj_moved[first_block + K] - e->traj_moved[first_block]) / (double)n_items;
+        rows = moved <= kInterpMovedMax;
+    }
+    e->last_rows = rows;
+    const int mode_now = kernel_mode(e) | (rows ? (kModeInterpRows | (e->interp_share << kModeShareShift)) : 0);
     // per-kernel timing (profiling >= 2) keeps prep and mix as launches of their own
     const bool have = e->ahead.valid && e->profiling < 2 && first_block >= 0 && e->ahead.first == first_block &&
                       e->ahead.K == K && e->ahead.mode == mode_now && e->ahead.canon == canon &&
@@ -477,7 +493,10 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         {
             const char *env = getenv("JF_INTERP_TABLE");
             e->interp_built = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
-            e->interp_use = e->interp_built;
+            e->interp_use = e->interp_built ? 2 : 0;
+            if (env && e->interp_built && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
+            const char *sh = getenv("JF_INTERP_SHARE");  // tuning runs
+            if (sh && atoi(sh) >= 0 && atoi(sh) <= 16) e->interp_share = atoi(sh);
         }
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + (e->interp_built ? kInterpRows : 0)) * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
@@ -1002,6 +1021,16 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     }
     e->traj_blocks = total_blocks;
     JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
+    // how many items of every block move (their (ele, azi) differ from the block before; block 0 counts as staying):
+    // what decides whether a run reads pre-interpolated rows (jf_engine::interp_use)
+    e->traj_moved.assign((size_t)total_blocks + 1, 0u);
+    if (e->interp_built)
+        for (int b = 1; b < total_blocks; b++) {
+            const float *p1 = positions + (size_t)b * e->S * 5, *p0 = p1 - (size_t)e->S * 5;
+            unsigned n = 0;
+            for (int s = 0; s < e->S; s++) n += p1[5 * s] != p0[5 * s] || p1[5 * s + 1] != p0[5 * s + 1];
+            e->traj_moved[(size_t)b + 1] = e->traj_moved[b] + n;
+        }
     // Processing order of the pair kernel: a unit sums G sources that are next to each other in this order.  With
     // automatic grouping the sources are ordered by the table row nearest to their first position, so that the units a
     // compute unit works on at a time read neighbouring rows of the 5.8 MB table (the L2 of an XCD holds 4 MB); the mix is
@@ -1168,13 +1197,23 @@ int jf_debug_set_reverb_form(jf_engine *e, int form) {
 int jf_debug_set_interp_table(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
+    if (on < 0 || on > 2) return fail(e, JF_ERR_ARG, "0 = never, 1 = always, 2 = decided per run");
     if (on && !e->interp_built) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
-    e->interp_use = on != 0;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
+    e->interp_use = on;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
     return JF_OK;
     });
 }
 
-int jf_debug_interp_table(const jf_engine *e) { return e && e->interp_built && e->interp_use ? 1 : 0; }
+int jf_debug_set_interp_share(jf_engine *e, int sixteenths) {
+    return jf_guard([&]() -> int {
+    if (!e || sixteenths < 0 || sixteenths > 16) return JF_ERR_ARG;
+    e->interp_share = sixteenths;
+    return JF_OK;
+    });
+}
+
+int jf_debug_interp_table(const jf_engine *e) { return e && e->interp_built ? e->interp_use : 0; }
+int jf_debug_last_run_used_rows(const jf_engine *e) { return e && e->last_rows ? 1 : 0; }
 
 int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask) {
     return jf_guard([&]() -> int {

@@ -1068,7 +1068,10 @@ JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2
 JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ pos, const SrcState *__restrict__ st,
                       ItemDesc *__restrict__ desc, int S, int K, int canon, int tid, ItemDesc *stage);
 
-template <int NOUT>
+// ROWS: the instantiation for launches whose descriptors may carry pre-interpolated rows (ItemDesc flags bit 2); the other
+// one does not contain that path at all (its presence alone costs the per-block weighting path registers and ~4 % more
+// instructions per source-block: profiles/r04/interp_table.md).
+template <int NOUT, bool ROWS>
 __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_pair[kPairsPerWg * kPairLds];
@@ -1209,7 +1212,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         // fetch(xh): see filtered_half.  A source with two filters (its sets do not share rows) fetches once.
         auto accumulate = [&](const ItemDesc *dp, auto &&fetch) {
             const int nn = dp->n_new;
-            if (dp->flags & 4) {
+            if (ROWS && (dp->flags & 4)) {
                 // both sets are pre-interpolated rows (whole-degree positions): one row each, no weights
                 if (!any_xfade)
                     filtered_half_pre<false>(P.htab, lofs, dp->rows_new[0], dp->rows_new[0], fetch, special, sLn, sRn, sLn, sRn);
@@ -1753,8 +1756,12 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         const float e_in = old_half ? old_ele : ele, a_in = old_half ? old_azi : azi;
         // A whole-degree position inside the pre-interpolated part of the table (jf_device.h: htab) is ONE row with weight 1:
         // the row holds the weighted sum the rule below would ask for, formed by the same operations in the same order.
-        pre = canon && (mode & kModeInterpRows) != 0 && e_in >= (float)kInterpEleMin && e_in <= (float)kInterpEleMax &&
-              a_in >= 0.0f && a_in < (float)kInterpAzi && floorf(e_in) == e_in && floorf(a_in) == a_in;
+        // Of the sources that move in this block only a share takes the rows (jf_device.h: kModeShareShift), chosen by
+        // source index so that all blocks of a source agree (block b's new row is block b + 1's old row).
+        const bool share_ok = !moved || ((s * 11) & 15) < ((mode >> kModeShareShift) & kModeShareMask);
+        pre = canon && (mode & kModeInterpRows) != 0 && share_ok && e_in >= (float)kInterpEleMin &&
+              e_in <= (float)kInterpEleMax && a_in >= 0.0f && a_in < (float)kInterpAzi && floorf(e_in) == e_in &&
+              floorf(a_in) == a_in;
         int n_in;
         if (pre) {
             rows[0] = rows[1] = rows[2] = rows[3] = kNumHrtf + ((int)e_in - kInterpEleMin) * kInterpAzi + (int)a_in;
@@ -2224,10 +2231,10 @@ hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source kernel, 1 
     const int threads = 64 * kWavesPerWg;
     if (kind == 1) {
         switch (nb) {
-        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1>, threads, 0); break;
-        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2>, threads, 0); break;
-        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<3>, threads, 0); break;
-        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<4>, threads, 0); break;
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1, false>, threads, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2, false>, threads, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<3, false>, threads, 0); break;
+        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<4, false>, threads, 0); break;
         default: return hipErrorInvalidValue;
         }
     } else {
@@ -2265,11 +2272,20 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
         // + the workgroups that prepare the following window's descriptors (two lanes per item)
         const int n_prep = Q.prep_pos != nullptr ? (2 * Q.S * Q.prep_K + 64 * kWavesPerWg - 1) / (64 * kWavesPerWg) : 0;
         const dim3 grid(wgs + n_prep);
+        const bool rows = (P.mode & kModeInterpRows) != 0;  // descriptors may name pre-interpolated rows
         switch (P.B / 64) {
-        case 1: hipLaunchKernelGGL(fused_pair_kernel<1>, grid, block, 0, st, Q); break;
-        case 2: hipLaunchKernelGGL(fused_pair_kernel<2>, grid, block, 0, st, Q); break;
-        case 3: hipLaunchKernelGGL(fused_pair_kernel<3>, grid, block, 0, st, Q); break;
-        case 4: hipLaunchKernelGGL(fused_pair_kernel<4>, grid, block, 0, st, Q); break;
+        case 1: if (rows) hipLaunchKernelGGL((fused_pair_kernel<1, true>), grid, block, 0, st, Q);
+                else hipLaunchKernelGGL((fused_pair_kernel<1, false>), grid, block, 0, st, Q);
+                break;
+        case 2: if (rows) hipLaunchKernelGGL((fused_pair_kernel<2, true>), grid, block, 0, st, Q);
+                else hipLaunchKernelGGL((fused_pair_kernel<2, false>), grid, block, 0, st, Q);
+                break;
+        case 3: if (rows) hipLaunchKernelGGL((fused_pair_kernel<3, true>), grid, block, 0, st, Q);
+                else hipLaunchKernelGGL((fused_pair_kernel<3, false>), grid, block, 0, st, Q);
+                break;
+        case 4: if (rows) hipLaunchKernelGGL((fused_pair_kernel<4, true>), grid, block, 0, st, Q);
+                else hipLaunchKernelGGL((fused_pair_kernel<4, false>), grid, block, 0, st, Q);
+                break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

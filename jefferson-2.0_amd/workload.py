@@ -30,9 +30,11 @@ def source_signal_and_start(src, n_samples=FS):
     return sig, ele, azi, r
 
 
-def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0, ele_override=None):
+def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0, ele_override=None, move_every=1):
     """Latched position records [n_blocks][len(src_ids)][5] for blocks first_block..
-    ele_override: every source at this elevation (tuning runs: 360 distinct positions instead of 43 560)."""
+    ele_override: every source at this elevation (tuning runs: 360 distinct positions instead of 43 560).
+    move_every: the azimuth advances by one degree every move_every-th block (1: SURVEY.md 8d's "moving";
+    172: the dwell of the reference's own benchmarkTesting, precision_test.cu:2093-2152)."""
     src_ids = np.asarray(src_ids)
     ele = np.array([-40 + (int(s) * 7) % 121 for s in src_ids], np.float32)
     if ele_override is not None:
@@ -40,7 +42,7 @@ def trajectories(jf, src_ids, n_blocks, moving=True, first_block=0, ele_override
     azi0 = np.array([(int(s) * 37) % 360 for s in src_ids], np.int64)
     r = np.array([source_signal_and_start(s, 1)[3] for s in src_ids], np.float32)
     b = np.arange(first_block, first_block + n_blocks, dtype=np.int64)[:, None]
-    azi = (azi0[None, :] + (b if moving else 0 * b)) % 360
+    azi = (azi0[None, :] + (b // move_every if moving else 0 * b)) % 360
     ele2 = np.broadcast_to(ele[None, :], azi.shape)
     r2 = np.broadcast_to(r[None, :], azi.shape)
     return jf.positions_from_spherical(ele2, azi.astype(np.float32), r2)
@@ -62,10 +64,11 @@ def n_terms_table(jf):
     return t
 
 
-def algorithmic_bytes(jf, pos, B, first_old=None, terms=None):
+def algorithmic_bytes(jf, pos, B, first_old=None, terms=None, pre_rows=False):
     """Algorithmic bytes of a [K][S][5] trajectory window, SURVEY.md 8(d): per source-block
     (rows_old + rows_new) * 8208 B of table + 4096 B window + 2*B*4 B stereo block out.
-    first_old: (ele, azi) [S][2] latched before the window (None -> (0, 0), a fresh engine)."""
+    first_old: (ele, azi) [S][2] latched before the window (None -> (0, 0), a fresh engine).
+    pre_rows: every filter set is one pre-interpolated row (8 KiB; whole-degree positions, include/jefferson.h)."""
     if terms is None:
         terms = n_terms_table(jf)
     ele = pos[..., 0].astype(np.int64)
@@ -79,12 +82,14 @@ def algorithmic_bytes(jf, pos, B, first_old=None, terms=None):
     n_new = terms[ele + 49, azi]
     moved = (prev_e != ele) | (prev_a != azi)
     n_old = np.where(moved, terms[prev_e + 49, prev_a], 0)
+    if pre_rows:
+        n_new, n_old = np.ones_like(n_new), moved.astype(n_new.dtype)
     rows = int(n_new.sum() + n_old.sum())
     items = K * S
     return rows * TABLE_ROW_BYTES + items * (WINDOW_BYTES + 2 * B * 4), rows, items
 
 
-def algorithmic_bytes_cyclic(jf, pos, blocks_per_step, B, first_step, n_steps, terms=None):
+def algorithmic_bytes_cyclic(jf, pos, blocks_per_step, B, first_step, n_steps, terms=None, pre_rows=False):
     """The same for a run that walks one uploaded period of positions [n_pos][S][5] again and again, one step =
     blocks_per_step consecutive blocks (bench.py): every step of the period is priced once -- the block before
     its first one is the one before it on the circle -- and counted as often as steps first_step ..
@@ -97,7 +102,7 @@ def algorithmic_bytes_cyclic(jf, pos, blocks_per_step, B, first_step, n_steps, t
     for j in range(n_pos // blocks_per_step):
         first_old = pos[(j * blocks_per_step - 1) % n_pos, :, :2].astype(np.int64)
         per_step.append(algorithmic_bytes(jf, pos[j * blocks_per_step:(j + 1) * blocks_per_step], B,
-                                          first_old=first_old, terms=terms))
+                                          first_old=first_old, terms=terms, pre_rows=pre_rows))
     tot = [0, 0, 0]
     for i in range(first_step, first_step + n_steps):
         for c, v in enumerate(per_step[i % len(per_step)]):
@@ -130,7 +135,7 @@ def flops_ifft_pruned(B):
     return FLOPS_IFFT_PRUNED + B * 24
 
 
-def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=True):
+def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=True, pre_rows=False):
     """Floating-point operations of one launch over the trajectory window pos [K][S][5].
 
     Returns (executed, reference): `executed` is what the shipped kernels have to do -- per source-block one
@@ -139,7 +144,9 @@ def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=Tr
     old sets (G = 1: one or two inverses per source-block; old_sets_spectral=False: one inverse per crossfading
     unit's SOURCE for the old sets, the form of the round-1 group kernel), the crossfade and the G-fold sum -- and `reference`
     is the reference's own algorithm (GPUSoundSource.cu:320-385): an unpruned inverse pair per set and source.
-    Silent items (position not interpolable) are counted like the others; the synthetic workloads have none."""
+    Silent items (position not interpolable) are counted like the others; the synthetic workloads have none.
+    pre_rows: the executed filters read pre-interpolated rows (no weighting: 12 flops per bin and set); `reference` is
+    unchanged -- the reference weights four rows per set and block."""
     if terms is None:
         terms = n_terms_table(jf)
     ele = pos[..., 0].astype(np.int64)
@@ -156,6 +163,7 @@ def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=Tr
     items = K * S
     front = items * (FLOPS_RFFT + FLOPS_DISTANCE)
     filt = int((NC * (8 * n_new + 12)).sum() + (NC * (8 * n_old + 12) * moved).sum())
+    filt_ex = int(items * NC * 12 + moved.sum() * NC * 12) if pre_rows else filt
     units_x = int(moved.reshape(K, S // G, G).any(axis=2).sum())     # units with a crossfade
     units = K * (S // G)
     old_inv = units_x if (old_sets_spectral or G == 1) else units_x * G
@@ -163,13 +171,13 @@ def flops_window(jf, pos, B, G, first_old=None, terms=None, old_sets_spectral=Tr
     xfade = units_x * B * FLOPS_XFADE_PER_FRAME
     gsum = items * NC * 4 * (1 + moved.mean()) if G > 1 else 0          # spectral sums over the unit's sources
     mix = units * 2 * B                                                 # mix_kernel: one add per float of a block
-    executed = front + filt + inv + xfade + int(gsum) + mix
+    executed = front + filt_ex + inv + xfade + int(gsum) + mix
     reference = (front + filt + int((1 + moved).sum()) * FLOPS_IFFT_FULL + int(moved.sum()) * B * FLOPS_XFADE_PER_FRAME
                  + items * 2 * B)
     return executed, reference
 
 
-def flops_cyclic(jf, pos, blocks_per_step, B, G, first_step, n_steps, terms=None, old_sets_spectral=True):
+def flops_cyclic(jf, pos, blocks_per_step, B, G, first_step, n_steps, terms=None, old_sets_spectral=True, pre_rows=False):
     """flops_window over a cyclically walked period of positions (see algorithmic_bytes_cyclic)."""
     if terms is None:
         terms = n_terms_table(jf)
@@ -179,7 +187,8 @@ def flops_cyclic(jf, pos, blocks_per_step, B, G, first_step, n_steps, terms=None
     for j in range(n_pos // blocks_per_step):
         first_old = pos[(j * blocks_per_step - 1) % n_pos, :, :2].astype(np.int64)
         per_step.append(flops_window(jf, pos[j * blocks_per_step:(j + 1) * blocks_per_step], B, G,
-                                     first_old=first_old, terms=terms, old_sets_spectral=old_sets_spectral))
+                                     first_old=first_old, terms=terms, old_sets_spectral=old_sets_spectral,
+                                     pre_rows=pre_rows))
     ex = ref = 0
     for i in range(first_step, first_step + n_steps):
         e, r = per_step[i % len(per_step)]

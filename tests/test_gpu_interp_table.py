@@ -39,9 +39,9 @@ def test_every_whole_degree_position_bit_identical_to_the_per_block_weighting(jf
     out = []
     for on in (True, False):
         e, _ = _engine(jf, hrir, S, K)
-        assert e.interp_table()
-        e.set_interp_table(on)
-        assert e.interp_table() == on
+        assert e.interp_table() == 2        # default: decided per run
+        e.set_interp_table(on)              # here: always / never
+        assert e.interp_table() == int(on)
         e.upload_positions(pos)
         e.batch_run(0, K)
         e.synchronize()
@@ -162,3 +162,39 @@ def test_other_rules_and_modes(jf, hrir, what):
         _, part = ora.process_batch(pos, want_partial=True)
         want = part.astype(np.float64).reshape(S // 4, 4, K, 2 * B).sum(axis=1).transpose(1, 0, 2)
         assert np.abs(outs[0] - want).max() <= TOL32 * 4 * max(1.0, np.abs(want).max())
+
+
+def test_the_rows_are_taken_per_run_by_how_many_items_move(jf, hrir):
+    """The default setting decides per run of an uploaded trajectory: sources that stay read one cached row per block,
+    sources that move every block would stream a new row from HBM per block, which is not faster than the weighting
+    (profiles/r04/interp_table.md) -- so a window takes the rows unless more than 30 % of its items move (the measured crossover is a third).
+    Whatever is chosen, the blocks are the same bit for bit as with the rows always or never."""
+    S, K, B = 16, 16, 128
+    ids = np.arange(S)
+    ele = (-40 + (ids * 9) % 131).astype(np.float32)
+
+    def traj(move_every):
+        b = np.arange(4 * K, dtype=np.int64)[:, None]
+        azi = ((ids * 23)[None, :] + b // move_every) % 360
+        return jf.positions_from_spherical(np.broadcast_to(ele, azi.shape), azi.astype(np.float32),
+                                           np.broadcast_to(np.float32(0.9), azi.shape))
+    for move_every, expect in ((1, False), (2, False), (4, True), (172, True)):
+        pos = traj(move_every)
+        outs = {}
+        for setting in (2, 1, 0):
+            e, _ = _engine(jf, hrir, S, K, B=B, group=4)
+            e.set_interp_table(setting)
+            e.upload_positions(pos)
+            blocks = []
+            for w in range(4):
+                e.batch_run(w * K, K)
+                e.synchronize()
+                if setting == 2:
+                    assert e.last_run_used_rows() == expect, (move_every, w)
+                else:
+                    assert e.last_run_used_rows() == bool(setting)
+                blocks.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
+            outs[setting] = np.concatenate(blocks)
+            e.close()
+        assert np.abs(outs[2]).max() > 0.01
+        assert np.array_equal(outs[2], outs[1]) and np.array_equal(outs[2], outs[0])
