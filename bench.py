@@ -162,7 +162,7 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
 # ------------------------------------------------------------------------------- PMC passes --
 PMC_PASSES = (("FETCH_SIZE",),
               ("WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
-               "GRBM_GUI_ACTIVE"))
+               "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_FLOPS_FP32"))
 
 
 def collect_pmc(extra_args, want_kernels):
@@ -400,13 +400,17 @@ def main():
     for i in range(W):
         step(prewarm + i)
     fence()
+    stride = args.event_stride
     if not os.environ.get("JF_NO_EVENTS"):  # tuning runs: how much do the event records cost?
         eng.profile_enable(2 if ir is not None else 1)  # level 1: two events around the fused kernel
         # A pair of event records costs ~7 us of stream time -- 2.7 % of a 0.25 ms step (1.30e11 against 1.33e11 with
         # JF_NO_EVENTS=1, profiles/r03_experiments.md): the fused launch is timed at every EVENT_STRIDE-th step of the timed
         # region, and its average is over those launches ("launches_timed").  With the reverb every kernel of such a step
         # is timed (eight records).
-        eng.profile_set_stride(args.event_stride)
+        # (a short run -- the driver's --steps 20 -- would rest on two or three timed launches: below eight of them every
+        # launch is timed instead, and the 7 us per record pair are in ms_per_step)
+        stride = args.event_stride if K >= 8 * args.event_stride else 1
+        eng.profile_set_stride(stride)
     t0 = time.perf_counter()
     for i in range(prewarm + W, prewarm + W + K):
         step(i)
@@ -441,6 +445,32 @@ def main():
                  "mix_kernel_us": p2["mix_ms"] / max(p2["launches"], 1) * 1e3,
                  "source": "HIP events on the engine stream, 16 untimed steps after the timed region"}
 
+    # SURVEY.md 8(d) config 4 asks for the communication fraction.  In the timed region the collective of step i overlaps
+    # step i + 1's kernels, so it is measured on its own afterwards: 16 more steps in which the engine's stream waits for the
+    # step's own collective, HIP events on that stream -- the first when the step's kernels are done, the second when the
+    # reduced mix is there.
+    comm_ms = None
+    if use_dist:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+        base_i = prewarm + W + K + (16 if ir is None else 0)
+        for n, (e0, e1) in enumerate(evs):
+            i = base_i + n
+            j = i & 1
+            eng.batch_run((i * KB) % n_pos, KB, mixes[j].data_ptr())
+            with torch.cuda.stream(ext):
+                e0.record(ext)
+                if backend == "nccl":
+                    wk = dist.reduce(mixes[j], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                else:
+                    wk = dist.all_reduce(mixes[j], op=dist.ReduceOp.SUM, async_op=True)
+                wk.wait()
+                e1.record(ext)
+        fence()
+        comm_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        t = torch.tensor([comm_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_ms = float(t.item())
+
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -472,18 +502,14 @@ def main():
                 "avg_launch_ms": prof["fused_ms"] / timed,
                 "launches_timed": timed,
                 "launch_timing": ("HIP events on the engine's stream around every %d-th fused launch of the timed region (%d of %d"
-                                  " launches; a pair of event records costs ~7 us of stream time)" % (args.event_stride, timed, K)
+                                  " launches; a pair of event records costs ~7 us of stream time)" % (stride, timed, K)
                                   if ir is None else
                                   "HIP events around every kernel of every %d-th step of the timed region (%d of %d steps)"
-                                  % (args.event_stride, timed, K)),
+                                  % (stride, timed, K)),
                 "launch_includes": ("the next window's descriptors (index/weight rule for 131 072 items in trailing "
                                     "workgroups, ~2.5 us of the launch, ~20 of the VALU instructions per source-block)"
                                     if fused_has_prep else None),
                 "flops_per_launch_executed": flops_ex / launches,
-                "flops_per_launch_reference_algorithm": flops_ref / launches,
-                # the same output priced with the reference's own algorithm (an unpruned inverse pair per filter set and
-                # source, GPUSoundSource.cu:320-385): comparable across kernels that skip different amounts of that work
-                "frac_reference_algorithm": (flops_ref / fused_s / 1e12 / FP32_VECTOR_PEAK_TF) if fused_s > 0 else 0.0,
                 "flop_model": "jefferson-2.0_amd/workload.py flops_window (textbook counts; tests/test_abi.py)",
                 "table_rows_per_source_block": rows / items,
                 "other_kernels": other,
@@ -492,6 +518,12 @@ def main():
                 # SIMD, register operands): the spec figure assumes 2.4 GHz, the clock under that load is ~1.9-2.0 GHz
                 "peak_sustained_measured": {"v_fma_f32": 120.2, "v_pk_fma_f32": 137.4, "unit": "TFLOP/s",
                                             "frac_of_v_fma_f32": tf / 120.2}}
+        # NOT a roofline fraction (it prices work the kernel does not do): the same output priced with the reference's own
+        # algorithm -- an unpruned inverse pair per filter set and source, GPUSoundSource.cu:320-385 --, comparable across
+        # kernels that skip different amounts of that work
+        ref_rate = {"flops_per_launch_reference_algorithm": flops_ref / launches,
+                    "tflops_if_the_reference_algorithm_were_executed": (flops_ref / fused_s / 1e12) if fused_s > 0 else 0.0,
+                    "note": "work-equivalent rate for comparisons between kernel generations, not an achieved figure"}
         # SURVEY.md 8(d)'s algorithmic bytes (table rows re-read per item): a CACHE-level rate, not an HBM rate
         roof["algorithmic_cache_gbps"] = abytes / fused_s / 1e9 if fused_s > 0 else 0.0
         roof["algorithmic_bytes_per_launch"] = abytes / launches
@@ -529,10 +561,21 @@ def main():
             if fpmc.get("SQ_WAVE_CYCLES") and fpmc.get("SQ_WAIT_ANY"):
                 iss["wave_time_waiting_share"] = fpmc["SQ_WAIT_ANY"] / fpmc["SQ_WAVE_CYCLES"]
             roof["issue"] = iss
+        if fpmc and fpmc.get("SQ_INSTS_VALU_FLOPS_FP32") and fused_s > 0:
+            # the hardware's own count of executed fp32 flops (per wave instruction: x 64 lanes), beside the textbook model
+            fl = fpmc["SQ_INSTS_VALU_FLOPS_FP32"] * 64.0
+            roof["frac_pmc"] = fl / (fused_s / launches) / 1e12 / FP32_VECTOR_PEAK_TF
+            roof["flops_per_launch_pmc"] = fl
+            roof["frac_pmc_source"] = "SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes per launch / avg_launch_ms; " + pmc_note
+        else:
+            roof["frac_pmc"] = None
         out = {
             "metric": "source-frames/s (sources x frames/sec) at 256-sample blocks",
             "value": value, "unit": "source-frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "prewarm_steps": prewarm,
+            "prewarm_policy": ("whatever --warmup says, at least 256 untimed steps (~65 ms of GPU time) run before the timed "
+                               "region: the first ~100 steps after an idle GPU run 10-15 % slower (clock ramp), so `value` is "
+                               "a warmed steady-state figure; prewarm_steps = max(0, 256 - warmup) of them are this script's own"),
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
@@ -552,6 +595,7 @@ def main():
             "real_time_factor": (KB * K * B / 44100.0) / dt,
             "us_per_source_block": dt / (S * KB * K) * 1e6,
             "roofline": roof,
+            "reference_algorithm_rate": ref_rate,
         }
         if use_dist:
             # the only exchange of the path: the sum of the per-rank stereo mixes
@@ -560,7 +604,16 @@ def main():
                            "backend": "RCCL" if backend == "nccl" else backend,
                            "payload_bytes_per_rank_per_step": KB * 2 * B * 4,
                            "overlap": "asynchronous on the collective's stream, double-buffered: step i + 1 computes "
-                                      "while step i reduces; no collective on the data path of the kernels"}
+                                      "while step i reduces; no collective on the data path of the kernels",
+                           # the collective's own duration against a step: what it WOULD cost if it were not overlapped
+                           "ms_per_collective": comm_ms,
+                           "fraction": (comm_ms / (dt / K * 1e3)) if comm_ms is not None else None,
+                           "fraction_is": "duration of one collective / ms_per_step; the collective runs beside the next "
+                                          "step's kernels, so this is an upper bound of its share of the step, not time added "
+                                          "to it",
+                           "measured": "HIP events on the engine's stream around the collective (kernels done -> reduced mix "
+                                       "there), 16 steps after the timed region with the stream waiting for its own step's "
+                                       "collective; max over ranks"}
         if ir is not None:
             # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
             # 690*129*8 B of IR spectra once per block (shared by all sources)

@@ -98,10 +98,24 @@ int jf_group_synchronize(jf_group *g);
  * batch_fetch, process_batch) fails on one GPU after others have already advanced, the shards are out of step and the
  * group is marked FAILED: every later processing call returns JF_ERR_STATE ("group failed") until the job is rebuilt
  * (jf_group_destroy + jf_group_create).  Setters and getters keep working so that the host can read
- * jf_group_last_error / jf_last_error(jf_group_engine(g, i)).  Several GPUs (n_gpus > 1) have only run on a
- * one-GPU box as a communicator of size 1 so far.
+ * jf_group_last_error / jf_last_error(jf_group_engine(g, i)).  jf_group_set_mode / _set_pause that fail on engine i > 0 set
+ * engines 0 .. i - 1 back, so the shards never render different algorithms.  Several GPUs (n_gpus > 1) have only run on a
+ * one-GPU box as a communicator of size 1 and as several shards on the one device (below) so far.
  */
 int jf_group_failed(const jf_group *g);
+
+/*
+ * Test support: what of the several-GPU host code a one-GPU box can exercise with MORE THAN ONE shard.
+ * jf_group_create_shards_on_device: n_shards engines, all on `device`, no RCCL communicator (RCCL refuses duplicate
+ * devices); batch runs leave every shard's mix in its buffer and jf_group_batch_fetch adds them on the host in shard order
+ * -- the sharding, the per-shard repack of the trajectory, the routing of the per-source calls, the job-wide controls and the
+ * FAILED transitions are the production code, only the wire is replaced.
+ * jf_group_debug_fail_next: the next processing step or control call that reaches shard `shard` fails with JF_ERR_DEVICE
+ * without touching the engine (-1 disarms).
+ */
+int jf_group_create_shards_on_device(const jf_config *cfg, int n_shards, int device, const float *hrir, int taps,
+                                     jf_group **out);
+int jf_group_debug_fail_next(jf_group *g, int shard);
 
 #ifdef __cplusplus
 }

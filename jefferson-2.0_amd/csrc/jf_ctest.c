@@ -6,6 +6,8 @@
  *   jf_ctest group N one job over N GPUs (jefferson_group.h: one engine per GPU, RCCL reduce of the mixes) against
  *                    one engine holding all sources: per-block calls (host sum) and batch calls (ncclReduce); then the
  *                    same with the job-wide controls -- mode switch, reverb stage, pause, source reset, clip peak
+ *   jf_ctest shards N N shards of one job on the ONE device (jf_group_create_shards_on_device: everything of the several-GPU
+ *                    host code but the wire) against one engine, and the FAILED transitions under forced failures
  *   jf_ctest bench N [steps] the bench workload from a C host: 1024 moving sources per GPU, 256-sample blocks, 128
  *                    blocks per jf_group_batch_run / _fetch; prints source-frames/s (bench.py's metric)
  *
@@ -217,6 +219,126 @@ static int test_group(int n_gpus) {
     return (d_batch <= tol && d_block <= tol && peak > 0.05 && ok_ctl) ? 0 : 1;
 }
 
+/* N > 1 shards on the ONE device (jf_group_create_shards_on_device: the production sharding, repack, routing, controls and
+ * failure handling with a host sum where the several-GPU form has ncclReduce) against one engine holding all sources; then
+ * forced failures on shard 1: a control call must leave every shard as it was, a processing call must leave the group
+ * FAILED -- JF_ERR_STATE from every later processing call, setters and error texts still there, destroy clean. */
+static int test_shards(int n_shards) {
+    enum { B = 128, S = 37, K = 5, RUNS = 3, TAPS = 128 }; /* 37 sources: shards of unequal size */
+    float *hrir = make_hrir(TAPS);
+    jf_config cfg = {B, 512, S, 0, K, 0};
+    jf_engine *one = NULL;
+    jf_group *grp = NULL;
+    CHECK(jf_engine_create(&cfg, hrir, TAPS, &one));
+    CHECK(jf_group_create_shards_on_device(&cfg, n_shards, 0, hrir, TAPS, &grp));
+    int covered = 0;
+    for (int i = 0; i < n_shards; i++) {
+        int lo, hi;
+        CHECK(jf_shard_range(S, n_shards, i, &lo, &hi));
+        if (jf_group_first_source(grp, i) != lo || jf_num_sources(jf_group_engine(grp, i)) != hi - lo) return 1;
+        covered += hi - lo;
+    }
+    if (covered != S || jf_group_num_gpus(grp) != n_shards) return 1;
+    for (int s = 0; s < S; s++) {
+        const size_t n = 7000 + 97 * (size_t)s;
+        float *sig = make_signal(n);
+        CHECK(jf_source_set_signal(one, s, sig, n));
+        CHECK(jf_group_source_set_signal(grp, s, sig, n));
+        free(sig);
+    }
+    /* every source on its own trajectory: a repack that put a record into the wrong shard or slot would show */
+    float *pos = (float *)malloc(sizeof(float) * JF_POS_FLOATS * S * K * RUNS);
+    for (int k = 0; k < K * RUNS; k++)
+        for (int s = 0; s < S; s++)
+            CHECK(jf_position_from_spherical((float)(-40 + (11 * s) % 121), (float)((53 * s + 3 * k) % 360), 0.4f + 0.07f * s,
+                                             pos + ((size_t)k * S + s) * JF_POS_FLOATS));
+    float *a = (float *)malloc(sizeof(float) * 2 * B * K * RUNS), *b = (float *)malloc(sizeof(float) * 2 * B * K * RUNS);
+    CHECK(jf_process_batch(one, K * RUNS, pos, a));
+    CHECK(jf_group_process_batch(grp, K * RUNS, pos, b));
+    double peak = 0;
+    const double d_batch = max_abs_diff(b, a, (size_t)2 * B * K * RUNS, &peak);
+    /* the device-resident form, a window in the middle of the trajectory */
+    CHECK(jf_batch_upload_positions(one, K * RUNS, pos));
+    CHECK(jf_group_batch_upload_positions(grp, K * RUNS, pos));
+    CHECK(jf_batch_run(one, K, K, NULL));
+    CHECK(jf_synchronize(one));
+    CHECK(jf_debug_copy_from_device(one, jf_batch_mix_device(one), a, sizeof(float) * 2 * B * K));
+    CHECK(jf_group_batch_run(grp, K, K));
+    if (jf_group_batch_run(grp, 0, K) != JF_ERR_STATE) return 1; /* one run in flight */
+    CHECK(jf_group_batch_fetch(grp, b));
+    const double d_run = max_abs_diff(b, a, (size_t)2 * B * K, NULL);
+    /* per-block calls, the controls with more than one engine behind them */
+    double d_block = 0, pk = 0;
+    int silent = 0;
+    for (int k = 0; k < 12; k++) {
+        if (k == 3 || k == 6) {
+            CHECK(jf_set_mode(one, k == 3 ? JF_MODE_FD_BASIC : JF_MODE_FD_COMPLEX));
+            CHECK(jf_group_set_mode(grp, k == 3 ? JF_MODE_FD_BASIC : JF_MODE_FD_COMPLEX));
+        }
+        if (k == 8 || k == 10) {
+            CHECK(jf_set_pause(one, k == 8));
+            CHECK(jf_group_set_pause(grp, k == 8));
+        }
+        for (int s = 0; s < S; s++) {
+            CHECK(jf_source_set_spherical(one, s, (float)(-30 + (13 * s) % 100), (float)((29 * s + 11 * k) % 360), 0.8f));
+            CHECK(jf_group_source_set_spherical(grp, s, (float)(-30 + (13 * s) % 100), (float)((29 * s + 11 * k) % 360), 0.8f));
+        }
+        CHECK(jf_process_block(one, a));
+        CHECK(jf_group_process_block(grp, b));
+        const double d = max_abs_diff(b, a, 2 * B, &pk);
+        if (d > d_block) d_block = d;
+        if (pk == 0) silent++;
+    }
+    const double tol = n_shards == 1 ? 0.0 : 4e-7 * S;
+    printf("shards: %d shards of %d sources on one device: batch max diff %g, run max diff %g, per-block max diff %g "
+           "(tolerance %g), peak %g, %d silent blocks (2 paused)\n", n_shards, S, d_batch, d_run, d_block, tol, peak, silent);
+    int ok = d_batch <= tol && d_run <= tol && d_block <= tol && peak > 0.05 && silent == 2;
+
+    /* ---- forced failures on the last shard */
+    const int last = n_shards - 1;
+    int ok_fail = 1;
+    if (n_shards > 1) {
+        /* a control call that fails on shard `last` leaves the earlier shards as they were: the next block is still the
+         * single engine's in the OLD mode, and the group is not failed */
+        CHECK(jf_group_debug_fail_next(grp, last));
+        ok_fail &= jf_group_set_mode(grp, JF_MODE_FD_BASIC) == JF_ERR_DEVICE && jf_group_failed(grp) == 0;
+        CHECK(jf_process_block(one, a));
+        CHECK(jf_group_process_block(grp, b));
+        ok_fail &= max_abs_diff(b, a, 2 * B, NULL) <= tol;
+        CHECK(jf_group_debug_fail_next(grp, last));
+        ok_fail &= jf_group_set_pause(grp, 1) == JF_ERR_DEVICE && jf_group_failed(grp) == 0;
+        CHECK(jf_process_block(one, a));
+        CHECK(jf_group_process_block(grp, b));
+        ok_fail &= max_abs_diff(b, a, 2 * B, &pk) <= tol && pk > 0;
+        /* a batch run that fails on shard `last` after the earlier shards have advanced */
+        CHECK(jf_group_debug_fail_next(grp, last));
+        ok_fail &= jf_group_batch_run(grp, 0, K) == JF_ERR_DEVICE && jf_group_failed(grp) == 1;
+        ok_fail &= strstr(jf_group_last_error(grp), "injected failure") != NULL;
+        ok_fail &= jf_group_batch_run(grp, 0, K) == JF_ERR_STATE && jf_group_process_block(grp, b) == JF_ERR_STATE;
+        ok_fail &= strstr(jf_group_last_error(grp), "group failed") != NULL && strstr(jf_group_last_error(grp), "injected") != NULL;
+        ok_fail &= jf_group_source_set_spherical(grp, S - 1, 0.0f, 0.0f, 1.0f) == JF_OK; /* setters stay usable */
+        ok_fail &= jf_group_failed(grp) == 1;
+        /* a second group: the failure in the collect loop of a per-block call */
+        jf_group *g2 = NULL;
+        CHECK(jf_group_create_shards_on_device(&cfg, n_shards, 0, hrir, TAPS, &g2));
+        CHECK(jf_group_process_block(g2, b));
+        CHECK(jf_group_debug_fail_next(g2, 0));   /* submit of shard 0 fails: nothing has advanced, not fatal */
+        ok_fail &= jf_group_process_block(g2, b) == JF_ERR_DEVICE && jf_group_failed(g2) == 0;
+        CHECK(jf_group_process_block(g2, b));
+        CHECK(jf_group_debug_fail_next(g2, last)); /* submit of the last shard fails: the others have a block in flight */
+        ok_fail &= jf_group_process_block(g2, b) == JF_ERR_DEVICE && jf_group_failed(g2) == 1;
+        jf_group_destroy(g2);
+        printf("shards: forced failures on shard %d: %s\n", last, ok_fail ? "as specified" : "WRONG");
+    }
+    jf_group_destroy(grp);
+    jf_engine_destroy(one);
+    free(pos);
+    free(a);
+    free(b);
+    free(hrir);
+    return (ok && ok_fail) ? 0 : 1;
+}
+
 static double now_s(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
@@ -273,8 +395,9 @@ static int test_bench(int n_gpus, int steps) {
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "pa")) return test_pa();
     if (argc >= 2 && !strcmp(argv[1], "group")) return test_group(argc >= 3 ? atoi(argv[2]) : 1);
+    if (argc >= 2 && !strcmp(argv[1], "shards")) return test_shards(argc >= 3 ? atoi(argv[2]) : 2);
     if (argc >= 2 && !strcmp(argv[1], "bench"))
         return test_bench(argc >= 3 ? atoi(argv[2]) : 1, argc >= 4 ? atoi(argv[3]) : 256);
-    fprintf(stderr, "usage: jf_ctest pa | group [n_gpus] | bench [n_gpus [steps]]\n");
+    fprintf(stderr, "usage: jf_ctest pa | group [n_gpus] | shards [n_shards] | bench [n_gpus [steps]]\n");
     return 64;
 }

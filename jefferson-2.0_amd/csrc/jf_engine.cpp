@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -56,6 +57,7 @@ struct EventPair {
 }  // namespace
 
 constexpr double kInterpMovedMax = 0.30;  // jf_engine::interp_use == 2: largest share of moving items a run may have to take the rows
+constexpr long kRtPollNs = 2000000;  // jf_collect_block polls the real-time kernel's completion words for at most this long
 constexpr int kRtMaxWgs = 128;  // workgroups (16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
 
 struct jf_engine {
@@ -527,15 +529,18 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         e->order.resize(S);
         for (size_t s = 0; s < S; s++) e->order[s] = (int)s;
         JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * S, hipMemcpyHostToDevice));
-        JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5, hipHostMallocMapped));
-        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, hipHostMallocMapped));
+        // host memory the kernels read and write in place, and whose words the host polls while a kernel runs: mapped AND
+        // coherent (fine-grained) explicitly -- not left to the runtime's default or to HIP_HOST_COHERENT
+        const unsigned kHostFlags = hipHostMallocMapped | hipHostMallocCoherent;
+        JF_HIP(e, hipHostMalloc(&e->h_pos_pinned, sizeof(float) * S * 5, kHostFlags));
+        JF_HIP(e, hipHostMalloc(&e->h_out_pinned, sizeof(float) * 2 * B * kRtMaxWgs, kHostFlags));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_pos, e->h_pos_pinned, 0));
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_out, e->h_out_pinned, 0));
-        JF_HIP(e, hipHostMalloc(&e->h_done, sizeof(int) * kRtMaxWgs, hipHostMallocMapped));
+        JF_HIP(e, hipHostMalloc(&e->h_done, sizeof(int) * kRtMaxWgs, kHostFlags));
         memset(e->h_done, 0, sizeof(int) * kRtMaxWgs);
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_done, e->h_done, 0));
         // the error word, followed by 64 KB that timing experiments of the kernels may fill (JF_EXP_STAMPS)
-        JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int) * 4 + 65536, hipHostMallocMapped));
+        JF_HIP(e, hipHostMalloc(&e->h_err, sizeof(int) * 4 + 65536, kHostFlags));
         memset(e->h_err, 0, sizeof(int) * 4 + 65536);
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_err, e->h_err, 0));
         e->d_signal.assign(S, nullptr);
@@ -842,11 +847,21 @@ int jf_collect_block(jf_engine *e, float *out) {
         // The real-time kernel says when its blocks are in host memory: poll its words (a few microseconds of spinning on the
         // audio thread, as cudaStreamSynchronize does in the reference, Audio.cu:107) -- and fall back to the stream if they
         // do not come (a faulting kernel must surface as an error, not as a spin).
+        // The spin is bounded by TIME (kRtPollNs: two milliseconds, a third of a 256-sample block's real time), read every
+        // 256 polls; after that the stream synchronisation below takes over.
         const volatile int *done = e->h_done;
-        for (long spins = 0; spins < 4000000 && !landed; spins++) {
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (long spins = 0; !landed; spins++) {
             landed = true;
             for (int g = 0; g < e->rt_wgs; g++) landed = landed && done[g] == e->rt_seq;
-            if (!landed) __builtin_ia32_pause();
+            if (landed) break;
+            __builtin_ia32_pause();
+            if ((spins & 255) == 255) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > kRtPollNs) break;
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }

@@ -21,6 +21,10 @@ struct jf_group {
     int traj_blocks;
     int run_blocks; /* > 0: a batch run is in flight (not yet fetched) */
     int failed;     /* a processing call failed part-way: the shards are out of step (jefferson_group.h) */
+    int mode, paused; /* what jf_group_set_mode / _set_pause last set on every engine (for the roll-back of a partial failure) */
+    int host_sum;   /* jf_group_create_shards_on_device: all shards on ONE device, no communicator; the mixes are added on the host */
+    float *hmix;    /* host_sum: [maxK][2B] scratch of jf_group_batch_fetch */
+    int inject;     /* jf_group_debug_fail_next: shard + 1 whose next processing step is made to fail (0: none) */
     float last_peak; /* max |sample| of the last block handed out by jf_group_process_block */
     char err[256];
 };
@@ -83,11 +87,14 @@ void jf_group_destroy(jf_group *g) {
     free(g->comm);
     free(g->d_red);
     free(g->blk);
+    free(g->hmix);
     free(g);
     if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
 }
 
-int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out) {
+/* one_device >= 0: every shard on that device, no communicator (jf_group_create_shards_on_device) */
+static int create_group(const jf_config *cfg, int n_gpus, const int *devices, int one_device, const float *hrir, int taps,
+                        jf_group **out) {
     if (!cfg || !hrir || !out) return fail(NULL, JF_ERR_ARG, "null argument", NULL);
     *out = NULL;
     if (n_gpus < 1 || n_gpus > cfg->n_sources) return fail(NULL, JF_ERR_ARG, "need 1 <= n_gpus <= n_sources", NULL);
@@ -102,18 +109,22 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
     g->S = cfg->n_sources;
     g->B = cfg->frames_per_buffer;
     g->maxK = cfg->max_batch_blocks;
+    g->mode = JF_MODE_FD_COMPLEX;
+    g->host_sum = one_device >= 0;
     g->dev = (int *)calloc(n_gpus, sizeof(int));
     g->lo = (int *)calloc(n_gpus + 1, sizeof(int));
     g->eng = (jf_engine **)calloc(n_gpus, sizeof(*g->eng));
     g->comm = (ncclComm_t *)calloc(n_gpus, sizeof(*g->comm));
     g->d_red = (float **)calloc(n_gpus, sizeof(*g->d_red));
     g->blk = (float *)calloc(2 * (size_t)(g->B > 0 ? g->B : 1), sizeof(float));
+    if (g->host_sum) g->hmix = (float *)calloc(2 * (size_t)(g->B > 0 ? g->B : 1) * (size_t)(g->maxK > 0 ? g->maxK : 1), sizeof(float));
     int rc = JF_OK;
-    if (!g->dev || !g->lo || !g->eng || !g->comm || !g->d_red || !g->blk) rc = fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
+    if (!g->dev || !g->lo || !g->eng || !g->comm || !g->d_red || !g->blk || (g->host_sum && !g->hmix))
+        rc = fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
     for (int i = 0; rc == JF_OK && i < n_gpus; i++) {
-        g->dev[i] = devices ? devices[i] : i;
+        g->dev[i] = g->host_sum ? one_device : (devices ? devices[i] : i);
         if (g->dev[i] < 0 || g->dev[i] >= ndev) rc = fail(NULL, JF_ERR_ARG, "device ordinal out of range", NULL);
-        for (int k = 0; rc == JF_OK && k < i; k++)
+        for (int k = 0; rc == JF_OK && !g->host_sum && k < i; k++)
             if (g->dev[k] == g->dev[i]) rc = fail(NULL, JF_ERR_ARG, "a device is listed twice (RCCL needs distinct devices)", NULL);
     }
     for (int i = 0; rc == JF_OK && i < n_gpus; i++) {
@@ -133,7 +144,7 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
             hipMalloc((void **)&g->d_red[i], sizeof(float) * 2 * (size_t)g->B * (size_t)g->maxK) != hipSuccess)
             rc = fail(NULL, JF_ERR_DEVICE, "hipMalloc of the reduce buffer failed", NULL);
     }
-    if (rc == JF_OK) {
+    if (rc == JF_OK && !g->host_sum) {
         ncclResult_t s = ncclCommInitAll(g->comm, n_gpus, g->dev);
         if (s != ncclSuccess) rc = fail(NULL, JF_ERR_DEVICE, "ncclCommInitAll", ncclGetErrorString(s));
     }
@@ -145,6 +156,30 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
     if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     *out = g;
     return JF_OK;
+}
+
+int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out) {
+    return create_group(cfg, n_gpus, devices, -1, hrir, taps, out);
+}
+
+int jf_group_create_shards_on_device(const jf_config *cfg, int n_shards, int device, const float *hrir, int taps,
+                                     jf_group **out) {
+    if (device < 0) return fail(NULL, JF_ERR_ARG, "device ordinal out of range", NULL);
+    return create_group(cfg, n_shards, NULL, device, hrir, taps, out);
+}
+
+int jf_group_debug_fail_next(jf_group *g, int shard) {
+    if (!g || shard < -1 || shard >= g->n) return JF_ERR_ARG;
+    g->inject = shard + 1;
+    return JF_OK;
+}
+
+/* jf_group_debug_fail_next: 1 once for the armed shard */
+static int injected(jf_group *g, int i) {
+    if (g->inject != i + 1) return 0;
+    g->inject = 0;
+    snprintf(g->err, sizeof(g->err), "injected failure on shard %d (jf_group_debug_fail_next)", i);
+    return 1;
 }
 
 const char *jf_group_last_error(const jf_group *g) { return g ? g->err : g_create_err; }
@@ -177,6 +212,10 @@ int jf_group_source_set_cartesian(jf_group *g, int src, float x, float y, float 
 /* a processing step on shard i: a failure once any shard may have advanced marks the group failed */
 #define JG_STEP(g, i, call)                                                          \
     do {                                                                             \
+        if (injected((g), (i))) {                                                    \
+            (g)->failed = 1;                                                         \
+            return JF_ERR_DEVICE;                                                    \
+        }                                                                            \
         int rc_ = (call);                                                            \
         if (rc_ != JF_OK) {                                                          \
             (g)->failed = 1;                                                         \
@@ -207,16 +246,34 @@ int jf_group_source_reset(jf_group *g, int src) {
     return JF_OK;
 }
 
+/* Forwarded to every engine; if engine i > 0 refuses, engines 0 .. i - 1 are set back to what they had, so the shards never
+ * render different algorithms -- and if even that fails the group is marked failed. */
 int jf_group_set_mode(jf_group *g, int mode) {
     if (!g) return JF_ERR_ARG;
     if (mode != JF_MODE_FD_COMPLEX && mode != JF_MODE_FD_BASIC) return fail(g, JF_ERR_ARG, "unknown mode", NULL);
-    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_set_mode(g->eng[i], mode));
+    for (int i = 0; i < g->n; i++) {
+        const int rc = injected(g, i) ? JF_ERR_DEVICE : jf_set_mode(g->eng[i], mode);
+        if (rc != JF_OK) {
+            for (int k = 0; k < i; k++)
+                if (jf_set_mode(g->eng[k], g->mode) != JF_OK) g->failed = 1;
+            return rc;
+        }
+    }
+    g->mode = mode;
     return JF_OK;
 }
 
 int jf_group_set_pause(jf_group *g, int paused) {
     if (!g) return JF_ERR_ARG;
-    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_set_pause(g->eng[i], paused));
+    for (int i = 0; i < g->n; i++) {
+        const int rc = injected(g, i) ? JF_ERR_DEVICE : jf_set_pause(g->eng[i], paused);
+        if (rc != JF_OK) {
+            for (int k = 0; k < i; k++)
+                if (jf_set_pause(g->eng[k], g->paused) != JF_OK) g->failed = 1;
+            return rc;
+        }
+    }
+    g->paused = paused != 0;
     return JF_OK;
 }
 
@@ -242,10 +299,11 @@ int jf_group_process_block(jf_group *g, float *out) {
     JG_ALIVE(g);
     /* every GPU gets its block before any is waited for */
     for (int i = 0; i < g->n; i++) {
-        const int rc = jf_submit_block(g->eng[i]);
+        const int inj = injected(g, i);
+        const int rc = inj ? JF_ERR_DEVICE : jf_submit_block(g->eng[i]);
         if (rc != JF_OK) {
             if (i > 0) g->failed = 1; /* shards 0 .. i-1 have a block in flight */
-            return fail(g, rc, "jf_submit_block", jf_last_error(g->eng[i]));
+            return inj ? rc : fail(g, rc, "jf_submit_block", jf_last_error(g->eng[i]));
         }
     }
     memset(out, 0, sizeof(float) * 2 * (size_t)g->B);
@@ -295,11 +353,16 @@ int jf_group_batch_run(jf_group *g, int first_block, int n_blocks) {
     JG_ALIVE(g);
     /* every engine's kernels, each on its own stream, its mix into its reduce buffer */
     for (int i = 0; i < g->n; i++) {
-        const int rc = jf_batch_run(g->eng[i], first_block, n_blocks, g->d_red[i]);
+        const int inj = injected(g, i);
+        const int rc = inj ? JF_ERR_DEVICE : jf_batch_run(g->eng[i], first_block, n_blocks, g->d_red[i]);
         if (rc != JF_OK) {
             if (i > 0) g->failed = 1; /* shards 0 .. i-1 have advanced */
-            return fail(g, rc, "jf_batch_run", jf_last_error(g->eng[i]));
+            return inj ? rc : fail(g, rc, "jf_batch_run", jf_last_error(g->eng[i]));
         }
+    }
+    if (g->host_sum) { /* shards of one device (test form): no communicator, jf_group_batch_fetch adds the mixes */
+        g->run_blocks = n_blocks;
+        return JF_OK;
     }
     /* the one exchange of the path: sum of the mixes to the first GPU, behind the kernels on the same streams.
      * From here on every shard has advanced: any failure leaves the group failed, and the collective group is always
@@ -327,9 +390,17 @@ int jf_group_batch_fetch(jf_group *g, float *out_mix) {
     (void)hipGetDevice(&prev);
     JG_HIP(g, hipSetDevice(g->dev[0]));
     hipStream_t st = (hipStream_t)jf_engine_stream(g->eng[0]);
-    hipError_t s = hipMemcpyAsync(out_mix, g->d_red[0], sizeof(float) * 2 * (size_t)g->B * (size_t)g->run_blocks,
-                                  hipMemcpyDeviceToHost, st);
+    const size_t n_mix = 2 * (size_t)g->B * (size_t)g->run_blocks;
+    hipError_t s = hipMemcpyAsync(out_mix, g->d_red[0], sizeof(float) * n_mix, hipMemcpyDeviceToHost, st);
     if (s == hipSuccess) s = hipStreamSynchronize(st);
+    /* shards of one device: the other shards' mixes are added here in shard order (Audio.cu:109-110), where the several-GPU
+     * form has had ncclReduce do it on the devices */
+    for (int i = 1; g->host_sum && s == hipSuccess && i < g->n; i++) {
+        hipStream_t si = (hipStream_t)jf_engine_stream(g->eng[i]);
+        s = hipMemcpyAsync(g->hmix, g->d_red[i], sizeof(float) * n_mix, hipMemcpyDeviceToHost, si);
+        if (s == hipSuccess) s = hipStreamSynchronize(si);
+        for (size_t k = 0; s == hipSuccess && k < n_mix; k++) out_mix[k] += g->hmix[k];
+    }
     if (prev >= 0) (void)hipSetDevice(prev);
     g->run_blocks = 0;
     if (s != hipSuccess) {

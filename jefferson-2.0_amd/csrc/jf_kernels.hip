@@ -1016,7 +1016,7 @@ JF_DEV void filtered_half_pre(const float4 *__restrict__ htab, unsigned lofs, in
     asm("" : "+v"(boff));  // see filtered_half
     const float4 *ha = htab + (size_t)__builtin_amdgcn_readfirstlane(row_a) * 512;
     const float4 *hb = htab + (size_t)__builtin_amdgcn_readfirstlane(row_b) * 512;
-    float4 h[BOTH ? 2 : 1][4];
+    float4 h[2][4];  // (h[1] is not touched without BOTH)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         h[0][q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ha + 64 * q) + boff);
@@ -1084,13 +1084,27 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     FusedParams P;
     const FusedParams JF_CONST_AS *const kernarg =
         (const FusedParams JF_CONST_AS *)__builtin_amdgcn_kernarg_segment_ptr();
+    // FusedParams is this kernel's ONLY parameter, so the kernel-argument segment starts with it; the whole struct is
+    // copied (every field of P is valid after a reload -- the loads of fields nobody reads afterwards are dead code).
+    static_assert(std::is_trivially_copyable<FusedParams>::value && std::is_standard_layout<FusedParams>::value,
+                  "FusedParams is re-read from the kernel-argument segment as plain bytes");
     auto reload_params = [&]() {
         const FusedParams JF_CONST_AS *q = kernarg;
         asm volatile("" : "+s"(q));
-        P.htab = q->htab, P.desc = q->desc, P.sigs = q->sigs, P.st_in = q->st_in, P.st_out = q->st_out;
+        // EVERY field, so that no stale or uninitialised one can be read after a reload (the size check below trips when a
+        // field is added to FusedParams and not here)
+        P.htab = q->htab, P.tw = q->tw, P.desc = q->desc, P.sigs = q->sigs, P.st_in = q->st_in, P.st_out = q->st_out;
         P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
         P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
-        P.n_pair_wgs = q->n_pair_wgs;
+        P.n_pair_wgs = q->n_pair_wgs, P.prep_pos = q->prep_pos, P.prep_desc = q->prep_desc, P.prep_K = q->prep_K;
+        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick;
+#pragma unroll
+        for (int i = 0; i < kNumElev + 1; i++) P.rt.offset[i] = q->rt.offset[i];
+#pragma unroll
+        for (int i = 0; i < kNumElev; i++) P.rt.inc[i] = q->rt.inc[i];
+        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
+                          sizeof(RingTable) == (2 * kNumElev + 1) * 4 + 4 + 8,
+                      "a field was added to FusedParams / RingTable: reload it here too");
     };
 #else
     const FusedParams &P = Pin;

@@ -8,8 +8,16 @@
  *     :2203-2250): start at (azi, ele), dwell `--dwell` blocks, then azimuth += `--step`
  *     degrees `--rounds` times; radius 0.5 (SoundSource.cu:12)
  *
+ *   - --script debugmode2: the scripted-motion run of the audio-only build (DEBUGMODE 2, main.cu:101-149): the source
+ *     starts at the constructor's position (ele 0, azi 0, r 0.5, SoundSource.cu:3-16) and the main thread sets the
+ *     way-points (ele, azi) = (4,2), (3,1), (2,4), (9,7), (0,0) one after the other, the k-th as soon as the source's
+ *     play position `count` has reached (k * 44100) % length (main.cu:105,113,121,128,135), then lets the stream run for two
+ *     more seconds (main.cu:142).  The reference polls `count` every 100 ms from another thread; here it is looked at
+ *     before every block (the audio thread's own granularity), so a run is reproducible: a way-point is latched by the
+ *     first block that starts with `count` at or past its mark.  `count` follows Audio.cu:121-139 (wraps at `length`).
+ *
  * usage: jf_render <hrir_dir> <in.wav> <out.wav> [--block 256] [--azi 3] [--ele 5]
- *                  [--dwell 172] [--rounds 72] [--step 5] [--radius 0.5] [--latency]
+ *                  [--dwell 172] [--rounds 72] [--step 5] [--radius 0.5] [--latency] [--script debugmode2]
  *   --latency  use jf_callback (the CUDA path's one-block latency, Audio.cu:104-117)
  *              instead of jf_process_block (the CPU path's ordering)
  *   --batch N  hand the engine N callbacks at a time (jf_process_batch: the same blocks, the positions the
@@ -23,6 +31,40 @@
 
 #include "../../include/jefferson.h"
 
+/* DEBUGMODE 2 (main.cu:101-149): way-points in the order the main thread sets them */
+static const float kScriptEle[5] = {4, 3, 2, 9, 0}, kScriptAzi[5] = {2, 1, 4, 7, 0};
+
+/* The scripted run as latched records: pos[total][JF_POS_FLOATS], block by block.  Returns the number of blocks, or 0. */
+static size_t script_debugmode2(size_t length, int block, float radius, float **pos_out) {
+    if (length == 0) return 0;
+    const size_t tail = (2 * 44100 + (size_t)block - 1) / (size_t)block; /* std::this_thread::sleep_for(2 s), main.cu:142 */
+    size_t cap = 6 * 44100 / (size_t)block + 5 * (length / (size_t)block + 2) + tail + 16, n = 0, left = 0;
+    float *pos = (float *)malloc(sizeof(float) * JF_POS_FLOATS * cap);
+    if (!pos) return 0;
+    float ele = 0, azi = 0; /* SoundSource::SoundSource() */
+    size_t count = 0;
+    int counter = 1;
+    while (n < cap) {
+        /* what the main thread has done by the time this block's callback runs */
+        while (counter <= 5 && count >= ((size_t)counter * 44100) % length) {
+            ele = kScriptEle[counter - 1];
+            azi = kScriptAzi[counter - 1];
+            if (++counter == 6) left = tail;
+        }
+        if (counter == 6 && left-- == 0) break;
+        if (jf_position_from_spherical(ele, azi, radius, pos + JF_POS_FLOATS * n) != JF_OK) {
+            free(pos);
+            return 0;
+        }
+        n++;
+        /* Audio.cu:121-139 */
+        if (count + (size_t)block < length) count += (size_t)block;
+        else count = (size_t)block - (length - count);
+    }
+    *pos_out = pos;
+    return n;
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -32,10 +74,10 @@ static double now_s(void) {
 int main(int argc, char **argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: %s <hrir_dir> <in.wav> <out.wav> [--block B] [--azi A] [--ele E] "
-                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N]\n", argv[0]);
+                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N] [--script debugmode2]\n", argv[0]);
         return 2;
     }
-    int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0;
+    int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0, script = 0;
     float azi = 3, ele = 5, step = 5, radius = 0.5f;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--latency")) latency = 1;
@@ -47,6 +89,7 @@ int main(int argc, char **argv) {
         else if (i + 1 < argc && !strcmp(argv[i], "--rounds")) rounds = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--step")) step = (float)atof(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--radius")) radius = (float)atof(argv[++i]);
+        else if (i + 1 < argc && !strcmp(argv[i], "--script") && !strcmp(argv[i + 1], "debugmode2")) script = 1, i++;
         else {
             fprintf(stderr, "unknown option %s\n", argv[i]);
             return 2;
@@ -74,6 +117,49 @@ int main(int argc, char **argv) {
     }
     jf_source_set_signal(e, 0, sig, n);
     jf_free(sig);
+
+    if (script) {
+        /* DEBUGMODE 2: the way-points as the blocks latch them; per block through the setter (what the main thread calls,
+         * SoundSource::updateFromSpherical) or, with --batch, as records handed over up front */
+        float *spos = NULL;
+        const size_t nb = script_debugmode2(n, block, radius, &spos);
+        float *sout = nb ? (float *)malloc(sizeof(float) * 2 * (size_t)block * nb) : NULL;
+        if (!nb || !sout) {
+            fprintf(stderr, "script: empty input or out of memory\n");
+            return 1;
+        }
+        int src = JF_OK;
+        const double ts = now_s();
+        jf_source_reset(e, 0);
+        if (batch > 0) {
+            for (size_t k0 = 0; k0 < nb && src == JF_OK; k0 += (size_t)batch) {
+                const int kb = nb - k0 < (size_t)batch ? (int)(nb - k0) : batch;
+                src = jf_process_batch(e, kb, spos + JF_POS_FLOATS * k0, sout + 2 * (size_t)block * k0);
+            }
+        } else {
+            if (latency) src = jf_callback(e, sout); /* priming call: the CUDA path hands out block k - 1 */
+            for (size_t k0 = 0; k0 < nb && src == JF_OK; k0++) {
+                const float *r = spos + JF_POS_FLOATS * k0; /* {ele, azi, x, y, z}: the setter takes (ele, azi, radius) */
+                jf_source_set_spherical(e, 0, r[0], r[1], radius);
+                src = latency ? jf_callback(e, sout + 2 * (size_t)block * k0) : jf_process_block(e, sout + 2 * (size_t)block * k0);
+            }
+        }
+        const double ds = now_s() - ts;
+        if (src != JF_OK) {
+            fprintf(stderr, "processing: %s\n", jf_last_error(e));
+            return 1;
+        }
+        if (jf_wav_write_stereo24(argv[3], sout, (size_t)block * nb, fs ? fs : 44100) != JF_OK) {
+            fprintf(stderr, "output: %s\n", jf_last_error(NULL));
+            return 1;
+        }
+        fprintf(stderr, "debugmode2: %zu blocks of %d frames in %.3f s: %.1f us per block, real-time factor %.1f\n", nb, block,
+                ds, 1e6 * ds / (double)nb, ((double)nb * block / 44100.0) / ds);
+        free(spos);
+        free(sout);
+        jf_engine_destroy(e);
+        return 0;
+    }
 
     const size_t total = (size_t)dwell * (size_t)(rounds + 1);
     float *out = (float *)malloc(sizeof(float) * 2 * (size_t)block * total);

@@ -35,6 +35,8 @@ _SIGS = {
     "jf_group_reverb_set_ir": (C.c_int, [C.c_void_p, _f, C.c_size_t, C.c_float]),
     "jf_group_last_block_peak": (C.c_float, [C.c_void_p]),
     "jf_group_failed": (C.c_int, [C.c_void_p]),
+    "jf_group_create_shards_on_device": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.c_int, _f, C.c_int, C.POINTER(C.c_void_p)]),
+    "jf_group_debug_fail_next": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

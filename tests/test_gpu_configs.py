@@ -269,6 +269,55 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     assert peak > 0.01
 
 
+def test_config4_bench_shape_with_the_default_grouping(jf, hrir, castanets):
+    """What `bench.py --reverb` itself launches -- 256 sources x 256 blocks per call, B = 128, 690 partitions, AUTOMATIC
+    grouping: the spatialiser behind the reverb stage is then fused_pair_kernel<2> over units of 16 sources in the engine's
+    processing order, reading the wet ring -- as two consecutive calls.  Every unit's stereo blocks against the float32 C
+    oracle's per-source blocks (reverb stage + spatialiser) summed over the unit's sources in that order; the mix as the
+    ordered sum of the units' blocks; sampled units against the float64 model as well."""
+    B, S, K = 128, 256, 256
+    ir = _ir(88200)
+    gain = 0.5
+    pos = _reverb_positions(jf, S, 2 * K)
+    sigs = [np.roll(castanets, 997 * s)[: 30000 + 64 * s] for s in range(S)]
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    for s in range(S):
+        e.set_signal(s, sigs[s])
+    e.set_reverb(ir, gain)
+    e.upload_positions(pos)
+    parts, mixes = [], []
+    for c in range(2):
+        e.batch_run(c * K, K)
+        e.synchronize()
+        ks = e.last_kernels()
+        assert any(k.startswith("fused_pair_kernel<2>") for k in ks) and any(k.startswith("reverb_mac") for k in ks), ks
+        G = e.last_source_group()
+        assert G == 16
+        parts.append(e.read_device(e.partial_device_ptr(), (K, S // G, 2 * B)))
+        mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
+    order = e.source_order()
+    e.close()
+    part, mix = np.concatenate(parts), np.concatenate(mixes)          # [2K][S/G][2B]
+    assert np.array_equal(mix, _ordered_mix(part))
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        ora.set_signal(s, sigs[s])
+    ora.set_reverb(ir, gain)
+    _, opart = ora.process_batch(pos, want_partial=True)               # [S][2K][2B]
+    ora.close()
+    tol = 2e-7 + 1e-7 * np.sqrt(690)          # float32 accumulation over 690 partitions, per source
+    worst = 0.0
+    for g in range(S // G):
+        want = opart[order[g * G:(g + 1) * G]].astype(np.float64).sum(axis=0)
+        err = np.abs(part[:, g] - want).max()
+        worst = max(worst, err)
+        assert err <= 2 * tol * G * max(1.0, np.abs(opart[order[g * G:(g + 1) * G]]).max()), g
+    assert np.abs(opart).max() > 0.01 and worst > 0.0
+    for g in (0, S // G - 1):                 # float64: gain * convolution -> spatialiser model, the unit's sources summed
+        want = sum(_reverb_model_blocks(hrir, B, 2 * K, ir, gain, sigs[s], pos[:, s]) for s in order[g * G:(g + 1) * G])
+        assert np.abs(part[:, g] - want).max() <= tol * G * max(1.0, np.abs(want).max()), g
+
+
 def test_realtime_reverb_reaches_the_reference_offline_form(jf, hrir, castanets):
     """The reference's reverb is a whole-signal product (cudaPart.cu:87-172): circular convolution of the zero-padded
     input with the impulse response, scaled by rms / rms2, looped as the source's `buf`.  The engine's stream form run

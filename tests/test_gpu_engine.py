@@ -129,30 +129,38 @@ def test_block_sizes(jf, hrir, castanets, B):
 
 def test_distance_sweep_gain_and_delay(jf, hrir):
     """a7: gain 1/(1 + fsvs r'^2) and the fractional circular delay, for radii up to the
-    alias-free limit at B = 256 (|coords| <= 5)."""
+    alias-free limit at B = 256 (|coords| <= 5).  The reference's bound -- 2e-7 (precision_test.cu:2158), for outputs
+    below 1: it flags |y| > 1 as clipping, Audio.cu:111 -- is asserted at EVERY radius on a stimulus inside that regime
+    (noise of amplitude 0.35 at the nearest radius, where the gain is ~1; 0.5 elsewhere).  The full-scale stimulus at the
+    nearest radius (|y| 0.9-1.3, the clipping regime) is held to its rms error instead: float32 transforms of 1024 points
+    leave 4.2e-8 rms there and the worst of a few thousand samples is 5-6 sigma, 2.0-2.8e-7 over six seeds whichever way the
+    complex products are written (profiles/r03/accuracy_seeds.txt; which stage owns that floor: profiles/r04/
+    error_floor.md) -- a known deviation recorded in DESIGN.md section 2, not a pass criterion; 5e-7 below only catches a
+    real regression."""
     rng = np.random.default_rng(11)
-    sig = rng.uniform(-.5, .5, 8192).astype(np.float32)
-    for r in (0.05, 0.5, 1.0, 2.0, 3.5, 4.9):
+    noise = rng.uniform(-.5, .5, 8192).astype(np.float32)
+    for r, amp in ((0.05, 0.7), (0.05, 2.0), (0.5, 1.0), (1.0, 1.0), (2.0, 1.0), (3.5, 1.0), (4.9, 1.0)):
+        sig = (noise * np.float32(amp)).astype(np.float32)
         e = jf.Engine(256, 512, 1, hrir=hrir)
         m = model64.Model(256, 512, 1, hrir)
         for x in (e, m):
             x.set_signal(0, sig)
             x.set_spherical(0, 0, 45, r)
+        loud = amp > 1.0          # full-scale noise at gain ~1
         sq = n = 0
+        peak = 0.0
         for _ in range(8):
             y, y64 = e.process_block(), m.process_block()
-            # The 2e-7 bound is for |y| < 1 (the reference flags > 1.0 as clipping, Audio.cu:111) and the reference's own
-            # signals; it holds here with a factor two to spare from r = 0.5 on (|y| <= 0.6: 0.9-1.15e-7 over six seeds).
-            # At r = 0.05 the gain is ~1 and FULL-SCALE NOISE drives |y| to 0.9-1.3: float32 transforms of 1024 points
-            # leave an rms error of 4.2e-8 there, and the largest of a few thousand samples is 5-6 sigma -- 2.0-2.8e-7
-            # over six seeds, the same with the complex products written as scalar or as packed instructions
-            # (profiles/accuracy_seeds.py, profiles/r03/accuracy_seeds.txt).  So that case is held to its rms error and
-            # to 3e-7 at the worst sample; a test at 2e-7 passed or failed by the seed.
-            loud = r < 0.1
-            assert np.abs(y - y64).max() <= (3e-7 if loud else TOL64) * max(1.0, np.abs(y64).max())
+            peak = max(peak, float(np.abs(y64).max()))
+            if loud:
+                assert np.abs(y - y64).max() <= 5e-7          # regression guard only (see above)
+            else:
+                assert np.abs(y64).max() < 1.0
+                assert np.abs(y - y64).max() <= TOL64         # the reference's bound, as it stands
             sq += float(np.sum((y - y64) ** 2))
             n += y.size
-        assert np.sqrt(sq / n) <= (6e-8 if r < 0.1 else 3e-8), r
+        assert np.sqrt(sq / n) <= (6e-8 if loud else 3e-8), (r, amp)
+        assert peak > (0.9 if loud else 0.004), (r, amp, peak)
         e.close()
 
 
@@ -414,6 +422,87 @@ def test_directory_loader_and_offline_driver(jf, hrir, castanets, tmp_path):
     assert open(outb, "rb").read() == open(outp, "rb").read()
 
 
+def test_scripted_motion_run_debugmode2(jf, hrir, castanets, tmp_path):
+    """`jf_render --script debugmode2` = the audio-only build's scripted run (DEBUGMODE 2, main.cu:101-149): the source
+    starts at the constructor's (0, 0) and takes the way-points (ele, azi) = (4,2), (3,1), (2,4), (9,7), (0,0), the k-th as soon
+    as its play position has reached (k * 44100) % length, then two more seconds.  Per-block calls (the setter before every
+    block, as the main thread does) and --batch (the same latched records up front) must write the same file, and that file
+    is the C oracle's output for the same script at the float32 tolerance (+ one 24-bit step); the five positions
+    interpolate as tests/golden/interp_known.json says."""
+    import json
+    import struct
+    import subprocess
+    import wave
+    from conftest import ROOT
+    kemar = str(tmp_path / "compact")
+    _write_compact_dir(kemar, hrir)
+    B = 256
+    # 6.2 s of input: the 2 s excerpt three times over, each pass with another gain and a slow fade, + a bit more
+    x = np.concatenate([castanets * g for g in (0.9, 0.6, 0.8)] + [castanets[:9000] * 0.5]).astype(np.float32)
+    x *= (0.75 + 0.25 * np.cos(np.arange(len(x)) / 30000.0)).astype(np.float32)
+    pcm = np.round(x.astype(np.float64) * 8388607.0).astype(np.int64)
+    inp = str(tmp_path / "in.wav")
+    with wave.open(inp, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(44100)
+        w.writeframes(b"".join(struct.pack("<i", int(v))[:3] for v in pcm))
+    sig, fs = jf.wav_read_mono(inp)             # what the driver itself reads (libsndfile scaling: / 2^23)
+    assert fs == 44100 and len(sig) == len(x)
+    exe = os.path.join(ROOT, "jefferson-2.0_amd", "jf_render")
+
+    def render(extra):
+        outp = str(tmp_path / ("out_" + "_".join(extra).replace("-", "") + ".wav"))
+        r = subprocess.run([exe, kemar, inp, outp, "--block", str(B), "--script", "debugmode2"] + extra, capture_output=True,
+                           text=True)
+        assert r.returncode == 0 and "debugmode2" in r.stderr, r.stderr
+        with wave.open(outp) as w:
+            assert (w.getnchannels(), w.getsampwidth()) == (2, 3)
+            raw = np.frombuffer(w.readframes(w.getnframes()), np.uint8).reshape(-1, 3).astype(np.int32)
+        v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+        return (np.where(v >= 1 << 23, v - (1 << 24), v) / 8388607.0).reshape(-1, 2 * B), open(outp, "rb").read()
+
+    got, raw_block = render([])
+    got_b, raw_batch = render(["--batch", "96"])
+    assert raw_batch == raw_block
+    # the script, restated here: way-point k latched by the first block that starts with count >= (k * 44100) % length
+    way = [(4, 2), (3, 1), (2, 4), (9, 7), (0, 0)]
+    n, count, k, pos, left = len(sig), 0, 1, (0, 0), None
+    script = []
+    while True:
+        while k <= 5 and count >= (k * 44100) % n:
+            pos = way[k - 1]
+            k += 1
+            if k == 6:
+                left = -(-2 * 44100 // B)
+        if k == 6:
+            if left == 0:
+                break
+            left -= 1
+        script.append(pos)
+        count = count + B if count + B < n else B - (n - count)
+    assert len(script) == got.shape[0]
+    first = [script.index(p) for p in way]
+    assert first == [-(-44100 * (j + 1) // B) for j in range(5)]      # one way-point per second of consumed input
+    ora = oracle_lib.Engine(B, 512, 1, hrir)
+    ora.set_signal(0, sig)
+    ora.reset(0)
+    want = []
+    for (ele, azi) in script:
+        ora.set_spherical(0, ele, azi, 0.5)
+        want.append(ora.process_block())
+    want = np.array(want)
+    assert np.abs(want).max() > 0.05
+    assert np.abs(got - want).max() <= 1.0 / 8388607 + TOL32
+    # the blocks right after a way-point differ from a run that stays at (0, 0): the script really moves the source
+    assert np.abs(got[first[0]] - got[first[0] - 1]).max() > 0
+    known = json.load(open(os.path.join(ROOT, "tests", "golden", "interp_known.json")))["points"]
+    for (ele, azi) in way:
+        idx, om = jf.interpolation(float(ele), float(azi))
+        assert idx.tolist() == known[f"{ele},{azi}"]["idx"]
+        assert np.array_equal(om, np.float32(known[f"{ele},{azi}"]["omegas"]))
+
+
 def test_rccl_reduce_on_the_engine_stream():
     """The RCCL side of bench.py's N > 1 path on the one GPU of this box: the `nccl` backend with world_size 1
     (communicator init, the engine's stream wrapped as an ExternalStream, asynchronous dist.reduce ordered after
@@ -557,13 +646,16 @@ def test_group_of_one_gpu_equals_the_engine(jf, hrir, castanets):
     eng.close()
 
 
-@pytest.mark.parametrize("args", [["pa"], ["group", "1"], ["bench", "1", "24"]])
+@pytest.mark.parametrize("args", [["pa"], ["group", "1"], ["shards", "2"], ["shards", "3"], ["bench", "1", "24"]])
 def test_plain_c_boundary_checks(args):
     """jf_ctest.c (plain C, linked against the C ABI only): `pa` drives jf_pa_callback with PortAudio's argument list
     for 200 blocks -- positions and pause changed in between -- against jf_callback on a twin engine (paCallback,
     Audio.cu:164-175); `group 1` runs jefferson_group.h over one GPU (RCCL communicator of size 1) against one engine,
     then again with the job-wide controls (reverb stage, mode switch, pause, reset, clip peak: Audio.cu:101,104,111-113,
-    cudaPart.cu:65-205); `bench 1` drives the bench workload (1024 moving sources, 128 blocks of 256 per run) through
+    cudaPart.cu:65-205); `shards N` runs N shards of one job on the one device (jf_group_create_shards_on_device: the
+    production sharding, the per-shard repack of the trajectory, the controls and the FAILED transitions under forced failures
+    on the last shard, with a host sum where several GPUs have ncclReduce; the mixing loop it distributes: Audio.cu:109-110);
+    `bench 1` drives the bench workload (1024 moving sources, 128 blocks of 256 per run) through
     jf_group_batch_run / _fetch and prints bench.py's metric."""
     import subprocess
     from conftest import ROOT
@@ -578,6 +670,8 @@ def test_plain_c_boundary_checks(args):
         assert b"max" in r.stdout
     if args[0] == "group":
         assert b"group controls" in r.stdout
+    if args[0] == "shards":
+        assert b"forced failures on shard" in r.stdout and b"as specified" in r.stdout
 
 
 def test_pair_hand_off_time_out_is_reported_not_hung():
@@ -720,6 +814,10 @@ def test_whole_bench_under_the_launcher_with_one_rank():
     assert out["verified"] is True, out.get("verification")
     assert out["n_gpus"] == 1 and out["steps"] == 8
     assert out["comm"]["backend"] == "RCCL"
+    # the communication fraction of SURVEY.md 8(d) config 4 is MEASURED (events around the collective), also with one rank
+    assert out["comm"]["ms_per_collective"] > 0 and 0 < out["comm"]["fraction"] < 1.0, out["comm"]
+    assert out["roofline"]["launches_timed"] == 8      # a short run times every launch
+    assert "prewarm_policy" in out and "frac_reference_algorithm" not in out["roofline"]
     n_cpu = len(os.sched_getaffinity(0))
     assert out["cpu_baseline"]["cores"] > 1 or n_cpu == 1
     assert out["roofline"]["frac"] > 0.05 and out["value"] > 1e10
