@@ -688,8 +688,11 @@ def test_pair_hand_off_time_out_is_reported_not_hung():
     from conftest import ROOT
     lib = os.path.join(ROOT, "tests", "build", "libjefferson_hip_droppub.so")
     assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc faultlib builds it (__graft_entry__.build() does)"
-    prod = os.path.join(ROOT, "jefferson-2.0_amd", "libjefferson_hip.so")
-    assert os.path.getmtime(lib) >= os.path.getmtime(prod) - 1.0, "stale fault-injection build: make -C jefferson-2.0_amd/csrc faultlib"
+    import ctypes
+    from jf_load import jf as _jf
+    _L = ctypes.CDLL(lib)
+    stale = [n for n in _jf.exported_symbols() if not hasattr(_L, n)]
+    assert not stale, f"stale fault-injection build (make -C jefferson-2.0_amd/csrc faultlib): it lacks {stale}"
     # without the permission the library must refuse to make an engine at all
     refuse = ('import os, sys\nsys.path.insert(0, os.environ["JF_ROOT"])\nfrom jf_load import jf\nimport numpy as np\n'
               'try:\n    jf.Engine(256, 512, 1, hrir=np.zeros((710, 2, 128), np.float32))\n    print("CREATED")\n'
