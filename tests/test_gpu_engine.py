@@ -688,11 +688,6 @@ def test_pair_hand_off_time_out_is_reported_not_hung():
     from conftest import ROOT
     lib = os.path.join(ROOT, "tests", "build", "libjefferson_hip_droppub.so")
     assert os.path.exists(lib), "make -C jefferson-2.0_amd/csrc faultlib builds it (__graft_entry__.build() does)"
-    import ctypes
-    from jf_load import jf as _jf
-    _L = ctypes.CDLL(lib)
-    stale = [n for n in _jf.exported_symbols() if not hasattr(_L, n)]
-    assert not stale, f"stale fault-injection build (make -C jefferson-2.0_amd/csrc faultlib): it lacks {stale}"
     # without the permission the library must refuse to make an engine at all
     refuse = ('import os, sys\nsys.path.insert(0, os.environ["JF_ROOT"])\nfrom jf_load import jf\nimport numpy as np\n'
               'try:\n    jf.Engine(256, 512, 1, hrir=np.zeros((710, 2, 128), np.float32))\n    print("CREATED")\n'
@@ -700,6 +695,7 @@ def test_pair_hand_off_time_out_is_reported_not_hung():
     env0 = {k: v for k, v in os.environ.items() if k != "JF_ALLOW_EXPERIMENT"}
     r0 = subprocess.run([sys.executable, "-c", refuse], env=dict(env0, JF_ROOT=ROOT, JF_LIB=lib), stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, timeout=300)
+    assert b"undefined symbol" not in r0.stderr, "stale fault-injection build: make -C jefferson-2.0_amd/csrc faultlib"
     assert r0.returncode == 0 and b"REFUSED -5" in r0.stdout and b"JF_ALLOW_EXPERIMENT" in r0.stdout, (r0.stdout, r0.stderr[-1000:])
     code = r'''
 import os, sys, time
