@@ -314,6 +314,15 @@ int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
+/* Partitioning of the convolution reverb, in effect from the next jf_reverb_set_ir: 0 = by the response's length (default:
+ * non-uniform from 48 partitions of frames_per_buffer on, unless jf_debug_set_reverb_form pins a uniform form), 1 = uniform
+ * (one partition per block: P multiply-accumulates per bin and block), 2 = non-uniform (a head of 16 partitions of one
+ * block + partitions of 16 blocks for the rest: P / 16 + 16; Gardner's zero-latency scheme with two sizes).  The reference's
+ * own form is one product over the whole signal (cudaPart.cu:87-153).  Same results to float32 rounding. */
+int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
+/* Returns the number of partitions of frames_per_buffer the impulse response has (0: stage off); *head = partitions of that
+ * size in use, *big = partitions of *big_taps taps behind them (0, 0: uniform partitioning). */
+int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps);
 /* Which batch calls use the pre-interpolated rows (JF_FLAG_NO_INTERP_TABLE above): 0 = none, 1 = all, 2 = decided per run
  * (the default when the rows were built): a run of an uploaded trajectory takes them unless more than 30 % of its items
  * move -- a source that stays reads its row out of the caches (12-18 % faster), one that moves streams 8 KB per block from

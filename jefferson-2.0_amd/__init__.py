@@ -96,6 +96,8 @@ _SIGS = {
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
+    "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
     "jf_debug_set_interp_share": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
     "jf_debug_count_desc_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -367,6 +369,16 @@ class Engine:
                                             _fp(dist), _fp(spec) if spec is not None else None))
         d = dist.view(np.complex64)[..., 0]
         return d if spec is None else (d, spec.view(np.complex64)[..., 0])
+
+    def set_reverb_partitioning(self, how):
+        """0 by length, 1 uniform, 2 non-uniform; in effect from the next set_reverb"""
+        self._chk(lib().jf_debug_set_reverb_partitioning(self.h, int(how)))
+
+    def reverb_partitions(self):
+        """(partitions of B the response has, head partitions in use, big partitions, taps per big partition)"""
+        h, b, t = C.c_int(), C.c_int(), C.c_int()
+        n = lib().jf_debug_reverb_partitions(self.h, C.byref(h), C.byref(b), C.byref(t))
+        return n, h.value, b.value, t.value
 
     def set_reverb_form(self, form):
         self._chk(lib().jf_debug_set_reverb_form(self.h, int(form)))

@@ -171,6 +171,36 @@ struct ReverbParams {
     const SrcState *st_in;    // count = wet-ring position of the first new sample of this call
     int S, K, B, P, Rg, Wr, head;
     int mac_form;             // 0 = chosen by call size; 1 per (block, source), 2 source groups, 3 block tiles
+    // Non-uniform partitioning (ReverbBigParams below): this stage is then the HEAD of the impulse response -- P = kRvBig
+    // partitions of B -- and adds the tail's contribution, which the big-partition kernels left in `fut`; every block's dry
+    // samples are also copied to `dryring`, from which the big-partition transform reads.  Null / 0: uniform partitioning.
+    float *dryring = nullptr;  // [S][Rd] dry input by absolute sample time mod Rd
+    int Rd = 0, dry_pos0 = 0;  // ring length; position of this call's first sample
+    const float *fut = nullptr;  // [S][F] the tail's contribution by absolute sample time mod F
+    int F = 0, fut_pos0 = 0;
+};
+
+// Level 1 of the non-uniformly partitioned reverb: the impulse response behind its first kRvBig * B taps in partitions of
+// B1 = kRvBig * B taps (transform length 2 B1).  Whenever kRvBig blocks of input are complete (absolute block index
+// j = m kRvBig), step m transforms the last 2 B1 dry samples, multiplies the last P1 such spectra with the P1 partition spectra
+// and leaves the B1 output samples for the blocks j .. j + kRvBig - 1 in `fut` -- they are due from the next block on, so
+// nothing is ever late (Gardner's scheme with two sizes).  Per output sample P1 + kRvBig complex multiply-accumulates per bin
+// instead of P = P1 kRvBig + kRvBig, and the delay line is read once per kRvBig blocks.
+constexpr int kRvBig = 16;
+struct ReverbBigParams {
+    const float2 *tw1;      // exp(+2 pi i j / (2 B1)), j < B1, from double
+    const float *dryring;   // [S][Rd]
+    float2 *fdl1;           // [S][R1][B1] spectra of the steps (ring, slot = step index mod R1), + [S][R1] compact bin-0 pairs
+    const float2 *hspec1;   // [P1][B1] partition spectra, pre-scaled by gain / B1, + [P1] compact bin-0 pairs
+    float2 *ybig;           // [S][n_steps][B1] products of this call's steps (batch form)
+    float *fut;             // [S][F]
+    int S, B1, P1, R1;
+    int Rn;                 // dry ring length in big blocks (Rd / B1)
+    int Fn;                 // fut ring length in big blocks (F / B1)
+    int n_steps;            // steps of this call: m = m_first .. m_first + n_steps - 1
+    int slot_first;         // m_first mod R1
+    int dblock_first;       // (m_first - 2) mod Rn: ring block of the first of the two big blocks step m_first transforms
+    int fut_first;          // m_first mod Fn: where step m_first's output goes
 };
 
 }  // namespace jf

@@ -38,7 +38,9 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
                            int n_wgs, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
-hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used);
+hipError_t launch_reverb(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st, int *form_used);
+hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
+                                float2 *d_hspec1, hipStream_t st);
 int kernels_build_kind();
 }  // namespace jf
 
@@ -157,6 +159,15 @@ struct jf_engine {
     float *d_rv_wet = nullptr;
     float *d_rv_prev[2] = {nullptr, nullptr};
     int *d_rv_count[2] = {nullptr, nullptr};
+    // non-uniform partitioning (ReverbBigParams, jf_device.h): rv_P is then the HEAD's partition count (kRvBig) and the rest
+    // of the impulse response lies in rv_P1 partitions of rv_B1 = kRvBig * B taps.  rv_P1 == 0: uniform partitioning.
+    int rv_partitioning = 0;     // jf_debug_set_reverb_partitioning: 0 by length, 1 uniform, 2 non-uniform (at the next set_ir)
+    int rv_P_total = 0;          // partitions of B the impulse response has (what rv_P is under uniform partitioning)
+    int rv_P1 = 0, rv_B1 = 0, rv_R1 = 0, rv_Rn = 0, rv_Fn = 0, rv_steps_max = 0;
+    long long rv_blocks = 0;     // blocks the stage has processed since it was set up: the big steps fall on multiples of kRvBig
+    int last_rv_steps = 0;       // big-partition steps the last call ran
+    float2 *d_rv_tw1 = nullptr, *d_rv_hspec1 = nullptr, *d_rv_fdl1 = nullptr, *d_rv_ybig = nullptr;
+    float *d_rv_dryring = nullptr, *d_rv_fut = nullptr;
     SrcSignal *d_sigs_wet = nullptr;  // [S] the wet rings as the spatialiser's signals
 };
 
@@ -247,9 +258,46 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     R.Wr = e->rv_Wr;
     R.head = e->rv_head;
     R.mac_form = e->rv_form;
-    JF_HIP(e, launch_reverb(R, e->stream, &e->last_rv_form));
+    ReverbBigParams G;
+    const bool big = e->rv_P1 > 0;
+    e->last_rv_steps = 0;
+    if (big) {
+        // the steps of the big partitions that fall into this call: before block j for every j = m kRvBig, m >= 1
+        const long long j0 = e->rv_blocks;
+        const int ph = (int)(j0 % kRvBig);
+        const int k1 = ph ? kRvBig - ph : (j0 == 0 ? kRvBig : 0);  // first block of the call with a step in front of it
+        const int n1 = k1 < K ? (K - 1 - k1) / kRvBig + 1 : 0;
+        const long long m_first = (j0 + k1) / kRvBig;
+        const int B1 = e->rv_B1;
+        R.dryring = e->d_rv_dryring;
+        R.Rd = e->rv_Rn * B1;
+        R.dry_pos0 = (int)((j0 * e->B) % R.Rd);
+        R.fut = e->d_rv_fut;
+        R.F = e->rv_Fn * B1;
+        R.fut_pos0 = (int)((j0 * e->B) % R.F);
+        G.tw1 = e->d_rv_tw1;
+        G.dryring = e->d_rv_dryring;
+        G.fdl1 = e->d_rv_fdl1;
+        G.hspec1 = e->d_rv_hspec1;
+        G.ybig = e->d_rv_ybig;
+        G.fut = e->d_rv_fut;
+        G.S = e->S;
+        G.B1 = B1;
+        G.P1 = e->rv_P1;
+        G.R1 = e->rv_R1;
+        G.Rn = e->rv_Rn;
+        G.Fn = e->rv_Fn;
+        G.n_steps = n1;
+        G.slot_first = (int)(m_first % e->rv_R1);
+        G.dblock_first = (int)(((m_first - 2) % e->rv_Rn + e->rv_Rn) % e->rv_Rn);
+        G.fut_first = (int)(m_first % e->rv_Fn);
+        if (n1 > e->rv_steps_max) return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
+        e->last_rv_steps = n1;
+    }
+    JF_HIP(e, launch_reverb(R, big ? &G : nullptr, e->stream, &e->last_rv_form));
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
+    e->rv_blocks += K;
     return JF_OK;
 }
 
@@ -389,11 +437,21 @@ void free_reverb(jf_engine *e) {
         e->d_rv_prev[i] = nullptr;
         e->d_rv_count[i] = nullptr;
     }
+    (void)hipFree(e->d_rv_tw1);
+    (void)hipFree(e->d_rv_hspec1);
+    (void)hipFree(e->d_rv_fdl1);
+    (void)hipFree(e->d_rv_ybig);
+    (void)hipFree(e->d_rv_dryring);
+    (void)hipFree(e->d_rv_fut);
+    e->d_rv_tw1 = e->d_rv_hspec1 = e->d_rv_fdl1 = e->d_rv_ybig = nullptr;
+    e->d_rv_dryring = e->d_rv_fut = nullptr;
     e->d_rv_hspec = nullptr;
     e->d_rv_fdl = nullptr;
     e->d_rv_wet = nullptr;
     e->d_sigs_wet = nullptr;
     e->rv_P = e->rv_Rg = e->rv_Wr = e->rv_head = 0;
+    e->rv_P_total = e->rv_P1 = e->rv_B1 = e->rv_R1 = e->rv_Rn = e->rv_Fn = e->rv_steps_max = 0;
+    e->rv_blocks = 0;
 }
 
 // zero one source's (or every source's, src < 0) window, counters and reverb state
@@ -410,6 +468,13 @@ int reset_sources(jf_engine *e, int src) {
         JF_HIP(e, hipMemset(e->d_rv_wet + s0 * e->rv_Wr, 0, sizeof(float) * e->rv_Wr * ns));
         JF_HIP(e, hipMemset(e->d_rv_prev[p] + s0 * B, 0, sizeof(float) * B * ns));
         JF_HIP(e, hipMemset(e->d_rv_count[p] + s0, 0, sizeof(int) * ns));
+        if (e->rv_P1 > 0) {  // the big partitions' delay line, the dry ring they read and what they have promised the next blocks
+            const size_t B1 = (size_t)e->rv_B1;
+            JF_HIP(e, hipMemset(e->d_rv_fdl1 + s0 * e->rv_R1 * B1, 0, sizeof(float2) * e->rv_R1 * B1 * ns));
+            JF_HIP(e, hipMemset(e->d_rv_fdl1 + (size_t)e->S * e->rv_R1 * B1 + s0 * e->rv_R1, 0, sizeof(float2) * e->rv_R1 * ns));
+            JF_HIP(e, hipMemset(e->d_rv_dryring + s0 * e->rv_Rn * B1, 0, sizeof(float) * e->rv_Rn * B1 * ns));
+            JF_HIP(e, hipMemset(e->d_rv_fut + s0 * e->rv_Fn * B1, 0, sizeof(float) * e->rv_Fn * B1 * ns));
+        }
     }
     return JF_OK;
 }
@@ -953,7 +1018,16 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     if (B != 64 && B != 128 && B != 256)
         return fail(e, JF_ERR_ARG, "reverb needs frames_per_buffer of 64, 128 or 256 (FFT of 2 blocks)");
     const size_t S = (size_t)e->S;
-    const int P = (int)((n_ir + B - 1) / B);
+    const int P_total = (int)((n_ir + B - 1) / B);
+    // Non-uniform partitioning for a response of at least three big partitions (unless a uniform form is pinned, or
+    // jf_debug_set_reverb_partitioning says otherwise): the stage below is then the head of kRvBig partitions of B
+    const bool nonuniform = e->rv_partitioning == 2 ||
+                            (e->rv_partitioning == 0 && e->rv_form == 0 && P_total >= 3 * kRvBig);
+    const int P = nonuniform ? kRvBig : P_total;
+    const int B1 = kRvBig * B;
+    const int P1 = nonuniform ? (int)((n_ir > (size_t)B1 ? n_ir - B1 : 0) + B1 - 1) / B1 : 0;
+    const int steps_max = e->maxK / kRvBig + 1;          // big-partition steps one call can contain
+    const int R1 = P1 + steps_max + 2, Rn = steps_max + 3, Fn = steps_max + 2;
     const int Rg = P + e->maxK;                          // slots a call may still read + the ones it writes
     const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
     float *d_ir = nullptr;
@@ -976,6 +1050,23 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
         JF_HIP(e, hipMemcpy(d_ir, ir, sizeof(float) * n_ir, hipMemcpyHostToDevice));
         // 1/B: normalisation of the B-point inverse used for the 2B-point real transform
         JF_HIP(e, launch_reverb_ir(d_ir, (int)n_ir, P, B, gain / (float)B, e->d_tw, e->d_rv_hspec, e->stream));
+        if (P1 > 0) {
+            // twiddles exp(+2 pi i j / (2 B1)), j < B1, from double
+            std::vector<float2> tw1((size_t)B1);
+            for (int j = 0; j < B1; j++) {
+                const double a = 3.14159265358979323846264338327950288 * j / (double)B1;
+                tw1[j] = make_float2((float)cos(a), (float)sin(a));
+            }
+            JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * B1));
+            JF_HIP(e, hipMemcpy(e->d_rv_tw1, tw1.data(), sizeof(float2) * B1, hipMemcpyHostToDevice));
+            JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * ((size_t)P1 * B1 + P1)));
+            JF_HIP(e, hipMalloc(&e->d_rv_fdl1, sizeof(float2) * (S * R1 * B1 + S * R1)));
+            JF_HIP(e, hipMalloc(&e->d_rv_ybig, sizeof(float2) * S * steps_max * B1));
+            JF_HIP(e, hipMalloc(&e->d_rv_dryring, sizeof(float) * S * Rn * B1));
+            JF_HIP(e, hipMalloc(&e->d_rv_fut, sizeof(float) * S * Fn * B1));
+            // 1/B1: normalisation of the B1-point inverse used for the 2 B1-point real transform
+            JF_HIP(e, launch_reverb_big_ir(d_ir, (int)n_ir, B1, P1, B1, gain / (float)B1, e->d_rv_tw1, e->d_rv_hspec1, e->stream));
+        }
         JF_HIP(e, hipStreamSynchronize(e->stream));
         return JF_OK;
     };
@@ -990,6 +1081,14 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     e->rv_Rg = Rg;
     e->rv_Wr = Wr;
     e->rv_head = 0;
+    e->rv_P_total = P_total;
+    e->rv_P1 = P1;
+    e->rv_B1 = P1 > 0 ? B1 : 0;
+    e->rv_R1 = R1;
+    e->rv_Rn = Rn;
+    e->rv_Fn = Fn;
+    e->rv_steps_max = steps_max;
+    e->rv_blocks = 0;
     return reset_sources(e, -1);
     });
 }
@@ -1254,6 +1353,22 @@ int jf_debug_read_table_rows(jf_engine *e, int first_row, int n, float *out) {
     });
 }
 
+int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
+    return jf_guard([&]() -> int {
+    if (!e || how < 0 || how > 2) return JF_ERR_ARG;
+    e->rv_partitioning = how;  // in effect from the next jf_reverb_set_ir
+    return JF_OK;
+    });
+}
+
+int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps) {
+    if (!e) return JF_ERR_ARG;
+    if (head) *head = e->rv_P;
+    if (big) *big = e->rv_P1;
+    if (big_taps) *big_taps = e->rv_B1;
+    return e->rv_P_total;
+}
+
 int jf_debug_read_table(jf_engine *e, float *out) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
@@ -1349,6 +1464,11 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         if (!e->last_rt && !e->last_prep_skipped) k = "prep_kernel;";
         if (e->rv_P > 0) {
             if (e->last_rv_form != 4) k += "reverb_fft_kernel<" + bs + ">;";  // 4: stage A runs inside the MAC kernel
+            if (e->last_rv_steps > 0) {  // the big partitions' steps of the call (non-uniform partitioning)
+                const std::string b1 = std::to_string(e->rv_B1);
+                k += "reverb_big_fft_kernel<" + b1 + ">;reverb_big_mac_kernel<" + b1 + "," + (e->last_rv_steps >= 4 ? "16" : "1") +
+                     ">;reverb_big_ifft_kernel<" + b1 + ">;";
+            }
             const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
             if (e->last_rv_form == 3) k += "reverb_mac_tiled_kernel<" + bs + "," + std::to_string(tile) + ">;";
             else if (e->last_rv_form == 4) k += "reverb_mac_kernel<" + bs + ",1,true>;";

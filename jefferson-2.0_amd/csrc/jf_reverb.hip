@@ -11,6 +11,13 @@
 // HBM-bound part: P x B x 8 bytes of FDL per source-block (690 x 1 KB at B = 128, 2 s IR).
 //
 // Spectra are stored packed: B complex per partition, bin 0 holding (X[0].re, X[B].re).
+//
+// NON-UNIFORM PARTITIONING (round 4; ReverbBigParams in jf_device.h): for a long impulse response the stage above is only
+// the HEAD -- the first kRvBig = 16 partitions of B -- and the rest of the response is cut into partitions of B1 = 16 B
+// taps: every 16 blocks one transform of 2 B1 samples, P1 = ceil((n_ir - B1) / B1) multiply-accumulates per bin (43
+// instead of 690 x 16 for the 2 s response at B = 128) and one inverse give the tail's contribution to the NEXT 16 blocks
+// (reverb_big_*), which the head's finishing step adds.  The reference's own form is ONE product over the whole signal
+// (cudaPart.cu:87-153: ~log N work per sample); uniform partitions cost P operations per sample, two sizes P / 16 + 16.
 #include <hip/hip_runtime.h>
 
 #include "jf_device.h"
@@ -116,6 +123,11 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
             xv[c] = v;
         }
         a[m] = make_float2(xv[0], xv[1]);
+        // non-uniform partitioning: the block's dry samples by absolute time (the big-partition transform reads them there;
+        // the ring length is a multiple of B, so a block never wraps inside)
+        if (P.dryring != nullptr && 2 * m >= B)
+            *reinterpret_cast<float2 *>(P.dryring + (size_t)s * P.Rd + (size_t)((P.dry_pos0 + k * B) % P.Rd) + (2 * m - B)) =
+                make_float2(xv[0], xv[1]);
     }
     if (k == P.K - 1) {
         // state for the next call: the last dry block and the advanced play position
@@ -219,9 +231,15 @@ JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const Reve
     const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
     float *wet = P.wet + (size_t)s * P.Wr;
     const int w0 = (int)(((long long)c0 + (long long)k * B) % P.Wr);
+    // non-uniform partitioning: + what the partitions behind the head contribute to this block (reverb_big_*)
+    const float *fut = P.fut != nullptr ? P.fut + (size_t)s * P.F + (size_t)((P.fut_pos0 + k * B) % P.F) : nullptr;
     for (int m = B / 2 + lane; m < B; m += 64) {
-        const float2 v = zt[m];
+        float2 v = zt[m];
         const int n = 2 * m - B;  // 0..B-2, even; the ring length is a multiple of B, w0 too
+        if (fut != nullptr) {
+            const float2 f = *reinterpret_cast<const float2 *>(fut + n);
+            v = make_float2(v.x + f.x, v.y + f.y);
+        }
         *reinterpret_cast<float2 *>(wet + w0 + n) = v;
     }
 }
@@ -459,6 +477,212 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
         if (k0 + i < P.K) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
 }
 
+// ------------------------------------------------- big partitions (level 1) --
+// Complex FFT of NPT points by a whole workgroup of NT threads in LDS: radix-2 Stockham autosort, ping-pong between a and b,
+// a barrier per pass; returns the buffer holding the result in natural order.  T2[j] = exp(+2 pi i j / (2 NPT)), j < NPT.
+template <int NPT, int DIR, int NT>
+JF_DEV float2 *cfft_wg(float2 *a, float2 *b, const float2 *__restrict__ T2, int tid) {
+#pragma unroll 1
+    for (int p = 1; p < NPT; p <<= 1) {
+        const int tstep = NPT / p;  // exp(-+ 2 pi i k / (2p)) = T2[k NPT / p]
+        for (int j = tid; j < NPT / 2; j += NT) {
+            const int k = j & (p - 1);
+            const float2 u0 = a[j];
+            const float2 w = T2[k * tstep];
+            const float2 u1 = DIR > 0 ? rv_mul(a[j + NPT / 2], w) : rv_mulc(a[j + NPT / 2], w);
+            const int dst = ((j - k) << 1) + k;
+            b[dst] = rv_add(u0, u1);
+            b[dst + p] = rv_sub(u0, u1);
+        }
+        __syncthreads();
+        float2 *t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+constexpr int kBigThreads = 256;
+
+// Step i of the call for source s: spectrum of the last 2 B1 dry samples into fdl1 (packed: bin 0 = (X[0], X[B1])).
+template <int B1>
+__global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
+    __shared__ float2 s_a[B1], s_b[B1];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
+    const float *ring = P.dryring + (size_t)s * P.Rn * B1;
+    // the two big blocks (m - 2, m - 1) as they lie in the ring: each contiguous, the second possibly wrapped to the front
+    const int blk0 = (P.dblock_first + i) % P.Rn, blk1 = (blk0 + 1) % P.Rn;
+    const float2 *x0 = reinterpret_cast<const float2 *>(ring + (size_t)blk0 * B1);
+    const float2 *x1 = reinterpret_cast<const float2 *>(ring + (size_t)blk1 * B1);
+    for (int m = tid; m < B1 / 2; m += kBigThreads) {
+        s_a[m] = x0[m];            // z[m] = x[2m] + j x[2m + 1]
+        s_a[m + B1 / 2] = x1[m];
+    }
+    __syncthreads();
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, P.tw1, tid);
+    const int slot = (P.slot_first + i) % P.R1;
+    float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
+    for (int q = tid; q < B1; q += kBigThreads) {
+        const float2 zk = Z[q];
+        const float2 zm = Z[(B1 - q) & (B1 - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 wo = rv_mulc(o, P.tw1[q]);
+        float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+        if (q == 0) {
+            x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
+            P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
+        }
+        out[q] = x;
+    }
+}
+
+// Y_m = sum_q X_{m-q} H_q for a tile of KB consecutive steps of one source: a sliding window of KB spectra in registers, per
+// partition ONE new X load and one H load feed KB multiply-accumulates (the scheme of reverb_mac_tiled_kernel).  A wave
+// covers 64 bins (one per lane) of ALL partitions, in ascending order -- no reduction between waves, and the sums are
+// the same whatever KB is.  The packed pair in bin 0 is carried as if it were complex; reverb_big_ifft_kernel recomputes it.
+constexpr int kBigMacWaves = 8;
+template <int B1, int KB>
+__global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const ReverbBigParams P) {
+    constexpr int WGS_PER_SPEC = B1 / (64 * kBigMacWaves);  // workgroups side by side over the bins
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = blockIdx.x % WGS_PER_SPEC;
+    const int rest = blockIdx.x / WGS_PER_SPEC;
+    const int n_tiles = (P.n_steps + KB - 1) / KB;
+    const int s = rest / n_tiles, i0 = (rest - s * n_tiles) * KB;  // first step of the tile
+    const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
+    const char *hp = reinterpret_cast<const char *>(P.hspec1);
+    unsigned voff = 8u * (unsigned)(64 * (kBigMacWaves * slice + wave) + lane);
+    asm volatile("" : "+v"(voff));
+    auto load_at = [&](const char *base) {
+        const float2 *q = reinterpret_cast<const float2 *>(base + voff);
+        return rv_v2{q->x, q->y};
+    };
+    auto slot_of = [&](int u) {  // slot of the spectrum of step (tile's first) + u (u may be far in the past)
+        int slot = (P.slot_first + i0 + u) % P.R1;
+        return slot < 0 ? slot + P.R1 : slot;
+    };
+    rv_v2 acc[KB], xr[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
+#pragma unroll
+    for (int i = 1; i < KB; i++) xr[i] = load_at(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8));  // X(i), i = 1 .. KB-1
+    int xslot = slot_of(0);
+    auto step = [&](int j) {  // j = q mod KB, a constant after unrolling
+        const rv_v2 h = load_at(hp);
+        xr[(KB - j) % KB] = load_at(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
+        xslot = xslot == 0 ? P.R1 - 1 : xslot - 1;
+        hp += (size_t)B1 * 8;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const rv_v2 x = xr[(i + KB - j) % KB];
+            acc[i].x = __builtin_fmaf(x.x, h.x, acc[i].x);
+            acc[i].y = __builtin_fmaf(x.x, h.y, acc[i].y);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const rv_v2 x = xr[(i + KB - j) % KB];
+            acc[i].x = __builtin_fmaf(-x.y, h.y, acc[i].x);
+            acc[i].y = __builtin_fmaf(x.y, h.x, acc[i].y);
+        }
+    };
+    int q0 = 0;
+    for (; q0 + KB <= P.P1; q0 += KB) {
+#pragma unroll
+        for (int j = 0; j < KB; j++) step(j);
+    }
+#pragma unroll
+    for (int j = 0; j < KB; j++)
+        if (q0 + j < P.P1) step(j);  // wave-uniform
+    float2 *y = P.ybig + ((size_t)s * P.n_steps + i0) * B1 + (voff >> 3);
+#pragma unroll
+    for (int i = 0; i < KB; i++)
+        if (i0 + i < P.n_steps) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
+}
+
+// Products of step i of source s -> the B1 samples the partitions behind the head contribute to the next kRvBig blocks.
+template <int B1>
+__global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
+    __shared__ float2 s_a[B1], s_b[B1];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
+    const float2 *y = P.ybig + ((size_t)s * P.n_steps + i) * B1;
+    for (int q = tid; q < B1; q += kBigThreads) s_b[q] = y[q];
+    // the true packed pair of bin 0: sum_q X0[m - q] .* H0[q] from the compact copies, wave 0's lanes over the partitions
+    if (tid < 64) {
+        const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
+        const float2 *h0 = P.hspec1 + (size_t)P.P1 * B1;
+        float2 y0 = make_float2(0.f, 0.f);
+        for (int q = tid; q < P.P1; q += 64) {
+            int slot = (P.slot_first + i - q) % P.R1;
+            if (slot < 0) slot += P.R1;
+            const float2 x = x0[slot], h = h0[q];
+            y0.x += x.x * h.x;
+            y0.y += x.y * h.y;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            y0.x += __shfl_xor(y0.x, m);
+            y0.y += __shfl_xor(y0.y, m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) s_b[0] = y0;  // (wave 0 itself stored s_b[0] above: same wave, program order)
+    }
+    __syncthreads();
+    // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2
+    for (int q = tid; q < B1; q += kBigThreads) {
+        const float2 yk = s_b[q];
+        const float2 ym = s_b[(B1 - q) & (B1 - 1)];
+        float2 z;
+        if (q == 0) {
+            z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));
+        } else {
+            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+            const float2 o = rv_mul(d, P.tw1[q]);
+            z = make_float2(e.x - o.y, e.y + o.x);
+        }
+        s_a[q] = z;
+    }
+    __syncthreads();
+    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, P.tw1, tid);
+    // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
+    float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
+    for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[m];
+}
+
+// Partition spectra of level 1: one workgroup per partition q: rfft([h[T0 + q B1 .. + B1), zeros]) * scale, packed.
+template <int B1>
+__global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float *__restrict__ ir, int n_ir, int t0, float scale,
+                                                                   const float2 *__restrict__ tw1, float2 *__restrict__ hspec1,
+                                                                   float2 *__restrict__ h0 /* [P1] compact bin-0 pairs */) {
+    __shared__ float2 s_a[B1], s_b[B1];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x;
+    for (int m = tid; m < B1; m += kBigThreads) {
+        const int n = 2 * m;
+        const long long i0 = (long long)t0 + (long long)q0 * B1 + n, i1 = i0 + 1;
+        const float a0 = (n < B1 && i0 < n_ir) ? ir[i0] : 0.0f;
+        const float a1 = (n + 1 < B1 && i1 < n_ir) ? ir[i1] : 0.0f;
+        s_a[m] = make_float2(a0, a1);
+    }
+    __syncthreads();
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw1, tid);
+    for (int q = tid; q < B1; q += kBigThreads) {
+        const float2 zk = Z[q];
+        const float2 zm = Z[(B1 - q) & (B1 - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 wo = rv_mulc(o, tw1[q]);
+        float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+        if (q == 0) x = make_float2(zk.x + zk.y, zk.x - zk.y);
+        hspec1[(size_t)q0 * B1 + q] = make_float2(x.x * scale, x.y * scale);
+        if (q == 0) h0[q0] = make_float2(x.x * scale, x.y * scale);
+    }
+}
+
 // ------------------------------------------------------------- IR spectra --
 // One wavefront per partition p: rfft([h_p (B taps), zeros]) * scale, packed.
 template <int B>
@@ -517,31 +741,74 @@ static void launch_mac_tiled(const ReverbParams &P, hipStream_t st) {
 }
 // Form of stage B by the amount of work in the call: block-tiled when the tiles alone fill the GPU,
 // else source-grouped, else (real-time calls) one workgroup per (block, source).
+hipError_t launch_reverb_big(const ReverbBigParams &P, hipStream_t st);
+
+// big: the big-partition steps of this call (non-uniform partitioning), or null
 template <int B, int T, int KB>
-static int launch_mac_any(const ReverbParams &P, hipStream_t st) {
+static int launch_mac_any(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st) {
     const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
     const long long tiles = (long long)((P.K + KB - 1) / KB) * P.S;
     const int form = (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) ? 3
                      : (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) ? 2
                                                                                                       : 1;
     if (form == 1 && P.K == 1 && force != 1) {  // a call of one block: stage A inside the kernel (pinning form 1 keeps two kernels)
+        if (big) (void)launch_reverb_big(*big, st);  // a step due at this block needs only the samples before it
         hipLaunchKernelGGL((reverb_mac_kernel<B, 1, true>), dim3(P.S), dim3(64 * kMacWaves), 0, st, P);
         return 4;
     }
     launch_fft<B>(P, st);
+    if (big) (void)launch_reverb_big(*big, st);  // behind the transforms (they fill the dry ring), before the finishing steps
     if (form == 3) launch_mac_tiled<B, KB>(P, st);
     else if (form == 2) launch_mac<B, T>(P, st);
     else launch_mac<B, 1>(P, st);
     return form;
 }
 
+hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
+                                float2 *d_hspec1, hipStream_t st) {
+    float2 *h0 = d_hspec1 + (size_t)P1 * B1;
+    switch (B1) {
+    case 1024: hipLaunchKernelGGL(reverb_big_ir_kernel<1024>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
+    case 2048: hipLaunchKernelGGL(reverb_big_ir_kernel<2048>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
+    case 4096: hipLaunchKernelGGL(reverb_big_ir_kernel<4096>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// The big-partition steps of one call: transforms, products (tiles of 16 steps when the call has several, else single
+// steps), inverses.  Must run behind the head's forward transforms of the same call (they fill the dry ring) and before its
+// finishing step (which adds `fut`).
+template <int B1>
+static void launch_big(const ReverbBigParams &P, hipStream_t st) {
+    hipLaunchKernelGGL(reverb_big_fft_kernel<B1>, dim3(P.n_steps * P.S), dim3(kBigThreads), 0, st, P);
+    constexpr int per_spec = B1 / (64 * kBigMacWaves);
+    if (P.n_steps >= 4) {
+        const int tiles = (P.n_steps + 15) / 16;
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec * tiles * P.S), dim3(64 * kBigMacWaves), 0, st, P);
+    } else {
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(per_spec * P.n_steps * P.S), dim3(64 * kBigMacWaves), 0, st, P);
+    }
+    hipLaunchKernelGGL(reverb_big_ifft_kernel<B1>, dim3(P.n_steps * P.S), dim3(kBigThreads), 0, st, P);
+}
+hipError_t launch_reverb_big(const ReverbBigParams &P, hipStream_t st) {
+    if (P.n_steps <= 0) return hipSuccess;
+    switch (P.B1) {
+    case 1024: launch_big<1024>(P, st); break;
+    case 2048: launch_big<2048>(P, st); break;
+    case 4096: launch_big<4096>(P, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // form_used: 1, 2, 3 as above (after reverb_fft_kernel); 4 = form 1 with stage A fused in (no reverb_fft_kernel)
-hipError_t launch_reverb(const ReverbParams &P, hipStream_t st, int *form_used) {
+hipError_t launch_reverb(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st, int *form_used) {
     int form = 0;
     switch (P.B) {
-    case 64: form = launch_mac_any<64, 4, 16>(P, st); break;
-    case 128: form = launch_mac_any<128, 4, 16>(P, st); break;
-    case 256: form = launch_mac_any<256, 2, 8>(P, st); break;
+    case 64: form = launch_mac_any<64, 4, 16>(P, big, st); break;
+    case 128: form = launch_mac_any<128, 4, 16>(P, big, st); break;
+    case 256: form = launch_mac_any<256, 2, 8>(P, big, st); break;
     default: return hipErrorInvalidValue;
     }
     if (form_used) *form_used = form;

@@ -217,12 +217,14 @@ def _reverb_model_blocks(hrir, B, K, ir, gain, sig, pos_s):
     return p[0]
 
 
-@pytest.mark.parametrize("S,K,form", [(16, 32, 3), (256, 32, 0), (256, 256, 0)])
-def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K, form):
+@pytest.mark.parametrize("S,K,form,part", [(16, 32, 3, 0), (256, 32, 0, 1), (256, 32, 0, 0), (256, 256, 0, 0)])
+def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K, form, part):
     """BASELINE.json configs[4]: B = 128, 2.0 s impulse response = 690 partitions.  (16 sources x 32 blocks, form 3
     pinned), (256 sources x 32 blocks: one pass of tiles) and (256 sources x 256 blocks per call -- the shape
     `bench.py --reverb` times: a delay-line ring of 690 + 256 slots, 16 tiles per source), each as TWO consecutive
-    calls so that the delay line, the wet ring and the windows carry over.  Per-source blocks of sampled sources
+    calls so that the delay line, the wet ring and the windows carry over.  form 3 pinned and part = 1: uniform partitions
+    (690 multiply-accumulates per bin and block, the tiled kernel over all of them); part = 0, form 0: what the engine
+    takes by itself for this response -- 16 partitions of 128 (the same tiled kernel) + 43 of 2048.  Per-source blocks of sampled sources
     against the float32 C oracle with its reverb stage (jfo_reverb_set_ir) and against gain * float64 convolution ->
     float64 spatialiser model; the mix as the ordered sum of the blocks."""
     B = 128
@@ -233,10 +235,12 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     sigs = [np.roll(castanets, 997 * s)[: 30000 + 64 * s] for s in range(S)]
     e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
     e.set_reverb_form(form)
+    e.set_reverb_partitioning(part)
     e.set_source_group(1)            # per-source blocks
     for s in range(S):
         e.set_signal(s, sigs[s])
     e.set_reverb(ir, gain)
+    assert e.reverb_partitions() == ((690, 690, 0, 0) if (form or part == 1) else (690, 16, 43, 2048))
     e.upload_positions(pos)
     parts, mixes = [], []
     for c in range(2):               # two calls: the delay line and the wet ring carry over
@@ -244,6 +248,8 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
         e.synchronize()
         if K >= 16:
             assert "reverb_mac_tiled_kernel<128,16>" in e.last_kernels()
+        if not form and part == 0:
+            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in e.last_kernels(), e.last_kernels()
         parts.append(e.read_device(e.partial_device_ptr(), (K, S, 2 * B)))
         mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
     e.close()

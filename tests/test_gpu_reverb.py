@@ -34,9 +34,10 @@ def _wet_stream(dry, n_total, ir, gain):
     return gain * wet
 
 
-def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False, form=0):
+def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False, form=0, part=0):
     eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max_k)
     eng.set_reverb_form(form)
+    eng.set_reverb_partitioning(part)
     for s in range(S):
         eng.set_signal(s, sigs[s])
     eng.set_reverb(ir, gain)
@@ -179,3 +180,112 @@ def test_reverb_off_and_unsupported_block(jf, hrir, castanets):
         assert np.array_equal(a.process_block(), b.process_block())
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------- non-uniform partitioning --
+@pytest.mark.parametrize("B,n_big,ragged", [(128, 3, 0), (128, 7, 901), (64, 5, 17), (256, 3, 1000)])
+def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, castanets, B, n_big, ragged):
+    """A head of 16 partitions of B + partitions of 16 B behind it (jf_debug_set_reverb_partitioning; the default for long
+    responses) against gain * float64 convolution -> float64 spatialiser model and against the engine with uniform
+    partitions, over 70 blocks = four steps of the big partitions, as ONE run of calls of ragged sizes (1, 5, 16, 17, 31
+    blocks: steps at the start, in the middle and at the end of a call, calls without any).  The response is n_big big
+    partitions long (+ a ragged rest)."""
+    S, K = 3, 70
+    n_ir = 16 * B + n_big * 16 * B - (16 * B - ragged if ragged else 0)
+    ir = _ir(n_ir, decay=3.0)
+    gain = 0.6
+    sigs = [castanets[5000 * s: 5000 * s + 12000 + 91 * s] for s in range(S)]
+    pos = _positions(jf, S, K)
+    want = _model(hrir, B, S, K, ir, gain, sigs, pos)
+    P = -(-n_ir // B)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * S
+    outs = {}
+    for part in (2, 1):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=31)
+        e.set_reverb_partitioning(part)
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+        e.set_reverb(ir, gain)
+        n, head, big, taps = e.reverb_partitions()
+        assert n == P and (head, big, taps) == ((16, -(-(n_ir - 16 * B) // (16 * B)), 16 * B) if part == 2 else (P, 0, 0))
+        got, b0 = [], 0
+        for k in (1, 5, 16, 17, 31):          # 70 blocks
+            got.append(e.process_batch(pos[b0:b0 + k]))
+            b0 += k
+        assert b0 == K
+        outs[part] = np.concatenate(got)
+        e.close()
+    assert np.abs(want).max() > 0.05
+    assert np.abs(outs[2] - want).max() <= tol
+    assert np.abs(outs[1] - want).max() <= tol
+    assert not np.array_equal(outs[1], outs[2])      # really another decomposition of the same convolution
+    # the tail matters: a response cut behind the head gives something else
+    cut = _model(hrir, B, S, K, ir[:16 * B], gain, sigs, pos)
+    assert np.abs(cut - want).max() > 100 * tol
+
+
+def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, castanets):
+    """Per-block calls (one step of the big partitions every 16th call, single-step product kernel) against batch calls
+    (several steps per call, 16-step tiles) with the head's form pinned for both: bit-identical -- the big partitions add
+    their products in the same order whatever the tile.  And the 2 s response of configs[4] takes the non-uniform form by
+    default: 16 + 43 partitions instead of 690."""
+    B, S, K = 128, 2, 80
+    ir = _ir(16 * B * 6 + 333, decay=3.0)
+    sigs = [castanets[:9000], castanets[10000:17000]]
+    pos = _positions(jf, S, K)
+    a = _run(jf, hrir, B, S, K, 80, ir, 0.5, sigs, pos, form=1, part=2)                   # one call: 4 steps, tiled
+    b = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True, form=1, part=2)    # 80 calls
+    assert np.array_equal(a, b)
+    c = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)                    # default: fused head kernel
+    want = _model(hrir, B, S, K, ir, 0.5, sigs, pos)
+    tol = (2e-7 + 1e-7 * np.sqrt(-(-len(ir) // B))) * max(1.0, np.abs(want).max()) * S
+    assert np.abs(c - want).max() <= tol and np.abs(a - want).max() <= tol
+    e = jf.Engine(128, 512, 1, hrir=hrir)
+    e.set_reverb(_ir(88200), 1.0)
+    assert e.reverb_partitions() == (690, 16, 43, 2048)
+    for _ in range(17):
+        e.process_block()
+    ks = e.last_kernels()          # the 17th block has a step in front of it
+    assert "reverb_big_fft_kernel<2048>" in ks and "reverb_big_mac_kernel<2048,1>" in ks and "reverb_mac_kernel<128,1,true>" in ks, ks
+    e.process_block()
+    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
+    e.close()
+
+
+def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
+    """A source reset, a new signal and a pause in the middle of a run, between steps of the big partitions: the
+    non-uniform engine follows the uniform one (same calls) within the float32 tolerance of two decompositions."""
+    B, S = 128, 3
+    ir = _ir(16 * B * 4 + 77, decay=3.0)
+    P = -(-len(ir) // B)
+    engines = []
+    for part in (2, 1):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=8)
+        e.set_reverb_partitioning(part)
+        for s_ in range(S):
+            e.set_signal(s_, castanets[3000 * s_: 3000 * s_ + 20000])
+            e.set_spherical(s_, 10 * s_, 50 * s_, 0.7)
+        e.set_reverb(ir, 0.7)
+        engines.append(e)
+    worst = peak = 0.0
+    for k in range(120):
+        if k == 37:
+            for e in engines:
+                e.reset(1)                                  # this source starts over; the others go on
+        if k == 55:
+            for e in engines:
+                e.set_signal(2, castanets[40000:47000])     # the old samples stay in the delay lines
+        if k in (70, 75):
+            for e in engines:
+                e.set_pause(k == 70)                        # nothing is consumed while paused
+        if k % 9 == 0:
+            for e in engines:
+                for s_ in range(S):
+                    e.set_spherical(s_, 10 * s_, (50 * s_ + k) % 360, 0.7)
+        y = [e.process_block() for e in engines]
+        worst = max(worst, float(np.abs(y[0] - y[1]).max()))
+        peak = max(peak, float(np.abs(y[1]).max()))
+    for e in engines:
+        e.close()
+    assert peak > 0.05
+    assert worst <= 2 * (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, peak) * S
