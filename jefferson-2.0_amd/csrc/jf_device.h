@@ -178,29 +178,56 @@ struct ReverbParams {
     int Rd = 0, dry_pos0 = 0;  // ring length; position of this call's first sample
     const float *fut = nullptr;  // [S][F] the tail's contribution by absolute sample time mod F
     int F = 0, fut_pos0 = 0;
+    // blocks copy_lo <= k < copy_hi of the call only copy their samples to the dry ring (no transform): the blocks of a batch
+    // call whose output the big partitions form directly and whose small spectra nobody reads later (0, 0: none)
+    int copy_lo = 0, copy_hi = 0;
+    // the multiply-accumulate / finishing stage works on blocks kb .. kb + kn - 1 of the call (set by launch_reverb)
+    int kb = 0, kn = 0;
 };
 
-// Level 1 of the non-uniformly partitioned reverb: the impulse response behind its first kRvBig * B taps in partitions of
-// B1 = kRvBig * B taps (transform length 2 B1).  Whenever kRvBig blocks of input are complete (absolute block index
-// j = m kRvBig), step m transforms the last 2 B1 dry samples, multiplies the last P1 such spectra with the P1 partition spectra
-// and leaves the B1 output samples for the blocks j .. j + kRvBig - 1 in `fut` -- they are due from the next block on, so
-// nothing is ever late (Gardner's scheme with two sizes).  Per output sample P1 + kRvBig complex multiply-accumulates per bin
-// instead of P = P1 kRvBig + kRvBig, and the delay line is read once per kRvBig blocks.
+// The non-uniformly partitioned reverb's second level: partitions of B1 = kRvBig * B taps (transform length 2 B1).
+//   X_m   = spectrum of the dry samples of big blocks m - 2 and m - 1 (absolute block indices 16 (m - 2) .. 16 m - 1), formed
+//           as soon as block 16 m - 1 has been taken in;
+//   H'_0  = spectrum of the response's first B1 taps, H'_1 .. H'_P1 = of the B1-tap partitions behind them.
+// A block that is worked on its own (per-block calls, the ragged ends of batch calls) gets taps [0, B1) from the uniform stage
+// above -- kRvBig partitions of B, no latency -- and the rest from  TAIL(m) = sum_{q < P1} X_{m-q} H'_{1+q}, the B1 samples the
+// partitions behind the head contribute to big block m, which depend only on samples before it (Gardner's zero-latency scheme
+// with two sizes): per block P1 / 16 + 16 multiply-accumulates per bin instead of P = 16 P1 + 16.  A big block that lies
+// INSIDE a batch call needs no head at all:  FULL(m) = sum_{q <= P1} X_{m+1-q} H'_q  is its whole wet signal (uniform
+// partitioning at the big size; its input is all there), one transform pair per 16 blocks instead of 16 pairs.
 constexpr int kRvBig = 16;
 struct ReverbBigParams {
-    const float2 *tw1;      // exp(+2 pi i j / (2 B1)), j < B1, from double
-    const float *dryring;   // [S][Rd]
-    float2 *fdl1;           // [S][R1][B1] spectra of the steps (ring, slot = step index mod R1), + [S][R1] compact bin-0 pairs
-    const float2 *hspec1;   // [P1][B1] partition spectra, pre-scaled by gain / B1, + [P1] compact bin-0 pairs
-    float2 *ybig;           // [S][n_steps][B1] products of this call's steps (batch form)
-    float *fut;             // [S][F]
-    int S, B1, P1, R1;
-    int Rn;                 // dry ring length in big blocks (Rd / B1)
-    int Fn;                 // fut ring length in big blocks (F / B1)
-    int n_steps;            // steps of this call: m = m_first .. m_first + n_steps - 1
-    int slot_first;         // m_first mod R1
-    int dblock_first;       // (m_first - 2) mod Rn: ring block of the first of the two big blocks step m_first transforms
-    int fut_first;          // m_first mod Fn: where step m_first's output goes
+    const float2 *tw1;      // exp(+2 pi i j / (2 B1)), j < 2 B1 (a full circle), from double
+    const float *dryring;   // [S][Rn B1]
+    float2 *fdl1;           // [S][R1][B1] the X_m (ring, slot = m mod R1), + [S][R1] compact copies of their packed bin-0 pairs
+    const float2 *hspec1;   // [P1 + 1][B1] the H'_q, pre-scaled by gain / B1, + [P1 + 1] compact bin-0 pairs
+    float2 *ybig;           // [S][n_prod][B1] products of one launch
+    float *fut;             // [S][Fn B1] TAIL(m) at ring block m mod Fn
+    float *wet;             // [S][Wr] the wet ring (FULL(m) goes straight there)
+    const SrcState *st_in;  // count = wet-ring position of the call's first new sample
+    int S, B, B1, P1, R1, Rn, Fn, Wr;
+    // transforms: X_m for m = first .. first + n_tr - 1
+    int n_tr = 0;
+    int tr_slot_first = 0;    // first mod R1
+    int tr_dblock_first = 0;  // (first - 2) mod Rn
+    // products: Y_i = sum_{q < n_part} X_{anchor + i - q} H'_{h_first + q}, i < n_prod
+    int n_prod = 0;
+    int anchor_slot_first = 0;  // anchor mod R1
+    int h_first = 0, n_part = 0;
+    int to_wet = 0;             // 0: Y_i -> fut ring block (fut_first + i) mod Fn;  1: -> the wet ring, blocks wet_k0 + 16 i .. + 15 of the call
+    int fut_first = 0, wet_k0 = 0;
+};
+
+// What the reverb stage does in one call (host side; launch_reverb)
+struct ReverbPlan {
+    bool big = false;             // non-uniform partitioning
+    ReverbBigParams tail_early;   // TAIL(m) for the big block the call starts in (n_prod = 0: not needed)
+    ReverbBigParams transforms;   // n_tr
+    ReverbBigParams middle;       // FULL(m) of the big blocks inside the call (to_wet)
+    ReverbBigParams tail_late;    // TAIL(m) for the big block the call ends in
+    int n_ranges = 1;             // block ranges the uniform stage's multiply-accumulate works on
+    int kb[2] = {0, 0}, kn[2] = {0, 0};
+    int forms[2] = {0, 0};        // out: form each range took
 };
 
 }  // namespace jf

@@ -38,7 +38,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
                            int n_wgs, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
-hipError_t launch_reverb(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st, int *form_used);
+hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
                                 float2 *d_hspec1, hipStream_t st);
 int kernels_build_kind();
@@ -164,8 +164,9 @@ struct jf_engine {
     int rv_partitioning = 0;     // jf_debug_set_reverb_partitioning: 0 by length, 1 uniform, 2 non-uniform (at the next set_ir)
     int rv_P_total = 0;          // partitions of B the impulse response has (what rv_P is under uniform partitioning)
     int rv_P1 = 0, rv_B1 = 0, rv_R1 = 0, rv_Rn = 0, rv_Fn = 0, rv_steps_max = 0;
-    long long rv_blocks = 0;     // blocks the stage has processed since it was set up: the big steps fall on multiples of kRvBig
-    int last_rv_steps = 0;       // big-partition steps the last call ran
+    long long rv_blocks = 0;     // blocks the stage has processed since it was set up: big block m = blocks 16 m .. 16 m + 15
+    long long rv_fut_m = 0;      // TAIL(m) has been formed for every big block up to this one (big block 0 has none: zeros)
+    ReverbPlan last_plan;        // what the last call did (jf_debug_last_kernels)
     float2 *d_rv_tw1 = nullptr, *d_rv_hspec1 = nullptr, *d_rv_fdl1 = nullptr, *d_rv_ybig = nullptr;
     float *d_rv_dryring = nullptr, *d_rv_fut = nullptr;
     SrcSignal *d_sigs_wet = nullptr;  // [S] the wet rings as the spatialiser's signals
@@ -258,43 +259,97 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     R.Wr = e->rv_Wr;
     R.head = e->rv_head;
     R.mac_form = e->rv_form;
-    ReverbBigParams G;
-    const bool big = e->rv_P1 > 0;
-    e->last_rv_steps = 0;
-    if (big) {
-        // the steps of the big partitions that fall into this call: before block j for every j = m kRvBig, m >= 1
-        const long long j0 = e->rv_blocks;
-        const int ph = (int)(j0 % kRvBig);
-        const int k1 = ph ? kRvBig - ph : (j0 == 0 ? kRvBig : 0);  // first block of the call with a step in front of it
-        const int n1 = k1 < K ? (K - 1 - k1) / kRvBig + 1 : 0;
-        const long long m_first = (j0 + k1) / kRvBig;
-        const int B1 = e->rv_B1;
+    ReverbPlan plan;
+    plan.big = e->rv_P1 > 0;
+    if (plan.big) {
+        // Absolute block indices j0 .. j1 - 1; big block m = blocks 16 m .. 16 m + 15.
+        const long long j0 = e->rv_blocks, j1 = j0 + K;
+        const int B1 = e->rv_B1, R1 = e->rv_R1, Rn = e->rv_Rn, Fn = e->rv_Fn;
         R.dryring = e->d_rv_dryring;
-        R.Rd = e->rv_Rn * B1;
+        R.Rd = Rn * B1;
         R.dry_pos0 = (int)((j0 * e->B) % R.Rd);
         R.fut = e->d_rv_fut;
-        R.F = e->rv_Fn * B1;
+        R.F = Fn * B1;
         R.fut_pos0 = (int)((j0 * e->B) % R.F);
+        ReverbBigParams G;
         G.tw1 = e->d_rv_tw1;
         G.dryring = e->d_rv_dryring;
         G.fdl1 = e->d_rv_fdl1;
         G.hspec1 = e->d_rv_hspec1;
         G.ybig = e->d_rv_ybig;
         G.fut = e->d_rv_fut;
+        G.wet = e->d_rv_wet;
+        G.st_in = e->d_state[p];
         G.S = e->S;
+        G.B = e->B;
         G.B1 = B1;
         G.P1 = e->rv_P1;
-        G.R1 = e->rv_R1;
-        G.Rn = e->rv_Rn;
-        G.Fn = e->rv_Fn;
-        G.n_steps = n1;
-        G.slot_first = (int)(m_first % e->rv_R1);
-        G.dblock_first = (int)(((m_first - 2) % e->rv_Rn + e->rv_Rn) % e->rv_Rn);
-        G.fut_first = (int)(m_first % e->rv_Fn);
-        if (n1 > e->rv_steps_max) return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
-        e->last_rv_steps = n1;
+        G.R1 = R1;
+        G.Rn = Rn;
+        G.Fn = Fn;
+        G.Wr = e->rv_Wr;
+        auto mod = [](long long a, int n) { return (int)(((a % n) + n) % n); };
+        // X_m is formed in the call that takes in block 16 m - 1:  j0 < 16 m <= j1
+        const long long m_lo = j0 / kRvBig + 1, m_hi = j1 / kRvBig;
+        plan.transforms = G;
+        plan.transforms.n_tr = m_hi >= m_lo ? (int)(m_hi - m_lo + 1) : 0;
+        plan.transforms.tr_slot_first = mod(m_lo, R1);
+        plan.transforms.tr_dblock_first = mod(m_lo - 2, Rn);
+        // big blocks that lie inside the call: m = ma .. m_hi - 1, their wet signal is FULL(m), anchored at X_{m+1}
+        const long long ma = (j0 + kRvBig - 1) / kRvBig;
+        const int n_mid = m_hi > ma ? (int)(m_hi - ma) : 0;
+        plan.middle = G;
+        plan.middle.n_prod = n_mid;
+        plan.middle.anchor_slot_first = mod(ma + 1, R1);
+        plan.middle.h_first = 0;
+        plan.middle.n_part = e->rv_P1 + 1;
+        plan.middle.to_wet = 1;
+        plan.middle.wet_k0 = (int)(ma * kRvBig - j0);
+        // the other blocks go through the uniform stage (head) + TAIL of their big block
+        if (n_mid > 0) {
+            plan.n_ranges = 2;
+            plan.kb[0] = 0;
+            plan.kn[0] = (int)(ma * kRvBig - j0);
+            plan.kb[1] = (int)(m_hi * kRvBig - j0);
+            plan.kn[1] = K - plan.kb[1];
+            // of the middle's blocks only the last 15 are transformed (the state the next blocks read)
+            R.copy_lo = plan.kn[0];
+            R.copy_hi = plan.kb[1] - (kRvBig - 1);
+        } else {
+            plan.n_ranges = 1;
+            plan.kb[0] = 0;
+            plan.kn[0] = K;
+        }
+        auto tail_for = [&](long long m) {
+            ReverbBigParams T = G;
+            T.n_prod = 1;
+            T.anchor_slot_first = mod(m, R1);
+            T.h_first = 1;
+            T.n_part = e->rv_P1;
+            T.to_wet = 0;
+            T.fut_first = mod(m, Fn);
+            return T;
+        };
+        plan.tail_early = G;
+        plan.tail_late = G;
+        // TAIL of the big block the call starts in, if one of its blocks goes through the uniform stage and nobody has formed
+        // it yet (its X_m are all there: the block before it has been taken in)
+        const long long mb = j0 / kRvBig;
+        if (plan.kn[0] > 0 && e->rv_fut_m < mb) {
+            plan.tail_early = tail_for(mb);
+            e->rv_fut_m = mb;
+        }
+        // ... and of the big block the call ends in, if the call reaches into it behind a boundary it has passed itself
+        const bool late = n_mid > 0 ? plan.kn[1] > 0 : (m_hi > mb && j1 > m_hi * kRvBig);
+        if (late && e->rv_fut_m < m_hi) {
+            plan.tail_late = tail_for(m_hi);
+            e->rv_fut_m = m_hi;
+        }
+        if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
+            return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
-    JF_HIP(e, launch_reverb(R, big ? &G : nullptr, e->stream, &e->last_rv_form));
+    JF_HIP(e, launch_reverb(R, &plan, e->stream, &e->last_rv_form));
+    e->last_plan = plan;
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
     e->rv_blocks += K;
@@ -451,7 +506,8 @@ void free_reverb(jf_engine *e) {
     e->d_sigs_wet = nullptr;
     e->rv_P = e->rv_Rg = e->rv_Wr = e->rv_head = 0;
     e->rv_P_total = e->rv_P1 = e->rv_B1 = e->rv_R1 = e->rv_Rn = e->rv_Fn = e->rv_steps_max = 0;
-    e->rv_blocks = 0;
+    e->rv_blocks = e->rv_fut_m = 0;
+    e->last_plan = ReverbPlan();
 }
 
 // zero one source's (or every source's, src < 0) window, counters and reverb state
@@ -1027,7 +1083,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const int B1 = kRvBig * B;
     const int P1 = nonuniform ? (int)((n_ir > (size_t)B1 ? n_ir - B1 : 0) + B1 - 1) / B1 : 0;
     const int steps_max = e->maxK / kRvBig + 1;          // big-partition steps one call can contain
-    const int R1 = P1 + steps_max + 2, Rn = steps_max + 3, Fn = steps_max + 2;
+    const int R1 = P1 + steps_max + 4, Rn = steps_max + 3, Fn = 4;
     const int Rg = P + e->maxK;                          // slots a call may still read + the ones it writes
     const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
     float *d_ir = nullptr;
@@ -1051,21 +1107,22 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
         // 1/B: normalisation of the B-point inverse used for the 2B-point real transform
         JF_HIP(e, launch_reverb_ir(d_ir, (int)n_ir, P, B, gain / (float)B, e->d_tw, e->d_rv_hspec, e->stream));
         if (P1 > 0) {
-            // twiddles exp(+2 pi i j / (2 B1)), j < B1, from double
-            std::vector<float2> tw1((size_t)B1);
-            for (int j = 0; j < B1; j++) {
+            // twiddles exp(+2 pi i j / (2 B1)), j < 2 B1 (a full circle), from double
+            std::vector<float2> tw1((size_t)2 * B1);
+            for (int j = 0; j < 2 * B1; j++) {
                 const double a = 3.14159265358979323846264338327950288 * j / (double)B1;
                 tw1[j] = make_float2((float)cos(a), (float)sin(a));
             }
-            JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * B1));
-            JF_HIP(e, hipMemcpy(e->d_rv_tw1, tw1.data(), sizeof(float2) * B1, hipMemcpyHostToDevice));
-            JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * ((size_t)P1 * B1 + P1)));
+            JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * 2 * B1));
+            JF_HIP(e, hipMemcpy(e->d_rv_tw1, tw1.data(), sizeof(float2) * 2 * B1, hipMemcpyHostToDevice));
+            JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * ((size_t)(P1 + 1) * B1 + P1 + 1)));
             JF_HIP(e, hipMalloc(&e->d_rv_fdl1, sizeof(float2) * (S * R1 * B1 + S * R1)));
             JF_HIP(e, hipMalloc(&e->d_rv_ybig, sizeof(float2) * S * steps_max * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_dryring, sizeof(float) * S * Rn * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_fut, sizeof(float) * S * Fn * B1));
             // 1/B1: normalisation of the B1-point inverse used for the 2 B1-point real transform
-            JF_HIP(e, launch_reverb_big_ir(d_ir, (int)n_ir, B1, P1, B1, gain / (float)B1, e->d_rv_tw1, e->d_rv_hspec1, e->stream));
+            // H'_0 .. H'_P1: the response from its first tap on in partitions of B1 (ReverbBigParams)
+            JF_HIP(e, launch_reverb_big_ir(d_ir, (int)n_ir, 0, P1 + 1, B1, gain / (float)B1, e->d_rv_tw1, e->d_rv_hspec1, e->stream));
         }
         JF_HIP(e, hipStreamSynchronize(e->stream));
         return JF_OK;
@@ -1088,7 +1145,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     e->rv_Rn = Rn;
     e->rv_Fn = Fn;
     e->rv_steps_max = steps_max;
-    e->rv_blocks = 0;
+    e->rv_blocks = e->rv_fut_m = 0;
     return reset_sources(e, -1);
     });
 }
@@ -1463,16 +1520,33 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         std::string k;
         if (!e->last_rt && !e->last_prep_skipped) k = "prep_kernel;";
         if (e->rv_P > 0) {
-            if (e->last_rv_form != 4) k += "reverb_fft_kernel<" + bs + ">;";  // 4: stage A runs inside the MAC kernel
-            if (e->last_rv_steps > 0) {  // the big partitions' steps of the call (non-uniform partitioning)
-                const std::string b1 = std::to_string(e->rv_B1);
-                k += "reverb_big_fft_kernel<" + b1 + ">;reverb_big_mac_kernel<" + b1 + "," + (e->last_rv_steps >= 4 ? "16" : "1") +
-                     ">;reverb_big_ifft_kernel<" + b1 + ">;";
-            }
+            const ReverbPlan &pl = e->last_plan;
+            const std::string b1 = std::to_string(e->rv_B1);
+            auto products = [&](const ReverbBigParams &g) {
+                return g.n_prod > 0 ? "reverb_big_mac_kernel<" + b1 + "," + (g.n_prod >= 4 ? "16" : "1") + ">;reverb_big_ifft_kernel<" +
+                                          b1 + ">;" : std::string();
+            };
             const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
-            if (e->last_rv_form == 3) k += "reverb_mac_tiled_kernel<" + bs + "," + std::to_string(tile) + ">;";
-            else if (e->last_rv_form == 4) k += "reverb_mac_kernel<" + bs + ",1,true>;";
-            else k += "reverb_mac_kernel<" + bs + "," + std::to_string(e->last_rv_form == 2 ? grp : 1) + ">;";
+            auto stage_b = [&](int form) {
+                if (form == 3) return "reverb_mac_tiled_kernel<" + bs + "," + std::to_string(tile) + ">;";
+                if (form == 4) return "reverb_mac_kernel<" + bs + ",1,true>;";
+                if (form == 0) return std::string();
+                return "reverb_mac_kernel<" + bs + "," + std::to_string(form == 2 ? grp : 1) + ">;";
+            };
+            if (pl.big) k += products(pl.tail_early);
+            if (e->last_rv_form == 4) {
+                k += stage_b(4);
+                if (pl.big && pl.transforms.n_tr > 0) k += "reverb_big_fft_kernel<" + b1 + ">;";
+            } else {
+                k += "reverb_fft_kernel<" + bs + ">;";
+                if (pl.big) {
+                    if (pl.transforms.n_tr > 0) k += "reverb_big_fft_kernel<" + b1 + ">;";
+                    k += products(pl.middle) + products(pl.tail_late);
+                    for (int r = 0; r < pl.n_ranges; r++) k += stage_b(pl.forms[r]);
+                } else {
+                    k += stage_b(e->last_rv_form);
+                }
+            }
         }
         // launch_mix: few partial blocks per audio block (16, 32 or 64 groups) take the one-thread-per-float form
         const int n_part = e->last_group > 0 ? e->S / e->last_group : e->S;

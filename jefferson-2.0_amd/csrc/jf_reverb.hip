@@ -60,29 +60,114 @@ typedef c2 rv_v2;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
     } while (0)
 
-// In-LDS complex FFT of NPT points by one wavefront: radix-2 Stockham autosort,
-// ping-pong between a and b; returns the buffer holding the result in natural order.
-// DIR = -1 forward, +1 inverse (unnormalised).  tw = exp(+2 pi i j / 1024).
-template <int NPT, int DIR>
-JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, int lane) {
-#pragma unroll 1
-    for (int p = 1; p < NPT; p <<= 1) {
-        const int tstep = 512 / p;  // exp(-+ 2 pi i k / (2p)) = tw[k * 512 / p]
-        for (int j = lane; j < NPT / 2; j += 64) {
-            const int k = j & (p - 1);
-            const float2 u0 = a[j];
-            const float2 w = tw[k * tstep];
-            const float2 u1 = DIR > 0 ? rv_mul(a[j + NPT / 2], w) : rv_mulc(a[j + NPT / 2], w);
-            const int dst = ((j - k) << 1) + k;
-            b[dst] = rv_add(u0, u1);
-            b[dst + p] = rv_sub(u0, u1);
+// ---- in-register butterflies (natural order in and out); DIR = -1 forward, +1 inverse
+template <int DIR>
+JF_DEV float2 rv_muli(float2 v) {  // v * (DIR * i)
+    return DIR > 0 ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x);
+}
+template <int DIR>
+JF_DEV void rv_fft2(float2 (&v)[2]) {
+    const float2 a = v[0], b = v[1];
+    v[0] = rv_add(a, b);
+    v[1] = rv_sub(a, b);
+}
+template <int DIR>
+JF_DEV void rv_fft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 t0 = rv_add(a0, a2), t1 = rv_sub(a0, a2);
+    const float2 t2 = rv_add(a1, a3), t3 = rv_muli<DIR>(rv_sub(a1, a3));
+    a0 = rv_add(t0, t2);
+    a1 = rv_add(t1, t3);
+    a2 = rv_sub(t0, t2);
+    a3 = rv_sub(t1, t3);
+}
+template <int DIR>
+JF_DEV void rv_fft4(float2 (&v)[4]) {
+    rv_fft4<DIR>(v[0], v[1], v[2], v[3]);
+}
+template <int DIR>
+JF_DEV void rv_fft8(float2 (&v)[8]) {
+    constexpr float h = 0.70710678118654752440f;
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    rv_fft4<DIR>(e0, e1, e2, e3);
+    rv_fft4<DIR>(o0, o1, o2, o3);
+    // o_k *= exp(DIR 2 pi i k / 8)
+    o1 = DIR > 0 ? make_float2(h * (o1.x - o1.y), h * (o1.x + o1.y)) : make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));
+    o2 = rv_muli<DIR>(o2);
+    o3 = DIR > 0 ? make_float2(-h * (o3.x + o3.y), h * (o3.x - o3.y)) : make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));
+    v[0] = rv_add(e0, o0);
+    v[4] = rv_sub(e0, o0);
+    v[1] = rv_add(e1, o1);
+    v[5] = rv_sub(e1, o1);
+    v[2] = rv_add(e2, o2);
+    v[6] = rv_sub(e2, o2);
+    v[3] = rv_add(e3, o3);
+    v[7] = rv_sub(e3, o3);
+}
+template <int R, int DIR>
+JF_DEV void rv_fftR(float2 (&v)[R]) {
+    if constexpr (R == 8) rv_fft8<DIR>(v);
+    else if constexpr (R == 4) rv_fft4<DIR>(v);
+    else rv_fft2<DIR>(v);
+}
+
+// One pass of radix R of the Stockham autosort FFT of NPT points, a -> b, by NT threads (tid of them): sub-transforms of
+// length Ns in, Ns R out.  T[j] = exp(+2 pi i j / TN), j < TN (a full circle), TN a multiple of 2 NPT... of Ns R.
+template <int NPT, int R, int DIR, int NT, int TN>
+JF_DEV void stockham_pass(const float2 *a, float2 *b, const float2 *__restrict__ T, int Ns, int tid) {
+    for (int j = tid; j < NPT / R; j += NT) {
+        const int k = j & (Ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = a[j + r * (NPT / R)];
+        const int t1 = k * (TN / (Ns * R));  // exp(+-2 pi i r k / (Ns R)) = T[r t1]
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+            const float2 w = T[r * t1];
+            v[r] = DIR > 0 ? rv_mul(v[r], w) : rv_mulc(v[r], w);
         }
-        JF_RV_SYNC();
+        rv_fftR<R, DIR>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) b[j0 + r * Ns] = v[r];
+    }
+}
+
+// Complex FFT of NPT points (a power of two, >= 64) in LDS, ping-pong between a and b: radix-8 passes, then one of radix 4
+// or 2 for what is left.  WG = false: one wavefront (JF_RV_SYNC between the passes); true: a workgroup of NT threads
+// (a barrier between the passes).  Returns the buffer holding the result in natural order.
+template <int NPT, int DIR, int NT, int TN, bool WG>
+JF_DEV float2 *cfft_lds(float2 *a, float2 *b, const float2 *__restrict__ T, int tid) {
+    int Ns = 1;
+    auto sync = [&]() {
+        if constexpr (WG) __syncthreads();
+        else JF_RV_SYNC();
+    };
+#pragma unroll 1
+    for (; Ns * 8 <= NPT; Ns *= 8) {
+        stockham_pass<NPT, 8, DIR, NT, TN>(a, b, T, Ns, tid);
+        sync();
         float2 *t = a;
         a = b;
         b = t;
     }
+    constexpr int kLog = __builtin_ctz(NPT) % 3;  // NPT = 8^n 2^kLog
+    if constexpr (kLog == 2) {
+        stockham_pass<NPT, 4, DIR, NT, TN>(a, b, T, NPT / 4, tid);
+        sync();
+        return b;
+    } else if constexpr (kLog == 1) {
+        stockham_pass<NPT, 2, DIR, NT, TN>(a, b, T, NPT / 2, tid);
+        sync();
+        return b;
+    }
     return a;
+}
+
+// by one wavefront; tw = exp(+2 pi i j / 1024), j < 1024
+template <int NPT, int DIR>
+JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, int lane) {
+    return cfft_lds<NPT, DIR, 64, 1024, false>(a, b, tw, lane);
 }
 
 }  // namespace
@@ -90,7 +175,7 @@ JF_DEV float2 *cfft_small(float2 *a, float2 *b, const float2 *__restrict__ tw, i
 // ---------------------------------------------------------------- stage A --
 // Spectrum of [x_{k-1}, x_k] of source s into the FDL, by one wavefront (a, b: 2 x B float2 of LDS).  x0: also left in
 // LDS for the caller (the real-time form of stage B uses it at once), or null.
-// tw: exp(+2 pi i j / 1024), j < 512 -- P.tw, or a copy of it in LDS (every pass of the transform reads it).
+// tw: exp(+2 pi i j / 1024), j < 1024 -- P.tw, or a copy of it in LDS (every pass of the transform reads it).
 template <int B>
 JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b, int lane, float2 *x0,
                        const float2 *tw) {
@@ -100,6 +185,17 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
     const int cur0 = (int)(((long long)dc0 + (long long)k * B) % L);
     const int prv0 = (int)(((long long)dc0 + (long long)(k > 0 ? k - 1 : 0) * B) % L);
     const float *prev_state = P.prev_in + (size_t)s * B;
+    if (k >= P.copy_lo && k < P.copy_hi) {
+        // a block whose output the big partitions form directly (ReverbBigParams: FULL) and whose spectrum nobody will read:
+        // its samples go to the dry ring, nothing else (never the call's last block, which leaves the state)
+        float *ring = P.dryring + (size_t)s * P.Rd + (size_t)((P.dry_pos0 + k * B) % P.Rd);
+        for (int n = lane; n < B; n += 64) {
+            int idx = cur0 + n;
+            idx = idx >= L ? idx - L : idx;
+            ring[n] = sg.ptr[idx];
+        }
+        return;
+    }
     // z[m] = x[2m] + j x[2m+1] over x = [previous block, current block]
     for (int m = lane; m < B; m += 64) {
         float xv[2];
@@ -164,8 +260,8 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
 template <int B>
 __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
     __shared__ float2 s_buf[4][2 * B];
-    __shared__ float2 s_tw[512];  // the transform reads a twiddle in each of its log2 B passes: from LDS, not from global memory
-    for (int j = threadIdx.x; j < 512; j += 256) s_tw[j] = P.tw[j];
+    __shared__ float2 s_tw[1024];  // the transform's passes read their twiddles from LDS, not from global memory
+    for (int j = threadIdx.x; j < 1024; j += 256) s_tw[j] = P.tw[j];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -265,7 +361,8 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int SG = P.S / T;
-    const int k = blockIdx.x / SG, s0 = (blockIdx.x - k * SG) * T;
+    const int kl = blockIdx.x / SG, s0 = (blockIdx.x - kl * SG) * T;
+    const int k = P.kb + kl;
 
     const float2 *fdl = P.fdl + (size_t)s0 * P.Rg * B + lane * NB;
     const float2 *hs = P.hspec + lane * NB;
@@ -387,7 +484,7 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
         kt = blockIdx.x / P.S;
         s = blockIdx.x - kt * P.S;
     }
-    const int k0 = kt * KB;
+    const int k0 = P.kb + kt * KB;
 
     // Addresses as a wave-uniform base (scalar registers) + one per-lane byte offset: the delay-line slot of X(-p) steps
     // back by one per partition (with a wrap), the IR spectrum forward by one -- no division and no 64-bit vector
@@ -474,45 +571,28 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
     __syncthreads();
 #pragma unroll 1
     for (int i = wave; i < KB; i += kTileWaves)
-        if (k0 + i < P.K) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
+        if (k0 + i < P.kb + P.kn) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
 }
 
 // ------------------------------------------------- big partitions (level 1) --
-// Complex FFT of NPT points by a whole workgroup of NT threads in LDS: radix-2 Stockham autosort, ping-pong between a and b,
-// a barrier per pass; returns the buffer holding the result in natural order.  T2[j] = exp(+2 pi i j / (2 NPT)), j < NPT.
+// Complex FFT of NPT points by a whole workgroup of NT threads in LDS.  T2[j] = exp(+2 pi i j / (2 NPT)), j < 2 NPT.
 template <int NPT, int DIR, int NT>
 JF_DEV float2 *cfft_wg(float2 *a, float2 *b, const float2 *__restrict__ T2, int tid) {
-#pragma unroll 1
-    for (int p = 1; p < NPT; p <<= 1) {
-        const int tstep = NPT / p;  // exp(-+ 2 pi i k / (2p)) = T2[k NPT / p]
-        for (int j = tid; j < NPT / 2; j += NT) {
-            const int k = j & (p - 1);
-            const float2 u0 = a[j];
-            const float2 w = T2[k * tstep];
-            const float2 u1 = DIR > 0 ? rv_mul(a[j + NPT / 2], w) : rv_mulc(a[j + NPT / 2], w);
-            const int dst = ((j - k) << 1) + k;
-            b[dst] = rv_add(u0, u1);
-            b[dst + p] = rv_sub(u0, u1);
-        }
-        __syncthreads();
-        float2 *t = a;
-        a = b;
-        b = t;
-    }
-    return a;
+    return cfft_lds<NPT, DIR, NT, 2 * NPT, true>(a, b, T2, tid);
 }
 
 constexpr int kBigThreads = 256;
 
-// Step i of the call for source s: spectrum of the last 2 B1 dry samples into fdl1 (packed: bin 0 = (X[0], X[B1])).
+// X_m of transform i of the launch (m = first + i) for source s: spectrum of the 2 B1 dry samples of big blocks m - 2, m - 1
+// into fdl1 (packed: bin 0 = (X[0], X[B1])).
 template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
     __shared__ float2 s_a[B1], s_b[B1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
     const float *ring = P.dryring + (size_t)s * P.Rn * B1;
-    // the two big blocks (m - 2, m - 1) as they lie in the ring: each contiguous, the second possibly wrapped to the front
-    const int blk0 = (P.dblock_first + i) % P.Rn, blk1 = (blk0 + 1) % P.Rn;
+    // the two big blocks as they lie in the ring: each contiguous, the second possibly wrapped to the front
+    const int blk0 = (P.tr_dblock_first + i) % P.Rn, blk1 = (blk0 + 1) % P.Rn;
     const float2 *x0 = reinterpret_cast<const float2 *>(ring + (size_t)blk0 * B1);
     const float2 *x1 = reinterpret_cast<const float2 *>(ring + (size_t)blk1 * B1);
     for (int m = tid; m < B1 / 2; m += kBigThreads) {
@@ -521,7 +601,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     }
     __syncthreads();
     const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, P.tw1, tid);
-    const int slot = (P.slot_first + i) % P.R1;
+    const int slot = (P.tr_slot_first + i) % P.R1;
     float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
     for (int q = tid; q < B1; q += kBigThreads) {
         const float2 zk = Z[q];
@@ -538,10 +618,11 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     }
 }
 
-// Y_m = sum_q X_{m-q} H_q for a tile of KB consecutive steps of one source: a sliding window of KB spectra in registers, per
-// partition ONE new X load and one H load feed KB multiply-accumulates (the scheme of reverb_mac_tiled_kernel).  A wave
-// covers 64 bins (one per lane) of ALL partitions, in ascending order -- no reduction between waves, and the sums are
-// the same whatever KB is.  The packed pair in bin 0 is carried as if it were complex; reverb_big_ifft_kernel recomputes it.
+// Y_i = sum_{q < n_part} X_{anchor + i - q} H'_{h_first + q} for a tile of KB consecutive products of one source: a sliding
+// window of KB spectra in registers, per partition ONE new X load and one H load feed KB multiply-accumulates (the scheme
+// of reverb_mac_tiled_kernel).  A wave covers 64 bins (one per lane) of ALL partitions, in ascending order -- no reduction
+// between waves, and the sums are the same whatever KB is.  The packed pair in bin 0 is carried as if it were complex;
+// reverb_big_ifft_kernel recomputes it.
 constexpr int kBigMacWaves = 8;
 template <int B1, int KB>
 __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const ReverbBigParams P) {
@@ -550,25 +631,26 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = blockIdx.x % WGS_PER_SPEC;
     const int rest = blockIdx.x / WGS_PER_SPEC;
-    const int n_tiles = (P.n_steps + KB - 1) / KB;
-    const int s = rest / n_tiles, i0 = (rest - s * n_tiles) * KB;  // first step of the tile
+    const int n_tiles = (P.n_prod + KB - 1) / KB;
+    const int s = rest / n_tiles, i0 = (rest - s * n_tiles) * KB;  // first product of the tile
     const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
-    const char *hp = reinterpret_cast<const char *>(P.hspec1);
+    const char *hp = reinterpret_cast<const char *>(P.hspec1 + (size_t)P.h_first * B1);
     unsigned voff = 8u * (unsigned)(64 * (kBigMacWaves * slice + wave) + lane);
     asm volatile("" : "+v"(voff));
     auto load_at = [&](const char *base) {
         const float2 *q = reinterpret_cast<const float2 *>(base + voff);
         return rv_v2{q->x, q->y};
     };
-    auto slot_of = [&](int u) {  // slot of the spectrum of step (tile's first) + u (u may be far in the past)
-        int slot = (P.slot_first + i0 + u) % P.R1;
+    auto slot_of = [&](int u) {  // slot of X_{anchor + i0 + u} (u may be far in the past)
+        int slot = (P.anchor_slot_first + i0 + u) % P.R1;
         return slot < 0 ? slot + P.R1 : slot;
     };
     rv_v2 acc[KB], xr[KB];
 #pragma unroll
     for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
+    // the window: X(i), i = 1 .. KB - 1 (products past the end of the launch read whatever lies there and are not stored)
 #pragma unroll
-    for (int i = 1; i < KB; i++) xr[i] = load_at(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8));  // X(i), i = 1 .. KB-1
+    for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_at(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
     int xslot = slot_of(0);
     auto step = [&](int j) {  // j = q mod KB, a constant after unrolling
         const rv_v2 h = load_at(hp);
@@ -589,34 +671,35 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
         }
     };
     int q0 = 0;
-    for (; q0 + KB <= P.P1; q0 += KB) {
+    for (; q0 + KB <= P.n_part; q0 += KB) {
 #pragma unroll
         for (int j = 0; j < KB; j++) step(j);
     }
 #pragma unroll
     for (int j = 0; j < KB; j++)
-        if (q0 + j < P.P1) step(j);  // wave-uniform
-    float2 *y = P.ybig + ((size_t)s * P.n_steps + i0) * B1 + (voff >> 3);
+        if (q0 + j < P.n_part) step(j);  // wave-uniform
+    float2 *y = P.ybig + ((size_t)s * P.n_prod + i0) * B1 + (voff >> 3);
 #pragma unroll
     for (int i = 0; i < KB; i++)
-        if (i0 + i < P.n_steps) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
+        if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
 }
 
-// Products of step i of source s -> the B1 samples the partitions behind the head contribute to the next kRvBig blocks.
+// Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.
 template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
     __shared__ float2 s_a[B1], s_b[B1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
-    const float2 *y = P.ybig + ((size_t)s * P.n_steps + i) * B1;
+    const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
     for (int q = tid; q < B1; q += kBigThreads) s_b[q] = y[q];
-    // the true packed pair of bin 0: sum_q X0[m - q] .* H0[q] from the compact copies, wave 0's lanes over the partitions
+    // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes over
+    // the partitions
     if (tid < 64) {
         const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
-        const float2 *h0 = P.hspec1 + (size_t)P.P1 * B1;
+        const float2 *h0 = P.hspec1 + (size_t)(P.P1 + 1) * B1 + P.h_first;
         float2 y0 = make_float2(0.f, 0.f);
-        for (int q = tid; q < P.P1; q += 64) {
-            int slot = (P.slot_first + i - q) % P.R1;
+        for (int q = tid; q < P.n_part; q += 64) {
+            int slot = (P.anchor_slot_first + i - q) % P.R1;
             if (slot < 0) slot += P.R1;
             const float2 x = x0[slot], h = h0[q];
             y0.x += x.x * h.x;
@@ -628,7 +711,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
             y0.y += __shfl_xor(y0.y, m);
         }
         __builtin_amdgcn_wave_barrier();
-        if (tid == 0) s_b[0] = y0;  // (wave 0 itself stored s_b[0] above: same wave, program order)
+        if (tid == 0) s_b[0] = y0;  // (thread 0 itself stored s_b[0] above: program order)
     }
     __syncthreads();
     // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2
@@ -649,11 +732,23 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
     __syncthreads();
     const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, P.tw1, tid);
     // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
-    float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
-    for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[m];
+    if (!P.to_wet) {
+        float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
+        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[m];
+    } else {
+        // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
+        const int c0 = P.st_in[s].count;
+        float *wet = P.wet + (size_t)s * P.Wr;
+        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
+            const int n = 2 * m - B1;                   // sample inside the big block
+            const int k = P.wet_k0 + kRvBig * i + n / P.B;  // block of the call
+            const int w0 = (int)(((long long)c0 + (long long)k * P.B) % P.Wr);
+            *reinterpret_cast<float2 *>(wet + w0 + (n - (n / P.B) * P.B)) = zt[m];
+        }
+    }
 }
 
-// Partition spectra of level 1: one workgroup per partition q: rfft([h[T0 + q B1 .. + B1), zeros]) * scale, packed.
+// The H'_q: one workgroup per partition q: rfft([h[t0 + q B1 .. + B1), zeros]) * scale, packed.
 template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float *__restrict__ ir, int n_ir, int t0, float scale,
                                                                    const float2 *__restrict__ tw1, float2 *__restrict__ hspec1,
@@ -727,41 +822,66 @@ hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float sca
     return hipGetLastError();
 }
 
-template <int B, int T>
-static void launch_mac(const ReverbParams &P, hipStream_t st) {
-    hipLaunchKernelGGL((reverb_mac_kernel<B, T>), dim3(P.K * (P.S / T)), dim3(64 * kMacWaves), 0, st, P);
+static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st);
+static void launch_big_products(const ReverbBigParams &P, hipStream_t st);
+template <int B>
+static void launch_fft(const ReverbParams &P, hipStream_t st);
+
+// Form of stage B for blocks kb .. kb + kn - 1 by the amount of work: block-tiled when the tiles alone fill the GPU, else
+// source-grouped, else (real-time calls) one workgroup per (block, source).
+template <int B, int T, int KB>
+static int launch_mac_range(const ReverbParams &P0, int kb, int kn, hipStream_t st) {
+    if (kn <= 0) return 0;
+    ReverbParams P = P0;
+    P.kb = kb;
+    P.kn = kn;
+    const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
+    const long long tiles = (long long)((kn + KB - 1) / KB) * P.S;
+    const int form = (force == 3 || (force == 0 && kn >= KB && tiles >= 512)) ? 3
+                     : (P.S % T == 0 && (force == 2 || (force == 0 && (long long)kn * P.S / T >= 512))) ? 2
+                                                                                                       : 1;
+    if (form == 3) hipLaunchKernelGGL((reverb_mac_tiled_kernel<B, KB>), dim3((kn + KB - 1) / KB * P.S), dim3(64 * kTileWaves), 0, st, P);
+    else if (form == 2) hipLaunchKernelGGL((reverb_mac_kernel<B, T>), dim3(kn * (P.S / T)), dim3(64 * kMacWaves), 0, st, P);
+    else hipLaunchKernelGGL((reverb_mac_kernel<B, 1>), dim3(kn * P.S), dim3(64 * kMacWaves), 0, st, P);
+    return form;
 }
+
+// The whole stage for one call.  plan == null: uniform partitioning, every block through stage B.
+template <int B, int T, int KB>
+static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st) {
+    const bool big = plan && plan->big;
+    if (big && plan->tail_early.n_prod > 0) launch_big_products(plan->tail_early, st);  // needs nothing of this call
+    const bool few = !(P.S % T == 0 && (long long)P.S / T >= 512);  // (many sources: the source-grouped form, two kernels)
+    if (P.K == 1 && P.mac_form == 0 && few) {
+        // a call of one block: stage A inside the kernel (pinning a form keeps two kernels)
+        ReverbParams Q = P;
+        Q.kb = 0;
+        Q.kn = 1;
+        hipLaunchKernelGGL((reverb_mac_kernel<B, 1, true>), dim3(P.S), dim3(64 * kMacWaves), 0, st, Q);
+        if (big && plan->transforms.n_tr > 0) launch_big_transforms(plan->transforms, st);  // the block completed a big block
+        if (plan) plan->forms[0] = 4;
+        return 4;
+    }
+    launch_fft<B>(P, st);  // transforms of the blocks (where needed) and the dry ring
+    int form = 0;
+    if (big) {
+        if (plan->transforms.n_tr > 0) launch_big_transforms(plan->transforms, st);
+        if (plan->middle.n_prod > 0) launch_big_products(plan->middle, st);
+        if (plan->tail_late.n_prod > 0) launch_big_products(plan->tail_late, st);
+        for (int r = 0; r < plan->n_ranges; r++) {
+            plan->forms[r] = launch_mac_range<B, T, KB>(P, plan->kb[r], plan->kn[r], st);
+            if (plan->forms[r]) form = plan->forms[r];
+        }
+    } else {
+        form = launch_mac_range<B, T, KB>(P, 0, P.K, st);
+        if (plan) plan->forms[0] = form;
+    }
+    return form;
+}
+
 template <int B>
 static void launch_fft(const ReverbParams &P, hipStream_t st) {
     hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3((P.K * P.S + 3) / 4), dim3(256), 0, st, P);
-}
-template <int B, int KB>
-static void launch_mac_tiled(const ReverbParams &P, hipStream_t st) {
-    hipLaunchKernelGGL((reverb_mac_tiled_kernel<B, KB>), dim3((P.K + KB - 1) / KB * P.S), dim3(64 * kTileWaves), 0, st, P);
-}
-// Form of stage B by the amount of work in the call: block-tiled when the tiles alone fill the GPU,
-// else source-grouped, else (real-time calls) one workgroup per (block, source).
-hipError_t launch_reverb_big(const ReverbBigParams &P, hipStream_t st);
-
-// big: the big-partition steps of this call (non-uniform partitioning), or null
-template <int B, int T, int KB>
-static int launch_mac_any(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st) {
-    const int force = P.mac_form;  // 0 = by size; 1, 2, 3 = tests pin one form
-    const long long tiles = (long long)((P.K + KB - 1) / KB) * P.S;
-    const int form = (force == 3 || (force == 0 && P.K >= KB && tiles >= 512)) ? 3
-                     : (P.S % T == 0 && (force == 2 || (force == 0 && (long long)P.K * P.S / T >= 512))) ? 2
-                                                                                                      : 1;
-    if (form == 1 && P.K == 1 && force != 1) {  // a call of one block: stage A inside the kernel (pinning form 1 keeps two kernels)
-        if (big) (void)launch_reverb_big(*big, st);  // a step due at this block needs only the samples before it
-        hipLaunchKernelGGL((reverb_mac_kernel<B, 1, true>), dim3(P.S), dim3(64 * kMacWaves), 0, st, P);
-        return 4;
-    }
-    launch_fft<B>(P, st);
-    if (big) (void)launch_reverb_big(*big, st);  // behind the transforms (they fill the dry ring), before the finishing steps
-    if (form == 3) launch_mac_tiled<B, KB>(P, st);
-    else if (form == 2) launch_mac<B, T>(P, st);
-    else launch_mac<B, 1>(P, st);
-    return form;
 }
 
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
@@ -776,39 +896,47 @@ hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int
     return hipGetLastError();
 }
 
-// The big-partition steps of one call: transforms, products (tiles of 16 steps when the call has several, else single
-// steps), inverses.  Must run behind the head's forward transforms of the same call (they fill the dry ring) and before its
-// finishing step (which adds `fut`).
 template <int B1>
-static void launch_big(const ReverbBigParams &P, hipStream_t st) {
-    hipLaunchKernelGGL(reverb_big_fft_kernel<B1>, dim3(P.n_steps * P.S), dim3(kBigThreads), 0, st, P);
+static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
+    hipLaunchKernelGGL(reverb_big_fft_kernel<B1>, dim3(P.n_tr * P.S), dim3(kBigThreads), 0, st, P);
+}
+// products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
+template <int B1>
+static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
     constexpr int per_spec = B1 / (64 * kBigMacWaves);
-    if (P.n_steps >= 4) {
-        const int tiles = (P.n_steps + 15) / 16;
+    if (P.n_prod >= 4) {
+        const int tiles = (P.n_prod + 15) / 16;
         hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec * tiles * P.S), dim3(64 * kBigMacWaves), 0, st, P);
     } else {
-        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(per_spec * P.n_steps * P.S), dim3(64 * kBigMacWaves), 0, st, P);
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(per_spec * P.n_prod * P.S), dim3(64 * kBigMacWaves), 0, st, P);
     }
-    hipLaunchKernelGGL(reverb_big_ifft_kernel<B1>, dim3(P.n_steps * P.S), dim3(kBigThreads), 0, st, P);
+    hipLaunchKernelGGL(reverb_big_ifft_kernel<B1>, dim3(P.n_prod * P.S), dim3(kBigThreads), 0, st, P);
 }
-hipError_t launch_reverb_big(const ReverbBigParams &P, hipStream_t st) {
-    if (P.n_steps <= 0) return hipSuccess;
+static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {
-    case 1024: launch_big<1024>(P, st); break;
-    case 2048: launch_big<2048>(P, st); break;
-    case 4096: launch_big<4096>(P, st); break;
-    default: return hipErrorInvalidValue;
+    case 1024: launch_big_transforms_t<1024>(P, st); break;
+    case 2048: launch_big_transforms_t<2048>(P, st); break;
+    case 4096: launch_big_transforms_t<4096>(P, st); break;
+    default: break;
     }
-    return hipGetLastError();
+}
+static void launch_big_products(const ReverbBigParams &P, hipStream_t st) {
+    switch (P.B1) {
+    case 1024: launch_big_products_t<1024>(P, st); break;
+    case 2048: launch_big_products_t<2048>(P, st); break;
+    case 4096: launch_big_products_t<4096>(P, st); break;
+    default: break;
+    }
 }
 
-// form_used: 1, 2, 3 as above (after reverb_fft_kernel); 4 = form 1 with stage A fused in (no reverb_fft_kernel)
-hipError_t launch_reverb(const ReverbParams &P, const ReverbBigParams *big, hipStream_t st, int *form_used) {
+// form_used: 1, 2, 3 = form of stage B (after reverb_fft_kernel), 4 = form 1 with stage A fused in (no reverb_fft_kernel),
+// 0 = no block went through stage B (a batch call whose blocks the big partitions formed alone)
+hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used) {
     int form = 0;
     switch (P.B) {
-    case 64: form = launch_mac_any<64, 4, 16>(P, big, st); break;
-    case 128: form = launch_mac_any<128, 4, 16>(P, big, st); break;
-    case 256: form = launch_mac_any<256, 2, 8>(P, big, st); break;
+    case 64: form = launch_stage<64, 4, 16>(P, plan, st); break;
+    case 128: form = launch_stage<128, 4, 16>(P, plan, st); break;
+    case 256: form = launch_stage<256, 2, 8>(P, plan, st); break;
     default: return hipErrorInvalidValue;
     }
     if (form_used) *form_used = form;

@@ -224,7 +224,8 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     `bench.py --reverb` times: a delay-line ring of 690 + 256 slots, 16 tiles per source), each as TWO consecutive
     calls so that the delay line, the wet ring and the windows carry over.  form 3 pinned and part = 1: uniform partitions
     (690 multiply-accumulates per bin and block, the tiled kernel over all of them); part = 0, form 0: what the engine
-    takes by itself for this response -- 16 partitions of 128 (the same tiled kernel) + 43 of 2048.  Per-source blocks of sampled sources
+    takes by itself for this response -- partitions of 2048 (44 of them for blocks inside a call of whole big blocks: these
+    calls; 16 of 128 + 43 of 2048 for blocks worked on their own).  Per-source blocks of sampled sources
     against the float32 C oracle with its reverb stage (jfo_reverb_set_ir) and against gain * float64 convolution ->
     float64 spatialiser model; the mix as the ordered sum of the blocks."""
     B = 128
@@ -246,10 +247,13 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     for c in range(2):               # two calls: the delay line and the wet ring carry over
         e.batch_run(c * K, K)
         e.synchronize()
-        if K >= 16:
-            assert "reverb_mac_tiled_kernel<128,16>" in e.last_kernels()
-        if not form and part == 0:
-            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in e.last_kernels(), e.last_kernels()
+        ks = e.last_kernels()
+        if form or part == 1:
+            assert "reverb_mac_tiled_kernel<128,16>" in ks, ks
+        else:
+            # calls of whole big blocks: the big partitions form every block's wet signal, no block goes through the head
+            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in ks and "reverb_big_fft_kernel<2048>" in ks, ks
+            assert not any(k.startswith("reverb_mac") for k in ks), ks
         parts.append(e.read_device(e.partial_device_ptr(), (K, S, 2 * B)))
         mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))
     e.close()

@@ -225,28 +225,47 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
 
 
 def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, castanets):
-    """Per-block calls (one step of the big partitions every 16th call, single-step product kernel) against batch calls
-    (several steps per call, 16-step tiles) with the head's form pinned for both: bit-identical -- the big partitions add
-    their products in the same order whatever the tile.  And the 2 s response of configs[4] takes the non-uniform form by
-    default: 16 + 43 partitions instead of 690."""
+    """Per-block calls against batch calls that contain no whole big block (ragged sizes up to 15, boundaries inside and at
+    their ends) with the head's form pinned for both: bit-identical -- every block is then head + TAIL(m), and TAIL's products
+    are added in the same order whatever the launch.  A batch call of whole big blocks forms their wet signal from the big
+    partitions alone (FULL(m): another decomposition): within the float64 tolerance, not bit-identical.  And the 2 s
+    response of configs[4] takes the non-uniform form by default: 16 + 43 partitions instead of 690."""
     B, S, K = 128, 2, 80
     ir = _ir(16 * B * 6 + 333, decay=3.0)
     sigs = [castanets[:9000], castanets[10000:17000]]
     pos = _positions(jf, S, K)
-    a = _run(jf, hrir, B, S, K, 80, ir, 0.5, sigs, pos, form=1, part=2)                   # one call: 4 steps, tiled
     b = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True, form=1, part=2)    # 80 calls
-    assert np.array_equal(a, b)
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=15)
+    e.set_reverb_form(1)
+    e.set_reverb_partitioning(2)
+    for s_ in range(S):
+        e.set_signal(s_, sigs[s_])
+    e.set_reverb(ir, 0.5)
+    got, b0 = [], 0
+    for k in (7, 15, 9, 3, 15, 15, 15, 1):
+        got.append(e.process_batch(pos[b0:b0 + k]))
+        assert not any("reverb_big_mac_kernel<2048,16>" in x for x in e.last_kernels())
+        b0 += k
+    e.close()
+    assert b0 == K and np.array_equal(np.concatenate(got), b)
+    a = _run(jf, hrir, B, S, K, 80, ir, 0.5, sigs, pos, form=1, part=2)                   # one call of five whole big blocks
     c = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)                    # default: fused head kernel
     want = _model(hrir, B, S, K, ir, 0.5, sigs, pos)
     tol = (2e-7 + 1e-7 * np.sqrt(-(-len(ir) // B))) * max(1.0, np.abs(want).max()) * S
-    assert np.abs(c - want).max() <= tol and np.abs(a - want).max() <= tol
+    assert np.abs(want).max() > 0.02
+    for x in (a, b, c):
+        assert np.abs(x - want).max() <= tol
+    assert not np.array_equal(a, b)
     e = jf.Engine(128, 512, 1, hrir=hrir)
     e.set_reverb(_ir(88200), 1.0)
     assert e.reverb_partitions() == (690, 16, 43, 2048)
-    for _ in range(17):
+    for _ in range(16):
         e.process_block()
-    ks = e.last_kernels()          # the 17th block has a step in front of it
-    assert "reverb_big_fft_kernel<2048>" in ks and "reverb_big_mac_kernel<2048,1>" in ks and "reverb_mac_kernel<128,1,true>" in ks, ks
+    ks = e.last_kernels()          # the 16th block completes a big block: its spectrum is formed behind the head
+    assert ks[:2] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048>"], ks
+    e.process_block()
+    ks = e.last_kernels()          # the 17th block is the first of big block 1: TAIL(1) in front of the head
+    assert ks[:3] == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048>", "reverb_mac_kernel<128,1,true>"], ks
     e.process_block()
     assert not any(k.startswith("reverb_big") for k in e.last_kernels())
     e.close()
