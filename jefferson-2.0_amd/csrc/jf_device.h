@@ -171,7 +171,7 @@ struct ReverbParams {
     const SrcState *st_in;    // count = wet-ring position of the first new sample of this call
     int S, K, B, P, Rg, Wr, head;
     int mac_form;             // 0 = chosen by call size; 1 per (block, source), 2 source groups, 3 block tiles
-    // Non-uniform partitioning (ReverbBigParams below): this stage is then the HEAD of the impulse response -- P = kRvBig
+    // Non-uniform partitioning (ReverbBigParams below): this stage is then the HEAD of the impulse response -- P = M
     // partitions of B -- and adds the tail's contribution, which the big-partition kernels left in `fut`; every block's dry
     // samples are also copied to `dryring`, from which the big-partition transform reads.  Null / 0: uniform partitioning.
     float *dryring = nullptr;  // [S][Rd] dry input by absolute sample time mod Rd
@@ -181,24 +181,32 @@ struct ReverbParams {
     // blocks copy_lo <= k < copy_hi of the call only copy their samples to the dry ring (no transform): the blocks of a batch
     // call whose output the big partitions form directly and whose small spectra nobody reads later (0, 0: none)
     int copy_lo = 0, copy_hi = 0;
+    // ... and blocks skip_lo <= k < skip_hi are not visited at all by the transform kernel: neither their spectrum nor their
+    // place in the dry ring will be read (the big-partition transforms take samples of the running call from the signal)
+    int skip_lo = 0, skip_hi = 0;
     // the multiply-accumulate / finishing stage works on blocks kb .. kb + kn - 1 of the call (set by launch_reverb)
     int kb = 0, kn = 0;
 };
 
-// The non-uniformly partitioned reverb's second level: partitions of B1 = kRvBig * B taps (transform length 2 B1).
+// The non-uniformly partitioned reverb's second level: partitions of B1 = M * B taps (transform length 2 B1).
 //   X_m   = spectrum of the dry samples of big blocks m - 2 and m - 1 (absolute block indices 16 (m - 2) .. 16 m - 1), formed
 //           as soon as block 16 m - 1 has been taken in;
 //   H'_0  = spectrum of the response's first B1 taps, H'_1 .. H'_P1 = of the B1-tap partitions behind them.
 // A block that is worked on its own (per-block calls, the ragged ends of batch calls) gets taps [0, B1) from the uniform stage
-// above -- kRvBig partitions of B, no latency -- and the rest from  TAIL(m) = sum_{q < P1} X_{m-q} H'_{1+q}, the B1 samples the
+// above -- M partitions of B, no latency -- and the rest from  TAIL(m) = sum_{q < P1} X_{m-q} H'_{1+q}, the B1 samples the
 // partitions behind the head contribute to big block m, which depend only on samples before it (Gardner's zero-latency scheme
 // with two sizes): per block P1 / 16 + 16 multiply-accumulates per bin instead of P = 16 P1 + 16.  A big block that lies
 // INSIDE a batch call needs no head at all:  FULL(m) = sum_{q <= P1} X_{m+1-q} H'_q  is its whole wet signal (uniform
 // partitioning at the big size; its input is all there), one transform pair per 16 blocks instead of 16 pairs.
-constexpr int kRvBig = 16;
+// blocks per big block: B1 = rv_big_blocks(B) * B is 1024 or 2048 taps (a transform of 2 B1 points by one workgroup in LDS)
+constexpr int rv_big_blocks(int B) { return B <= 128 ? 16 : 8; }
 struct ReverbBigParams {
     const float2 *tw1;      // exp(+2 pi i j / (2 B1)), j < 2 B1 (a full circle), from double
-    const float *dryring;   // [S][Rn B1]
+    const float *dryring;   // [S][Rn B1] dry samples of EARLIER calls by absolute time (and of this call's blocks that the
+                            // uniform stage transformed); samples of the running call are read from the signal itself
+    const SrcSignal *dry;   // [S]
+    const int *dry_count_in;  // [S] play position of the call's first sample
+    int dry_pos0;           // ring position of the call's first sample
     float2 *fdl1;           // [S][R1][B1] the X_m (ring, slot = m mod R1), + [S][R1] compact copies of their packed bin-0 pairs
     const float2 *hspec1;   // [P1 + 1][B1] the H'_q, pre-scaled by gain / B1, + [P1 + 1] compact bin-0 pairs
     float2 *ybig;           // [S][n_prod][B1] products of one launch
@@ -206,15 +214,16 @@ struct ReverbBigParams {
     float *wet;             // [S][Wr] the wet ring (FULL(m) goes straight there)
     const SrcState *st_in;  // count = wet-ring position of the call's first new sample
     int S, B, B1, P1, R1, Rn, Fn, Wr;
+    int M;                  // blocks per big block: B1 / B
     // transforms: X_m for m = first .. first + n_tr - 1
     int n_tr = 0;
     int tr_slot_first = 0;    // first mod R1
-    int tr_dblock_first = 0;  // (first - 2) mod Rn
+    int tr_rel_first = 0;     // first sample of X_first's 2 B1 samples, relative to the call's first sample (< 0: before it)
     // products: Y_i = sum_{q < n_part} X_{anchor + i - q} H'_{h_first + q}, i < n_prod
     int n_prod = 0;
     int anchor_slot_first = 0;  // anchor mod R1
     int h_first = 0, n_part = 0;
-    int to_wet = 0;             // 0: Y_i -> fut ring block (fut_first + i) mod Fn;  1: -> the wet ring, blocks wet_k0 + 16 i .. + 15 of the call
+    int to_wet = 0;             // 0: Y_i -> fut ring block (fut_first + i) mod Fn;  1: -> the wet ring, blocks wet_k0 + M i .. + M - 1 of the call
     int fut_first = 0, wet_k0 = 0;
 };
 

@@ -159,10 +159,11 @@ struct jf_engine {
     float *d_rv_wet = nullptr;
     float *d_rv_prev[2] = {nullptr, nullptr};
     int *d_rv_count[2] = {nullptr, nullptr};
-    // non-uniform partitioning (ReverbBigParams, jf_device.h): rv_P is then the HEAD's partition count (kRvBig) and the rest
-    // of the impulse response lies in rv_P1 partitions of rv_B1 = kRvBig * B taps.  rv_P1 == 0: uniform partitioning.
+    // non-uniform partitioning (ReverbBigParams, jf_device.h): rv_P is then the HEAD's partition count (rv_M) and the rest
+    // of the impulse response lies in rv_P1 partitions of rv_B1 = rv_M * B taps.  rv_P1 == 0: uniform partitioning.
     int rv_partitioning = 0;     // jf_debug_set_reverb_partitioning: 0 by length, 1 uniform, 2 non-uniform (at the next set_ir)
     int rv_P_total = 0;          // partitions of B the impulse response has (what rv_P is under uniform partitioning)
+    int rv_M = 0;                // blocks per big block (rv_big_blocks(B)): rv_B1 = rv_M * B
     int rv_P1 = 0, rv_B1 = 0, rv_R1 = 0, rv_Rn = 0, rv_Fn = 0, rv_steps_max = 0;
     long long rv_blocks = 0;     // blocks the stage has processed since it was set up: big block m = blocks 16 m .. 16 m + 15
     long long rv_fut_m = 0;      // TAIL(m) has been formed for every big block up to this one (big block 0 has none: zeros)
@@ -264,7 +265,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     if (plan.big) {
         // Absolute block indices j0 .. j1 - 1; big block m = blocks 16 m .. 16 m + 15.
         const long long j0 = e->rv_blocks, j1 = j0 + K;
-        const int B1 = e->rv_B1, R1 = e->rv_R1, Rn = e->rv_Rn, Fn = e->rv_Fn;
+        const int B1 = e->rv_B1, R1 = e->rv_R1, Rn = e->rv_Rn, Fn = e->rv_Fn, M = e->rv_M;
         R.dryring = e->d_rv_dryring;
         R.Rd = Rn * B1;
         R.dry_pos0 = (int)((j0 * e->B) % R.Rd);
@@ -274,6 +275,9 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         ReverbBigParams G;
         G.tw1 = e->d_rv_tw1;
         G.dryring = e->d_rv_dryring;
+        G.dry = e->d_sigs;
+        G.dry_count_in = e->d_rv_count[p];
+        G.dry_pos0 = R.dry_pos0;
         G.fdl1 = e->d_rv_fdl1;
         G.hspec1 = e->d_rv_hspec1;
         G.ybig = e->d_rv_ybig;
@@ -288,15 +292,16 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         G.Rn = Rn;
         G.Fn = Fn;
         G.Wr = e->rv_Wr;
+        G.M = M;
         auto mod = [](long long a, int n) { return (int)(((a % n) + n) % n); };
         // X_m is formed in the call that takes in block 16 m - 1:  j0 < 16 m <= j1
-        const long long m_lo = j0 / kRvBig + 1, m_hi = j1 / kRvBig;
+        const long long m_lo = j0 / M + 1, m_hi = j1 / M;
         plan.transforms = G;
         plan.transforms.n_tr = m_hi >= m_lo ? (int)(m_hi - m_lo + 1) : 0;
         plan.transforms.tr_slot_first = mod(m_lo, R1);
-        plan.transforms.tr_dblock_first = mod(m_lo - 2, Rn);
+        plan.transforms.tr_rel_first = (int)((m_lo - 2) * B1 - j0 * e->B);
         // big blocks that lie inside the call: m = ma .. m_hi - 1, their wet signal is FULL(m), anchored at X_{m+1}
-        const long long ma = (j0 + kRvBig - 1) / kRvBig;
+        const long long ma = (j0 + M - 1) / M;
         const int n_mid = m_hi > ma ? (int)(m_hi - ma) : 0;
         plan.middle = G;
         plan.middle.n_prod = n_mid;
@@ -304,17 +309,20 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         plan.middle.h_first = 0;
         plan.middle.n_part = e->rv_P1 + 1;
         plan.middle.to_wet = 1;
-        plan.middle.wet_k0 = (int)(ma * kRvBig - j0);
+        plan.middle.wet_k0 = (int)(ma * M - j0);
         // the other blocks go through the uniform stage (head) + TAIL of their big block
         if (n_mid > 0) {
             plan.n_ranges = 2;
             plan.kb[0] = 0;
-            plan.kn[0] = (int)(ma * kRvBig - j0);
-            plan.kb[1] = (int)(m_hi * kRvBig - j0);
+            plan.kn[0] = (int)(ma * M - j0);
+            plan.kb[1] = (int)(m_hi * M - j0);
             plan.kn[1] = K - plan.kb[1];
             // of the middle's blocks only the last 15 are transformed (the state the next blocks read)
             R.copy_lo = plan.kn[0];
-            R.copy_hi = plan.kb[1] - (kRvBig - 1);
+            R.copy_hi = plan.kb[1] - (M - 1);
+            // ... and only the last whole big block is copied to the dry ring (later calls' transforms reach back two big blocks)
+            R.skip_lo = R.copy_lo;
+            R.skip_hi = std::max(R.copy_lo, plan.kb[1] - M);
         } else {
             plan.n_ranges = 1;
             plan.kb[0] = 0;
@@ -334,13 +342,13 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         plan.tail_late = G;
         // TAIL of the big block the call starts in, if one of its blocks goes through the uniform stage and nobody has formed
         // it yet (its X_m are all there: the block before it has been taken in)
-        const long long mb = j0 / kRvBig;
+        const long long mb = j0 / M;
         if (plan.kn[0] > 0 && e->rv_fut_m < mb) {
             plan.tail_early = tail_for(mb);
             e->rv_fut_m = mb;
         }
         // ... and of the big block the call ends in, if the call reaches into it behind a boundary it has passed itself
-        const bool late = n_mid > 0 ? plan.kn[1] > 0 : (m_hi > mb && j1 > m_hi * kRvBig);
+        const bool late = n_mid > 0 ? plan.kn[1] > 0 : (m_hi > mb && j1 > m_hi * M);
         if (late && e->rv_fut_m < m_hi) {
             plan.tail_late = tail_for(m_hi);
             e->rv_fut_m = m_hi;
@@ -505,7 +513,7 @@ void free_reverb(jf_engine *e) {
     e->d_rv_wet = nullptr;
     e->d_sigs_wet = nullptr;
     e->rv_P = e->rv_Rg = e->rv_Wr = e->rv_head = 0;
-    e->rv_P_total = e->rv_P1 = e->rv_B1 = e->rv_R1 = e->rv_Rn = e->rv_Fn = e->rv_steps_max = 0;
+    e->rv_P_total = e->rv_P1 = e->rv_B1 = e->rv_M = e->rv_R1 = e->rv_Rn = e->rv_Fn = e->rv_steps_max = 0;
     e->rv_blocks = e->rv_fut_m = 0;
     e->last_plan = ReverbPlan();
 }
@@ -1076,13 +1084,14 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const size_t S = (size_t)e->S;
     const int P_total = (int)((n_ir + B - 1) / B);
     // Non-uniform partitioning for a response of at least three big partitions (unless a uniform form is pinned, or
-    // jf_debug_set_reverb_partitioning says otherwise): the stage below is then the head of kRvBig partitions of B
+    // jf_debug_set_reverb_partitioning says otherwise): the stage below is then the head of rv_big_blocks(B) partitions of B
     const bool nonuniform = e->rv_partitioning == 2 ||
-                            (e->rv_partitioning == 0 && e->rv_form == 0 && P_total >= 3 * kRvBig);
-    const int P = nonuniform ? kRvBig : P_total;
-    const int B1 = kRvBig * B;
+                            (e->rv_partitioning == 0 && e->rv_form == 0 && P_total >= 3 * rv_big_blocks(B));
+    const int M = rv_big_blocks(B);
+    const int P = nonuniform ? M : P_total;
+    const int B1 = M * B;
     const int P1 = nonuniform ? (int)((n_ir > (size_t)B1 ? n_ir - B1 : 0) + B1 - 1) / B1 : 0;
-    const int steps_max = e->maxK / kRvBig + 1;          // big-partition steps one call can contain
+    const int steps_max = e->maxK / M + 1;               // big blocks one call can complete
     const int R1 = P1 + steps_max + 4, Rn = steps_max + 3, Fn = 4;
     const int Rg = P + e->maxK;                          // slots a call may still read + the ones it writes
     const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
@@ -1141,6 +1150,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     e->rv_P_total = P_total;
     e->rv_P1 = P1;
     e->rv_B1 = P1 > 0 ? B1 : 0;
+    e->rv_M = P1 > 0 ? M : 0;
     e->rv_R1 = R1;
     e->rv_Rn = Rn;
     e->rv_Fn = Fn;

@@ -13,7 +13,7 @@
 // Spectra are stored packed: B complex per partition, bin 0 holding (X[0].re, X[B].re).
 //
 // NON-UNIFORM PARTITIONING (round 4; ReverbBigParams in jf_device.h): for a long impulse response the stage above is only
-// the HEAD -- the first kRvBig = 16 partitions of B -- and the rest of the response is cut into partitions of B1 = 16 B
+// the HEAD -- the first M = 16 partitions of B -- and the rest of the response is cut into partitions of B1 = 16 B
 // taps: every 16 blocks one transform of 2 B1 samples, P1 = ceil((n_ir - B1) / B1) multiply-accumulates per bin (43
 // instead of 690 x 16 for the 2 s response at B = 128) and one inverse give the tail's contribution to the NEXT 16 blocks
 // (reverb_big_*), which the head's finishing step adds.  The reference's own form is ONE product over the whole signal
@@ -111,31 +111,44 @@ JF_DEV void rv_fftR(float2 (&v)[R]) {
     else rv_fft2<DIR>(v);
 }
 
+// LDS index of element i of a transform buffer.  PAD: one float2 of padding per 32 -- the passes write at strides of 8, 64,
+// 512 elements, which without it land on one or two banks (a 32-way conflict in the first pass).
+template <bool PAD>
+JF_DEV int rv_at(int i) {
+    return PAD ? i + (i >> 5) : i;
+}
+template <bool PAD>
+constexpr int rv_buf_len(int n) {
+    return PAD ? n + n / 32 : n;
+}
+
 // One pass of radix R of the Stockham autosort FFT of NPT points, a -> b, by NT threads (tid of them): sub-transforms of
-// length Ns in, Ns R out.  T[j] = exp(+2 pi i j / TN), j < TN (a full circle), TN a multiple of 2 NPT... of Ns R.
-template <int NPT, int R, int DIR, int NT, int TN>
+// length Ns in, Ns R out.  T[j] = exp(+2 pi i j / TN), j < TN (a full circle), TN a multiple of Ns R.
+template <int NPT, int R, int DIR, int NT, int TN, bool PAD>
 JF_DEV void stockham_pass(const float2 *a, float2 *b, const float2 *__restrict__ T, int Ns, int tid) {
     for (int j = tid; j < NPT / R; j += NT) {
         const int k = j & (Ns - 1);
         float2 v[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = a[j + r * (NPT / R)];
-        const int t1 = k * (TN / (Ns * R));  // exp(+-2 pi i r k / (Ns R)) = T[r t1]
+        for (int r = 0; r < R; r++) v[r] = a[rv_at<PAD>(j + r * (NPT / R))];
+        if (Ns > 1) {  // (the first pass's twiddles are all 1)
+            const int t1 = k * (TN / (Ns * R));  // exp(+-2 pi i r k / (Ns R)) = T[r t1]
 #pragma unroll
-        for (int r = 1; r < R; r++) {
-            const float2 w = T[r * t1];
-            v[r] = DIR > 0 ? rv_mul(v[r], w) : rv_mulc(v[r], w);
+            for (int r = 1; r < R; r++) {
+                const float2 w = T[r * t1];
+                v[r] = DIR > 0 ? rv_mul(v[r], w) : rv_mulc(v[r], w);
+            }
         }
         rv_fftR<R, DIR>(v);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; r++) b[j0 + r * Ns] = v[r];
+        for (int r = 0; r < R; r++) b[rv_at<PAD>(j0 + r * Ns)] = v[r];
     }
 }
 
 // Complex FFT of NPT points (a power of two, >= 64) in LDS, ping-pong between a and b: radix-8 passes, then one of radix 4
 // or 2 for what is left.  WG = false: one wavefront (JF_RV_SYNC between the passes); true: a workgroup of NT threads
-// (a barrier between the passes).  Returns the buffer holding the result in natural order.
+// (a barrier between the passes; the buffers are padded, rv_at).  Returns the buffer holding the result in natural order.
 template <int NPT, int DIR, int NT, int TN, bool WG>
 JF_DEV float2 *cfft_lds(float2 *a, float2 *b, const float2 *__restrict__ T, int tid) {
     int Ns = 1;
@@ -145,7 +158,7 @@ JF_DEV float2 *cfft_lds(float2 *a, float2 *b, const float2 *__restrict__ T, int 
     };
 #pragma unroll 1
     for (; Ns * 8 <= NPT; Ns *= 8) {
-        stockham_pass<NPT, 8, DIR, NT, TN>(a, b, T, Ns, tid);
+        stockham_pass<NPT, 8, DIR, NT, TN, WG>(a, b, T, Ns, tid);
         sync();
         float2 *t = a;
         a = b;
@@ -153,11 +166,11 @@ JF_DEV float2 *cfft_lds(float2 *a, float2 *b, const float2 *__restrict__ T, int 
     }
     constexpr int kLog = __builtin_ctz(NPT) % 3;  // NPT = 8^n 2^kLog
     if constexpr (kLog == 2) {
-        stockham_pass<NPT, 4, DIR, NT, TN>(a, b, T, NPT / 4, tid);
+        stockham_pass<NPT, 4, DIR, NT, TN, WG>(a, b, T, NPT / 4, tid);
         sync();
         return b;
     } else if constexpr (kLog == 1) {
-        stockham_pass<NPT, 2, DIR, NT, TN>(a, b, T, NPT / 2, tid);
+        stockham_pass<NPT, 2, DIR, NT, TN, WG>(a, b, T, NPT / 2, tid);
         sync();
         return b;
     }
@@ -266,8 +279,10 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x * 4 + wave;
-    if (g >= P.K * P.S) return;
-    const int k = g / P.S, s = g - k * P.S;
+    const int n_skip = P.skip_hi - P.skip_lo;  // blocks nobody needs transformed or copied (launch_fft sizes the grid)
+    if (g >= (P.K - n_skip) * P.S) return;
+    const int ka = g / P.S, s = g - ka * P.S;
+    const int k = ka < P.skip_lo ? ka : ka + n_skip;
     rv_forward<B>(P, k, s, s_buf[wave], s_buf[wave] + B, lane, nullptr, s_tw);
 }
 
@@ -587,25 +602,37 @@ constexpr int kBigThreads = 256;
 // into fdl1 (packed: bin 0 = (X[0], X[B1])).
 template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_a[B1], s_b[B1];
+    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
+    // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
+    // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
     const float *ring = P.dryring + (size_t)s * P.Rn * B1;
-    // the two big blocks as they lie in the ring: each contiguous, the second possibly wrapped to the front
-    const int blk0 = (P.tr_dblock_first + i) % P.Rn, blk1 = (blk0 + 1) % P.Rn;
-    const float2 *x0 = reinterpret_cast<const float2 *>(ring + (size_t)blk0 * B1);
-    const float2 *x1 = reinterpret_cast<const float2 *>(ring + (size_t)blk1 * B1);
-    for (int m = tid; m < B1 / 2; m += kBigThreads) {
-        s_a[m] = x0[m];            // z[m] = x[2m] + j x[2m + 1]
-        s_a[m + B1 / 2] = x1[m];
+    const int Rd = P.Rn * B1;
+    const SrcSignal sg = P.dry[s];
+    const int L = sg.length, dc0 = P.dry_count_in[s];
+    const int rel0 = P.tr_rel_first + i * B1;
+    for (int m = tid; m < B1; m += kBigThreads) {  // z[m] = x[2m] + j x[2m + 1]
+        const int rel = rel0 + 2 * m;              // even; the ring / signal boundary (rel = 0) never splits a pair
+        float2 z;
+        if (rel < 0) {
+            int pos = P.dry_pos0 + rel;
+            pos = pos < 0 ? pos + Rd : pos;
+            z = *reinterpret_cast<const float2 *>(ring + pos);
+        } else {
+            const int i0 = (int)(((long long)dc0 + rel) % L);
+            const int i1 = i0 + 1 == L ? 0 : i0 + 1;
+            z = make_float2(sg.ptr[i0], sg.ptr[i1]);
+        }
+        s_a[rv_at<true>(m)] = z;
     }
     __syncthreads();
     const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, P.tw1, tid);
     const int slot = (P.tr_slot_first + i) % P.R1;
     float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
     for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 zk = Z[q];
-        const float2 zm = Z[(B1 - q) & (B1 - 1)];
+        const float2 zk = Z[rv_at<true>(q)];
+        const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
         const float2 wo = rv_mulc(o, P.tw1[q]);
@@ -687,11 +714,11 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
 // Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.
 template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_a[B1], s_b[B1];
+    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
     const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
-    for (int q = tid; q < B1; q += kBigThreads) s_b[q] = y[q];
+    for (int q = tid; q < B1; q += kBigThreads) s_b[rv_at<true>(q)] = y[q];
     // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes over
     // the partitions
     if (tid < 64) {
@@ -716,8 +743,8 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
     __syncthreads();
     // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2
     for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 yk = s_b[q];
-        const float2 ym = s_b[(B1 - q) & (B1 - 1)];
+        const float2 yk = s_b[rv_at<true>(q)];
+        const float2 ym = s_b[rv_at<true>((B1 - q) & (B1 - 1))];
         float2 z;
         if (q == 0) {
             z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));
@@ -727,23 +754,23 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
             const float2 o = rv_mul(d, P.tw1[q]);
             z = make_float2(e.x - o.y, e.y + o.x);
         }
-        s_a[q] = z;
+        s_a[rv_at<true>(q)] = z;
     }
     __syncthreads();
     const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, P.tw1, tid);
     // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
     if (!P.to_wet) {
         float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
-        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[m];
+        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_at<true>(m)];
     } else {
         // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
         const int c0 = P.st_in[s].count;
         float *wet = P.wet + (size_t)s * P.Wr;
         for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
             const int n = 2 * m - B1;                   // sample inside the big block
-            const int k = P.wet_k0 + kRvBig * i + n / P.B;  // block of the call
+            const int k = P.wet_k0 + P.M * i + n / P.B;  // block of the call
             const int w0 = (int)(((long long)c0 + (long long)k * P.B) % P.Wr);
-            *reinterpret_cast<float2 *>(wet + w0 + (n - (n / P.B) * P.B)) = zt[m];
+            *reinterpret_cast<float2 *>(wet + w0 + (n - (n / P.B) * P.B)) = zt[rv_at<true>(m)];
         }
     }
 }
@@ -753,7 +780,7 @@ template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float *__restrict__ ir, int n_ir, int t0, float scale,
                                                                    const float2 *__restrict__ tw1, float2 *__restrict__ hspec1,
                                                                    float2 *__restrict__ h0 /* [P1] compact bin-0 pairs */) {
-    __shared__ float2 s_a[B1], s_b[B1];
+    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x;
     for (int m = tid; m < B1; m += kBigThreads) {
@@ -761,13 +788,13 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
         const long long i0 = (long long)t0 + (long long)q0 * B1 + n, i1 = i0 + 1;
         const float a0 = (n < B1 && i0 < n_ir) ? ir[i0] : 0.0f;
         const float a1 = (n + 1 < B1 && i1 < n_ir) ? ir[i1] : 0.0f;
-        s_a[m] = make_float2(a0, a1);
+        s_a[rv_at<true>(m)] = make_float2(a0, a1);
     }
     __syncthreads();
     const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw1, tid);
     for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 zk = Z[q];
-        const float2 zm = Z[(B1 - q) & (B1 - 1)];
+        const float2 zk = Z[rv_at<true>(q)];
+        const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
         const float2 wo = rv_mulc(o, tw1[q]);
@@ -881,7 +908,7 @@ static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st)
 
 template <int B>
 static void launch_fft(const ReverbParams &P, hipStream_t st) {
-    hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3((P.K * P.S + 3) / 4), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3(((P.K - (P.skip_hi - P.skip_lo)) * P.S + 3) / 4), dim3(256), 0, st, P);
 }
 
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
@@ -890,7 +917,6 @@ hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int
     switch (B1) {
     case 1024: hipLaunchKernelGGL(reverb_big_ir_kernel<1024>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
     case 2048: hipLaunchKernelGGL(reverb_big_ir_kernel<2048>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
-    case 4096: hipLaunchKernelGGL(reverb_big_ir_kernel<4096>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -916,7 +942,6 @@ static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {
     case 1024: launch_big_transforms_t<1024>(P, st); break;
     case 2048: launch_big_transforms_t<2048>(P, st); break;
-    case 4096: launch_big_transforms_t<4096>(P, st); break;
     default: break;
     }
 }
@@ -924,7 +949,6 @@ static void launch_big_products(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {
     case 1024: launch_big_products_t<1024>(P, st); break;
     case 2048: launch_big_products_t<2048>(P, st); break;
-    case 4096: launch_big_products_t<4096>(P, st); break;
     default: break;
     }
 }

@@ -300,7 +300,7 @@ def test_config4_bench_shape_with_the_default_grouping(jf, hrir, castanets):
         e.batch_run(c * K, K)
         e.synchronize()
         ks = e.last_kernels()
-        assert any(k.startswith("fused_pair_kernel<2>") for k in ks) and any(k.startswith("reverb_mac") for k in ks), ks
+        assert any(k.startswith("fused_pair_kernel<2>") for k in ks) and any(k.startswith("reverb_big_mac") for k in ks), ks
         G = e.last_source_group()
         assert G == 16
         parts.append(e.read_device(e.partial_device_ptr(), (K, S // G, 2 * B)))
