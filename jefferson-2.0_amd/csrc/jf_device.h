@@ -208,13 +208,15 @@ struct ReverbBigParams {
     const int *dry_count_in;  // [S] play position of the call's first sample
     int dry_pos0;           // ring position of the call's first sample
     float2 *fdl1;           // [S][R1][B1] the X_m (ring, slot = m mod R1), + [S][R1] compact copies of their packed bin-0 pairs
-    const float2 *hspec1;   // [P1 + 1][B1] the H'_q, pre-scaled by gain / B1, + [P1 + 1] compact bin-0 pairs
+    const float2 *hspec1;   // [NP][B1] the H'_q, pre-scaled by gain / B1 (q <= P1; zeros behind them: the product kernel works
+                            // in groups of 16 partitions), + [NP] compact bin-0 pairs
     float2 *ybig;           // [S][n_prod][B1] products of one launch
     float *fut;             // [S][Fn B1] TAIL(m) at ring block m mod Fn
     float *wet;             // [S][Wr] the wet ring (FULL(m) goes straight there)
     const SrcState *st_in;  // count = wet-ring position of the call's first new sample
     int S, B, B1, P1, R1, Rn, Fn, Wr;
     int M;                  // blocks per big block: B1 / B
+    int NP;                 // partitions hspec1 has room for (P1 + 1 + 16)
     // transforms: X_m for m = first .. first + n_tr - 1
     int n_tr = 0;
     int tr_slot_first = 0;    // first mod R1

@@ -293,6 +293,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         G.Fn = Fn;
         G.Wr = e->rv_Wr;
         G.M = M;
+        G.NP = e->rv_P1 + 17;
         auto mod = [](long long a, int n) { return (int)(((a % n) + n) % n); };
         // X_m is formed in the call that takes in block 16 m - 1:  j0 < 16 m <= j1
         const long long m_lo = j0 / M + 1, m_hi = j1 / M;
@@ -1092,7 +1093,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const int B1 = M * B;
     const int P1 = nonuniform ? (int)((n_ir > (size_t)B1 ? n_ir - B1 : 0) + B1 - 1) / B1 : 0;
     const int steps_max = e->maxK / M + 1;               // big blocks one call can complete
-    const int R1 = P1 + steps_max + 4, Rn = steps_max + 3, Fn = 4;
+    const int R1 = P1 + 16 + steps_max + 4, Rn = steps_max + 3, Fn = 4;  // (+ 16: the product kernel reads whole groups of 16 slots)
     const int Rg = P + e->maxK;                          // slots a call may still read + the ones it writes
     const int Wr = (e->maxK + kN / B + 1) * B;           // >= PAD_LEN, multiple of B
     float *d_ir = nullptr;
@@ -1124,7 +1125,9 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
             }
             JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * 2 * B1));
             JF_HIP(e, hipMemcpy(e->d_rv_tw1, tw1.data(), sizeof(float2) * 2 * B1, hipMemcpyHostToDevice));
-            JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * ((size_t)(P1 + 1) * B1 + P1 + 1)));
+            const size_t NP = (size_t)P1 + 17;  // H'_0 .. H'_P1 and 16 partitions of zeros
+            JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * (NP * B1 + NP)));
+            JF_HIP(e, hipMemset(e->d_rv_hspec1, 0, sizeof(float2) * (NP * B1 + NP)));
             JF_HIP(e, hipMalloc(&e->d_rv_fdl1, sizeof(float2) * (S * R1 * B1 + S * R1)));
             JF_HIP(e, hipMalloc(&e->d_rv_ybig, sizeof(float2) * S * steps_max * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_dryring, sizeof(float) * S * Rn * B1));

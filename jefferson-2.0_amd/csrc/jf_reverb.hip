@@ -590,10 +590,67 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
 }
 
 // ------------------------------------------------- big partitions (level 1) --
-// Complex FFT of NPT points by a whole workgroup of NT threads in LDS.  T2[j] = exp(+2 pi i j / (2 NPT)), j < 2 NPT.
+// Complex FFT of NPT = 1024 or 2048 points by a whole workgroup of NT = 256 threads in LDS: radix 8, 8, 8 and a last pass of
+// radix 2 or 4.  T2[j] = exp(+2 pi i j / (2 NPT)), j < 2 NPT.  The twiddles a thread needs do not depend on the data: they
+// are loaded into registers FIRST (BigTwiddles::load, before the caller fetches its input), so that a transform waits for
+// global memory once, not once per pass.
+template <int NPT, int NT>
+struct BigTwiddles {
+    static constexpr int RL = NPT / 512;               // radix of the last pass
+    static constexpr int NL = NPT / RL / NT;           // its butterflies per thread
+    static_assert(NPT / 8 <= NT && NL >= 1, "one radix-8 butterfly per thread at most");
+    float2 w8[2][7];        // passes with Ns = 8 and 64: exp(2 pi i r k / (8 Ns)), r = 1 .. 7
+    float2 wl[NL][RL - 1];  // last pass (Ns = 512)
+    JF_DEV void load(const float2 *__restrict__ T2, int tid) {
+        const int j = tid < NPT / 8 ? tid : 0;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int Ns = p ? 64 : 8;
+            const int t1 = (j & (Ns - 1)) * (2 * NPT / (Ns * 8));
+#pragma unroll
+            for (int r = 1; r < 8; r++) w8[p][r - 1] = T2[r * t1];
+        }
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int t1 = ((tid + u * NT) & 511) * (2 * NPT / (512 * RL));
+#pragma unroll
+            for (int r = 1; r < RL; r++) wl[u][r - 1] = T2[r * t1];
+        }
+    }
+};
+
+// one pass with the twiddles given (w[r - 1] for r = 1 .. R - 1; null: all 1), butterfly j of the pass
+template <int NPT, int R, int DIR>
+JF_DEV void big_pass(const float2 *a, float2 *b, const float2 *w, int Ns, int j) {
+    const int k = j & (Ns - 1);
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = a[rv_at<true>(j + r * (NPT / R))];
+    if (w != nullptr) {
+#pragma unroll
+        for (int r = 1; r < R; r++) v[r] = DIR > 0 ? rv_mul(v[r], w[r - 1]) : rv_mulc(v[r], w[r - 1]);
+    }
+    rv_fftR<R, DIR>(v);
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; r++) b[rv_at<true>(j0 + r * Ns)] = v[r];
+}
+
+// a holds the input (padded layout, rv_at<true>); returns the buffer holding the result in natural order (same layout)
 template <int NPT, int DIR, int NT>
-JF_DEV float2 *cfft_wg(float2 *a, float2 *b, const float2 *__restrict__ T2, int tid) {
-    return cfft_lds<NPT, DIR, NT, 2 * NPT, true>(a, b, T2, tid);
+JF_DEV float2 *cfft_wg(float2 *a, float2 *b, const BigTwiddles<NPT, NT> &tw, int tid) {
+    const bool on = tid < NPT / 8;
+    if (on) big_pass<NPT, 8, DIR>(a, b, nullptr, 1, tid);
+    __syncthreads();
+    if (on) big_pass<NPT, 8, DIR>(b, a, tw.w8[0], 8, tid);
+    __syncthreads();
+    if (on) big_pass<NPT, 8, DIR>(a, b, tw.w8[1], 64, tid);
+    __syncthreads();
+    constexpr int RL = BigTwiddles<NPT, NT>::RL;
+#pragma unroll
+    for (int u = 0; u < BigTwiddles<NPT, NT>::NL; u++) big_pass<NPT, RL, DIR>(b, a, tw.wl[u], 512, tid + u * NT);
+    __syncthreads();
+    return a;
 }
 
 constexpr int kBigThreads = 256;
@@ -605,6 +662,8 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
+    BigTwiddles<B1, kBigThreads> tw;
+    tw.load(P.tw1, tid);
     // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
     // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
     const float *ring = P.dryring + (size_t)s * P.Rn * B1;
@@ -627,7 +686,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
         s_a[rv_at<true>(m)] = z;
     }
     __syncthreads();
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, P.tw1, tid);
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw, tid);
     const int slot = (P.tr_slot_first + i) % P.R1;
     float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
     for (int q = tid; q < B1; q += kBigThreads) {
@@ -697,14 +756,12 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
             acc[i].y = __builtin_fmaf(x.y, h.x, acc[i].y);
         }
     };
-    int q0 = 0;
-    for (; q0 + KB <= P.n_part; q0 += KB) {
+    // whole groups of KB partitions, straight-line (loads of later steps may move above earlier multiply-accumulates): the
+    // partitions behind the response's last one are zeros (hspec1), the delay-line slots they meet hold older spectra
+    for (int q0 = 0; q0 < P.n_part; q0 += KB) {
 #pragma unroll
         for (int j = 0; j < KB; j++) step(j);
     }
-#pragma unroll
-    for (int j = 0; j < KB; j++)
-        if (q0 + j < P.n_part) step(j);  // wave-uniform
     float2 *y = P.ybig + ((size_t)s * P.n_prod + i0) * B1 + (voff >> 3);
 #pragma unroll
     for (int i = 0; i < KB; i++)
@@ -718,12 +775,14 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
     const int tid = threadIdx.x;
     const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
     const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
+    BigTwiddles<B1, kBigThreads> tw;
+    tw.load(P.tw1, tid);
     for (int q = tid; q < B1; q += kBigThreads) s_b[rv_at<true>(q)] = y[q];
     // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes over
     // the partitions
     if (tid < 64) {
         const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
-        const float2 *h0 = P.hspec1 + (size_t)(P.P1 + 1) * B1 + P.h_first;
+        const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
         float2 y0 = make_float2(0.f, 0.f);
         for (int q = tid; q < P.n_part; q += 64) {
             int slot = (P.anchor_slot_first + i - q) % P.R1;
@@ -757,7 +816,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
         s_a[rv_at<true>(q)] = z;
     }
     __syncthreads();
-    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, P.tw1, tid);
+    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, tw, tid);
     // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
     if (!P.to_wet) {
         float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
@@ -783,6 +842,8 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
     __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x;
+    BigTwiddles<B1, kBigThreads> tw;
+    tw.load(tw1, tid);
     for (int m = tid; m < B1; m += kBigThreads) {
         const int n = 2 * m;
         const long long i0 = (long long)t0 + (long long)q0 * B1 + n, i1 = i0 + 1;
@@ -791,7 +852,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
         s_a[rv_at<true>(m)] = make_float2(a0, a1);
     }
     __syncthreads();
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw1, tid);
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw, tid);
     for (int q = tid; q < B1; q += kBigThreads) {
         const float2 zk = Z[rv_at<true>(q)];
         const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
@@ -913,7 +974,7 @@ static void launch_fft(const ReverbParams &P, hipStream_t st) {
 
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
                                 float2 *d_hspec1, hipStream_t st) {
-    float2 *h0 = d_hspec1 + (size_t)P1 * B1;
+    float2 *h0 = d_hspec1 + (size_t)(P1 + 16) * B1;  // behind the P1 partitions written here and 16 of zeros
     switch (B1) {
     case 1024: hipLaunchKernelGGL(reverb_big_ir_kernel<1024>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;
     case 2048: hipLaunchKernelGGL(reverb_big_ir_kernel<2048>, dim3(P1), dim3(kBigThreads), 0, st, d_ir, n_ir, t0, scale, d_tw1, d_hspec1, h0); break;

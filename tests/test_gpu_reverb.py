@@ -185,13 +185,15 @@ def test_reverb_off_and_unsupported_block(jf, hrir, castanets):
 # ------------------------------------------------------------------------------- non-uniform partitioning --
 @pytest.mark.parametrize("B,n_big,ragged", [(128, 3, 0), (128, 7, 901), (64, 5, 17), (256, 3, 1000)])
 def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, castanets, B, n_big, ragged):
-    """A head of 16 partitions of B + partitions of 16 B behind it (jf_debug_set_reverb_partitioning; the default for long
+    """A head of M = 16 (B = 256: 8) partitions of B + partitions of M B behind it (jf_debug_set_reverb_partitioning; the default for long
     responses) against gain * float64 convolution -> float64 spatialiser model and against the engine with uniform
     partitions, over 70 blocks = four steps of the big partitions, as ONE run of calls of ragged sizes (1, 5, 16, 17, 31
     blocks: steps at the start, in the middle and at the end of a call, calls without any).  The response is n_big big
     partitions long (+ a ragged rest)."""
     S, K = 3, 70
-    n_ir = 16 * B + n_big * 16 * B - (16 * B - ragged if ragged else 0)
+    M = 16 if B <= 128 else 8        # blocks per big block: big partitions of 1024 or 2048 taps
+    B1 = M * B
+    n_ir = B1 + n_big * B1 - (B1 - ragged if ragged else 0)
     ir = _ir(n_ir, decay=3.0)
     gain = 0.6
     sigs = [castanets[5000 * s: 5000 * s + 12000 + 91 * s] for s in range(S)]
@@ -207,7 +209,7 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
             e.set_signal(s_, sigs[s_])
         e.set_reverb(ir, gain)
         n, head, big, taps = e.reverb_partitions()
-        assert n == P and (head, big, taps) == ((16, -(-(n_ir - 16 * B) // (16 * B)), 16 * B) if part == 2 else (P, 0, 0))
+        assert n == P and (head, big, taps) == ((M, -(-(n_ir - B1) // B1), B1) if part == 2 else (P, 0, 0))
         got, b0 = [], 0
         for k in (1, 5, 16, 17, 31):          # 70 blocks
             got.append(e.process_batch(pos[b0:b0 + k]))
@@ -220,7 +222,7 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
     assert np.abs(outs[1] - want).max() <= tol
     assert not np.array_equal(outs[1], outs[2])      # really another decomposition of the same convolution
     # the tail matters: a response cut behind the head gives something else
-    cut = _model(hrir, B, S, K, ir[:16 * B], gain, sigs, pos)
+    cut = _model(hrir, B, S, K, ir[:B1], gain, sigs, pos)
     assert np.abs(cut - want).max() > 100 * tol
 
 
