@@ -1553,9 +1553,10 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             } else {
                 k += "reverb_fft_kernel<" + bs + ">;";
                 if (pl.big) {
+                    if (pl.n_ranges > 1) k += stage_b(pl.forms[0]);
                     if (pl.transforms.n_tr > 0) k += "reverb_big_fft_kernel<" + b1 + ">;";
                     k += products(pl.middle) + products(pl.tail_late);
-                    for (int r = 0; r < pl.n_ranges; r++) k += stage_b(pl.forms[r]);
+                    k += stage_b(pl.forms[pl.n_ranges > 1 ? 1 : 0]);
                 } else {
                     k += stage_b(e->last_rv_form);
                 }

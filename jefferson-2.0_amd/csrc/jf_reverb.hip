@@ -953,13 +953,22 @@ static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st)
     launch_fft<B>(P, st);  // transforms of the blocks (where needed) and the dry ring
     int form = 0;
     if (big) {
+        // The blocks in front of the call's first whole big block first: they read the fut ring at their big block's place,
+        // which TAIL of the big block the call ENDS in may share (the ring has four places) -- and they need nothing of
+        // what follows.
+        // (A call without a whole big block inside has ONE range, whose blocks behind a boundary need TAIL_late: two
+        // neighbouring big blocks, two places.)
+        const bool split = plan->n_ranges > 1;
+        if (split) {
+            plan->forms[0] = launch_mac_range<B, T, KB>(P, plan->kb[0], plan->kn[0], st);
+            if (plan->forms[0]) form = plan->forms[0];
+        }
         if (plan->transforms.n_tr > 0) launch_big_transforms(plan->transforms, st);
         if (plan->middle.n_prod > 0) launch_big_products(plan->middle, st);
         if (plan->tail_late.n_prod > 0) launch_big_products(plan->tail_late, st);
-        for (int r = 0; r < plan->n_ranges; r++) {
-            plan->forms[r] = launch_mac_range<B, T, KB>(P, plan->kb[r], plan->kn[r], st);
-            if (plan->forms[r]) form = plan->forms[r];
-        }
+        const int r = split ? 1 : 0;
+        plan->forms[r] = launch_mac_range<B, T, KB>(P, plan->kb[r], plan->kn[r], st);
+        if (plan->forms[r]) form = plan->forms[r];
     } else {
         form = launch_mac_range<B, T, KB>(P, 0, P.K, st);
         if (plan) plan->forms[0] = form;
