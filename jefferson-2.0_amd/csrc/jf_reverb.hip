@@ -671,6 +671,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     const SrcSignal sg = P.dry[s];
     const int L = sg.length, dc0 = P.dry_count_in[s];
     const int rel0 = P.tr_rel_first + i * B1;
+    // signal index of the first sample at or behind the call's start (one division per workgroup, none per sample: the
+    // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
+    const int first_in = rel0 < 0 ? 0 : rel0;
+    const unsigned start = (unsigned)(((long long)dc0 + first_in) % L);
     for (int m = tid; m < B1; m += kBigThreads) {  // z[m] = x[2m] + j x[2m + 1]
         const int rel = rel0 + 2 * m;              // even; the ring / signal boundary (rel = 0) never splits a pair
         float2 z;
@@ -679,8 +683,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
             pos = pos < 0 ? pos + Rd : pos;
             z = *reinterpret_cast<const float2 *>(ring + pos);
         } else {
-            const int i0 = (int)(((long long)dc0 + rel) % L);
-            const int i1 = i0 + 1 == L ? 0 : i0 + 1;
+            unsigned i0 = start + (unsigned)(rel - first_in);
+#pragma unroll
+            for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
+            const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
             z = make_float2(sg.ptr[i0], sg.ptr[i1]);
         }
         s_a[rv_at<true>(m)] = z;
@@ -827,9 +833,11 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
         float *wet = P.wet + (size_t)s * P.Wr;
         for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
             const int n = 2 * m - B1;                   // sample inside the big block
-            const int k = P.wet_k0 + P.M * i + n / P.B;  // block of the call
-            const int w0 = (int)(((long long)c0 + (long long)k * P.B) % P.Wr);
-            *reinterpret_cast<float2 *>(wet + w0 + (n - (n / P.B) * P.B)) = zt[rv_at<true>(m)];
+            const int kb = n / P.B;                      // (B is a power of two or 192: the compiler cannot know; once per pair)
+            const int k = P.wet_k0 + P.M * i + kb;       // block of the call
+            int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
+            w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
+            *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_at<true>(m)];
         }
     }
 }

@@ -203,21 +203,26 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
     tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * S
     outs = {}
     for part in (2, 1):
-        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=31)
-        e.set_reverb_partitioning(part)
-        for s_ in range(S):
-            e.set_signal(s_, sigs[s_])
-        e.set_reverb(ir, gain)
-        n, head, big, taps = e.reverb_partitions()
-        assert n == P and (head, big, taps) == ((M, -(-(n_ir - B1) // B1), B1) if part == 2 else (P, 0, 0))
-        got, b0 = [], 0
-        for k in (1, 5, 16, 17, 31):          # 70 blocks
-            got.append(e.process_batch(pos[b0:b0 + k]))
-            b0 += k
-        assert b0 == K
-        outs[part] = np.concatenate(got)
-        e.close()
+        for sizes in ((1, 5, 16, 17, 31), (6, 64)):      # 70 blocks either way
+            e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max(sizes))
+            e.set_reverb_partitioning(part)
+            for s_ in range(S):
+                e.set_signal(s_, sigs[s_])
+            e.set_reverb(ir, gain)
+            n, head, big, taps = e.reverb_partitions()
+            assert n == P and (head, big, taps) == ((M, -(-(n_ir - B1) // B1), B1) if part == 2 else (P, 0, 0))
+            got, b0 = [], 0
+            for k in sizes:
+                got.append(e.process_batch(pos[b0:b0 + k]))
+                b0 += k
+            assert b0 == K
+            outs[part, sizes] = np.concatenate(got)
+            e.close()
+        outs[part] = outs[part, (1, 5, 16, 17, 31)]
     assert np.abs(want).max() > 0.02
+    # (6, 64): blocks in front of the call's first whole big block, whole big blocks, and blocks behind the last, whose
+    # big blocks are a multiple of four apart: TAIL of the one must not land on the other's place in the fut ring
+    assert np.abs(outs[2, (6, 64)] - want).max() <= tol
     assert np.abs(outs[2] - want).max() <= tol
     assert np.abs(outs[1] - want).max() <= tol
     assert not np.array_equal(outs[1], outs[2])      # really another decomposition of the same convolution
