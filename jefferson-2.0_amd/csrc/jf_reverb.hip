@@ -111,15 +111,16 @@ JF_DEV void rv_fftR(float2 (&v)[R]) {
     else rv_fft2<DIR>(v);
 }
 
-// LDS index of element i of a transform buffer.  PAD: one float2 of padding per 32 -- the passes write at strides of 8, 64,
-// 512 elements, which without it land on one or two banks (a 32-way conflict in the first pass).
+// LDS index of element i of a transform buffer.  PAD: one float2 of padding per 8 -- the passes write at strides of 8 and
+// 64 elements, which without it land on one or two banks (a 32-way conflict in the first pass); with it a half-wave's 8-byte
+// stores cover every bank twice, which is what 256 bytes take anyway.
 template <bool PAD>
 JF_DEV int rv_at(int i) {
-    return PAD ? i + (i >> 5) : i;
+    return PAD ? i + (i >> 3) : i;
 }
 template <bool PAD>
 constexpr int rv_buf_len(int n) {
-    return PAD ? n + n / 32 : n;
+    return PAD ? n + n / 8 : n;
 }
 
 // One pass of radix R of the Stockham autosort FFT of NPT points, a -> b, by NT threads (tid of them): sub-transforms of
@@ -619,38 +620,42 @@ struct BigTwiddles {
     }
 };
 
-// one pass with the twiddles given (w[r - 1] for r = 1 .. R - 1; null: all 1), butterfly j of the pass
+// one pass with the twiddles given (w[r - 1] for r = 1 .. R - 1), butterfly j of the pass
 template <int NPT, int R, int DIR>
 JF_DEV void big_pass(const float2 *a, float2 *b, const float2 *w, int Ns, int j) {
     const int k = j & (Ns - 1);
     float2 v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = a[rv_at<true>(j + r * (NPT / R))];
-    if (w != nullptr) {
 #pragma unroll
-        for (int r = 1; r < R; r++) v[r] = DIR > 0 ? rv_mul(v[r], w[r - 1]) : rv_mulc(v[r], w[r - 1]);
-    }
+    for (int r = 1; r < R; r++) v[r] = DIR > 0 ? rv_mul(v[r], w[r - 1]) : rv_mulc(v[r], w[r - 1]);
     rv_fftR<R, DIR>(v);
     const int j0 = (j - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; r++) b[rv_at<true>(j0 + r * Ns)] = v[r];
 }
 
-// a holds the input (padded layout, rv_at<true>); returns the buffer holding the result in natural order (same layout)
+// The input comes in REGISTERS: v[r] = x[tid + r NPT / 8] of threads tid < NPT / 8 (the first pass needs no twiddles and
+// reads nothing from LDS: the caller loads straight from global memory).  Returns the buffer (a or b, padded layout rv_at<true>)
+// that holds the result in natural order.
 template <int NPT, int DIR, int NT>
-JF_DEV float2 *cfft_wg(float2 *a, float2 *b, const BigTwiddles<NPT, NT> &tw, int tid) {
+JF_DEV float2 *cfft_wg(float2 (&v)[8], float2 *a, float2 *b, const BigTwiddles<NPT, NT> &tw, int tid) {
     const bool on = tid < NPT / 8;
-    if (on) big_pass<NPT, 8, DIR>(a, b, nullptr, 1, tid);
+    if (on) {
+        rv_fft8<DIR>(v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) a[rv_at<true>(8 * tid + r)] = v[r];
+    }
     __syncthreads();
-    if (on) big_pass<NPT, 8, DIR>(b, a, tw.w8[0], 8, tid);
+    if (on) big_pass<NPT, 8, DIR>(a, b, tw.w8[0], 8, tid);
     __syncthreads();
-    if (on) big_pass<NPT, 8, DIR>(a, b, tw.w8[1], 64, tid);
+    if (on) big_pass<NPT, 8, DIR>(b, a, tw.w8[1], 64, tid);
     __syncthreads();
     constexpr int RL = BigTwiddles<NPT, NT>::RL;
 #pragma unroll
-    for (int u = 0; u < BigTwiddles<NPT, NT>::NL; u++) big_pass<NPT, RL, DIR>(b, a, tw.wl[u], 512, tid + u * NT);
+    for (int u = 0; u < BigTwiddles<NPT, NT>::NL; u++) big_pass<NPT, RL, DIR>(a, b, tw.wl[u], 512, tid + u * NT);
     __syncthreads();
-    return a;
+    return b;
 }
 
 constexpr int kBigThreads = 256;
@@ -675,24 +680,24 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
     const int first_in = rel0 < 0 ? 0 : rel0;
     const unsigned start = (unsigned)(((long long)dc0 + first_in) % L);
-    for (int m = tid; m < B1; m += kBigThreads) {  // z[m] = x[2m] + j x[2m + 1]
-        const int rel = rel0 + 2 * m;              // even; the ring / signal boundary (rel = 0) never splits a pair
-        float2 z;
+    float2 v[8];  // z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8: the first pass's input
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+        const int rel = rel0 + 2 * m;  // even; the ring / signal boundary (rel = 0) never splits a pair
         if (rel < 0) {
             int pos = P.dry_pos0 + rel;
             pos = pos < 0 ? pos + Rd : pos;
-            z = *reinterpret_cast<const float2 *>(ring + pos);
+            v[r] = *reinterpret_cast<const float2 *>(ring + pos);
         } else {
             unsigned i0 = start + (unsigned)(rel - first_in);
 #pragma unroll
             for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
             const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
-            z = make_float2(sg.ptr[i0], sg.ptr[i1]);
+            v[r] = make_float2(sg.ptr[i0], sg.ptr[i1]);
         }
-        s_a[rv_at<true>(m)] = z;
     }
-    __syncthreads();
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw, tid);
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(v, s_a, s_b, tw, tid);
     const int slot = (P.tr_slot_first + i) % P.R1;
     float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
     for (int q = tid; q < B1; q += kBigThreads) {
@@ -783,13 +788,12 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
     const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
     BigTwiddles<B1, kBigThreads> tw;
     tw.load(P.tw1, tid);
-    for (int q = tid; q < B1; q += kBigThreads) s_b[rv_at<true>(q)] = y[q];
     // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes over
-    // the partitions
+    // the partitions (thread 0, which owns bin 0 below, is one of them)
+    float2 y0 = make_float2(0.f, 0.f);
     if (tid < 64) {
         const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
         const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
-        float2 y0 = make_float2(0.f, 0.f);
         for (int q = tid; q < P.n_part; q += 64) {
             int slot = (P.anchor_slot_first + i - q) % P.R1;
             if (slot < 0) slot += P.R1;
@@ -802,27 +806,25 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
             y0.x += __shfl_xor(y0.x, m);
             y0.y += __shfl_xor(y0.y, m);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) s_b[0] = y0;  // (thread 0 itself stored s_b[0] above: program order)
     }
-    __syncthreads();
-    // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2
-    for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 yk = s_b[rv_at<true>(q)];
-        const float2 ym = s_b[rv_at<true>((B1 - q) & (B1 - 1))];
-        float2 z;
+    // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
+    // memory into the first pass's registers: q = tid + r B1 / 8
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+        const float2 yk = y[q];
+        const float2 ym = y[(B1 - q) & (B1 - 1)];
         if (q == 0) {
-            z = make_float2(0.5f * (yk.x + yk.y), 0.5f * (yk.x - yk.y));
+            v[r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
         } else {
             const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
             const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
             const float2 o = rv_mul(d, P.tw1[q]);
-            z = make_float2(e.x - o.y, e.y + o.x);
+            v[r] = make_float2(e.x - o.y, e.y + o.x);
         }
-        s_a[rv_at<true>(q)] = z;
     }
-    __syncthreads();
-    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(s_a, s_b, tw, tid);
+    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(v, s_a, s_b, tw, tid);
     // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
     if (!P.to_wet) {
         float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
@@ -852,15 +854,17 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
     const int q0 = blockIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
     tw.load(tw1, tid);
-    for (int m = tid; m < B1; m += kBigThreads) {
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
         const int n = 2 * m;
         const long long i0 = (long long)t0 + (long long)q0 * B1 + n, i1 = i0 + 1;
         const float a0 = (n < B1 && i0 < n_ir) ? ir[i0] : 0.0f;
         const float a1 = (n + 1 < B1 && i1 < n_ir) ? ir[i1] : 0.0f;
-        s_a[rv_at<true>(m)] = make_float2(a0, a1);
+        v[r] = make_float2(a0, a1);
     }
-    __syncthreads();
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(s_a, s_b, tw, tid);
+    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(v, s_a, s_b, tw, tid);
     for (int q = tid; q < B1; q += kBigThreads) {
         const float2 zk = Z[rv_at<true>(q)];
         const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
