@@ -283,6 +283,9 @@ def main():
     # when the group has one rank -- the N > 1 code path on a one-GPU box (tests/test_gpu_engine.py)
     use_dist = world_env is not None
 
+    # --reverb: the counters of the stage's product kernel -- batch calls: the big partitions' (or, with uniform partitions,
+    # the tiled kernel); one-block calls: the head's kernel, which runs every block
+    rv_pmc_kernels = ("reverb_mac_kernel",) if args.realtime else ("reverb_big_mac_kernel", "reverb_mac_tiled_kernel")
     pmc, pmc_note = None, ("not collected: the counter passes run only at N = 1 (a profiled child per rank would "
                            "share the GPUs with the measurement)" if world > 1 else "not collected (--no-pmc / --pmc-child)")
     if world == 1 and not args.pmc_child and not args.no_pmc:
@@ -290,7 +293,7 @@ def main():
                  + (["--move-every", str(args.move_every)] if args.move_every != 1 else [])
                  + (["--realtime"] if args.realtime else [])
                  + (["--rv-sources", str(args.rv_sources), "--rv-ir-seconds", str(args.rv_ir_seconds)] if args.reverb else []))
-        pmc, pmc_note = collect_pmc(extra, ("reverb_mac",) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
+        pmc, pmc_note = collect_pmc(extra, rv_pmc_kernels if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
 
     backend = os.environ.get("JF_DIST_BACKEND", "nccl")
     torch = dist = None
@@ -338,6 +341,8 @@ def main():
     if os.environ.get("JF_SOURCE_GROUP"):
         eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
     if ir is not None:
+        if os.environ.get("JF_RV_PARTITIONING"):   # 1 = uniform partitions (round 3's form), 2 = non-uniform; default: by length
+            eng.set_reverb_partitioning(int(os.environ["JF_RV_PARTITIONING"]))
         eng.set_reverb(ir, RV_GAIN)
     # The trajectories are periodic (azimuth + 1 degree per block: 360 blocks), so a long run walks one
     # uploaded period again and again instead of holding (steps x blocks x sources) records: any --steps
@@ -615,57 +620,86 @@ def main():
                                        "there), 16 steps after the timed region with the stream waiting for its own step's "
                                        "collective; max over ranks"}
         if ir is not None:
-            # per source-block 690*129*8 B of delay line read + 129*8 B written, and the
-            # 690*129*8 B of IR spectra once per block (shared by all sources)
             P = -(-len(ir) // B)
-            rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
-            t = reverb_ms / timed * 1e-3  # average over the steps whose kernels were timed
-            mac_name = next((k for k in kernels if k.startswith("reverb_mac")), "reverb_mac")
+            t = reverb_ms / timed * 1e-3  # average time of the reverb stage's kernels over the steps that were timed
+            n_tot, p_head, p_big, big_taps = eng.reverb_partitions()
             std = S == 256 and len(ir) == 88200
+            parts = (f"{p_head} partitions of {B} + {p_big} of {big_taps}" if p_big else f"{P} partitions of {B}")
             out["config"]["workload"] = (("configs[4]: " if std else "configs[4] scaled: ")
-                                         + f"{S} sources + {len(ir) / 44100.0:g} s convolution-reverb IR, partitioned "
-                                           f"overlap-save ({P} partitions of 128), 128-sample blocks"
+                                         + f"{S} sources + {len(ir) / 44100.0:g} s convolution-reverb IR ({P} blocks long), "
+                                           f"partitioned overlap-save ({parts}), {B}-sample blocks"
                                          + (", ONE block per call (real-time shape)" if args.realtime else ""))
-            macs = S * KB * P * B
-            # the reverb stage's kernels as the engine launched them (one-block calls run the transform inside the
-            # multiply-accumulate kernel)
             rv_kernels = [k for k in kernels if k.startswith("reverb_")]
-            rv = {"kernel": " + ".join(rv_kernels) if rv_kernels else mac_name, "avg_launch_ms": t * 1e3,
-                  "algorithmic_bytes_per_launch": rb, "multiply_accumulates_per_launch": macs}
-            if args.realtime:
-                # one block per call: every source's P KB of delay line is read once per block and nothing of the
-                # stream is reused within the call.  Between calls the whole delay line is re-read: if it fits the
-                # 256 MiB Infinity Cache (256 sources x 690 partitions: 181 MB) the stream comes out of THAT, and
-                # FETCH_SIZE (the L2's fabric-side requests) cannot tell the two apart; past it (512 sources or a 4 s
-                # impulse response: 362 MB) the bytes come from HBM.  `level` says which this run is.
-                fdl_bytes = S * (P + KB) * B * 8
-                in_mall = fdl_bytes + P * B * 8 <= 256 * 2 ** 20
+            rv = {"kernel": " + ".join(rv_kernels), "kernels_are": "the reverb stage's kernels of the LAST timed step",
+                  "avg_stage_ms": t * 1e3, "stage_timing": "HIP events around the stage's kernels on the engine's stream"}
+            if p_big:
+                # Non-uniform partitioning (jf_device.h: ReverbBigParams).  Per big block (M blocks) and source: one
+                # transform of 2 B1 samples, P1 + 1 (FULL: blocks inside a batch call) or P1 (TAIL) spectra of the delay
+                # line against as many partition spectra, one inverse; blocks worked on their own add the head's M
+                # partitions of B.  The stage is bound by the delay-line stream (HBM): bytes below are ALGORITHMIC --
+                # every spectrum a product needs counted once per tile of 16 products (the kernel keeps a sliding window).
+                M, B1 = big_taps // B, big_taps
+                if args.realtime:
+                    # averages over the 16-block cycle: one transform, one TAIL product + inverse, 16 heads
+                    fdl_read = S * p_big * B1 * 8 / M
+                    rb = fdl_read + S * (B1 * 8 * 3 + 2 * B1 * 4) / M + S * (p_head * B * 8 + B * 8 + 2 * B * 4)
+                    macs = S * (p_big * B1 / M + p_head * B)
+                    flops = 8.0 * macs + S * (2 * 5 * B1 * np.log2(B1) / M + 2 * 5 * B * np.log2(B))
+                    fdl_bytes = S * (p_big + 1) * B1 * 8
+                else:
+                    nb_big = KB // M   # whole big blocks per call (KB is a multiple of M: the bench's calls are aligned)
+                    fdl_read = S * (p_big + 1 + min(nb_big, 16) - 1) * B1 * 8 * (-(-nb_big // 16))
+                    rb = fdl_read + (p_big + 1) * B1 * 8 + 3 * S * nb_big * B1 * 8 + 2 * S * KB * B * 4
+                    macs = S * nb_big * (p_big + 1) * B1
+                    flops = 8.0 * macs + 2 * S * nb_big * 5 * B1 * np.log2(B1)
+                    fdl_bytes = S * (p_big + 1 + nb_big) * B1 * 8
                 gbs = rb / t / 1e9 if t > 0 else 0.0
-                rv.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                           "level": "infinity-cache (the delay line fits the 256 MiB MALL: NOT an HBM figure)" if in_mall
-                                    else "hbm (the delay line is larger than the 256 MiB Infinity Cache)",
-                           "delay_line_bytes": fdl_bytes,
-                           "frac_of_achievable_6300": gbs / HBM_ACHIEVABLE_GBS,
-                           "achievable_note": "MI355X_MICROARCH.md: 8 TB/s spec peak, ~6.3 TB/s achievable from HBM"})
+                rv.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_step": rb, "delay_line_bytes_read_per_step": fdl_read,
+                           "multiply_accumulates_per_step": macs, "flops_per_step": flops,
+                           "valu_fp32_frac": flops / t / 1e12 / FP32_VECTOR_PEAK_TF if t > 0 else 0.0,
+                           "delay_line_bytes_resident": fdl_bytes,
+                           "level": ("the delay line (%d MB) fits the 256 MiB Infinity Cache: part of the stream comes out of it"
+                                     % (fdl_bytes // 10 ** 6)) if fdl_bytes <= 256 * 2 ** 20 else "hbm (the delay line is larger "
+                                    "than the 256 MiB Infinity Cache)",
+                           "uniform_partitioning_would_need": {"multiply_accumulates_per_step": S * KB * P * B,
+                                                               "delay_line_bytes_read_per_step": S * KB * P * B * 8 if args.realtime
+                                                               else S * (-(-KB // 16)) * (P + 15) * B * 8},
+                           "frac_of_achievable_6300": gbs / HBM_ACHIEVABLE_GBS})
             else:
-                # block tiles: each delay-line slot is read once per tile of 16 blocks and stays in the Infinity
-                # Cache; the bound is fp32 FMA issue (8 flops per complex multiply-accumulate, four FMAs)
-                tfr = 8.0 * macs / t / 1e12 if t > 0 else 0.0
-                rv.update({"bound": "valu-fp32", "achieved": tfr, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": tfr / FP32_VECTOR_PEAK_TF, "traffic": None,
-                           "peak_sustained_measured": {"v_fma_f32": 120.2, "v_pk_fma_f32": 137.4, "unit": "TFLOP/s",
-                                                       "frac_of_v_fma_f32": tfr / 120.2},
-                           "algorithmic_cache_gbps": rb / t / 1e9 if t > 0 else 0.0,
-                           "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
+                # uniform partitioning (per source-block P*129*8 B of delay line read + 129*8 B written, and
+                # the P*129*8 B of IR spectra once per block)
+                rb = S * KB * (P * (B + 1) * 8 + (B + 1) * 8) + KB * P * (B + 1) * 8
+                macs = S * KB * P * B
+                rv.update({"algorithmic_bytes_per_step": rb, "multiply_accumulates_per_step": macs})
+                if args.realtime:
+                    fdl_bytes = S * (P + KB) * B * 8
+                    in_mall = fdl_bytes + P * B * 8 <= 256 * 2 ** 20
+                    gbs = rb / t / 1e9 if t > 0 else 0.0
+                    rv.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                               "level": "infinity-cache (the delay line fits the 256 MiB MALL: NOT an HBM figure)" if in_mall
+                                        else "hbm (the delay line is larger than the 256 MiB Infinity Cache)",
+                               "delay_line_bytes": fdl_bytes,
+                               "frac_of_achievable_6300": gbs / HBM_ACHIEVABLE_GBS,
+                               "achievable_note": "MI355X_MICROARCH.md: 8 TB/s spec peak, ~6.3 TB/s achievable from HBM"})
+                else:
+                    tfr = 8.0 * macs / t / 1e12 if t > 0 else 0.0
+                    rv.update({"bound": "valu-fp32", "achieved": tfr, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tfr / FP32_VECTOR_PEAK_TF, "traffic": None,
+                               "algorithmic_cache_gbps": rb / t / 1e9 if t > 0 else 0.0,
+                               "min_hbm_bytes_per_launch": S * P * B * 8 + P * B * 8 + S * KB * (B * 8 + B * 4)})
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 rv["traffic"] = pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024
-                rv["traffic_source"] = pmc_note + " (multiply-accumulate kernel only; FETCH_SIZE x 2 + WRITE_SIZE; " \
-                                                  "FETCH_SIZE counts Infinity-Cache hits too)"
-            # the reverb stage's multiply-accumulate kernel is this configuration's dominant kernel: its roofline is the
-            # line's `roofline`; the spatialiser's fused kernel (a sixth of the step) keeps its own under another key
+                rv["traffic_is"] = ("per launch of the stage's product kernel only (" + ", ".join(rv_pmc_kernels) + "): FETCH_SIZE x 2 + "
+                                    "WRITE_SIZE; FETCH_SIZE counts Infinity-Cache hits too; " + pmc_note)
+            # Which kernel dominates the step: with uniform partitions the reverb's multiply-accumulate kernel (5/6 of a step);
+            # with non-uniform ones the spatialiser's fused kernel again (~40 %).  `roofline` is the reverb stage's -- this
+            # configuration's subject -- and the spatialiser's fused kernel keeps its own under another key.
             out["spatialiser_roofline"] = out["roofline"]
             out["roofline"] = rv
+            out["step_split_ms"] = {"reverb_stage": t * 1e3, "spatialiser_fused_kernel": prof["fused_ms"] / timed,
+                                    "whole_step": dt / K * 1e3}
             out["metric"] = "source-frames/s (sources x frames/sec) at 128-sample blocks, reverb + spatialiser"
         if world == 1 and ir is None:
             try:

@@ -1,4 +1,5 @@
-"""Real-time (one block per call) cost of configs[4]: 256 sources, B = 128, 2 s IR, reverb + spatialiser."""
+"""Real-time (one block per call) cost of configs[4]: 256 sources, B = 128, 2 s IR, reverb + spatialiser, per block of the
+16-block cycle of the non-uniformly partitioned stage (and, with JF_RV_UNIFORM=1, of uniform partitioning: round 3's form)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,22 +9,31 @@ hrir = np.load(os.path.join(ROOT, "tests/golden/kemar_hrir_710x2x128_i16.npy")).
 rng = np.random.default_rng(99)
 ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
 ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
-S, B = 256, 128
-e = jf.Engine(B, 512, S, hrir=hrir)
-for s in range(S):
-    e.set_signal(s, np.random.default_rng(1234 + s).uniform(-.5, .5, 44100).astype(np.float32))
-    e.set_spherical(s, -40 + (s * 7) % 121, (s * 37) % 360, 1.0)
-e.set_reverb(ir, 0.5)
-out = np.zeros(2 * B, np.float32)
-fp = out.ctypes.data_as(jf._f)
-L = jf.lib()
-for k in range(20):
-    L.jf_process_block(e.h, fp)
-ts = []
-for k in range(200):
-    t0 = time.perf_counter(); L.jf_process_block(e.h, fp); ts.append(time.perf_counter() - t0)
-ts = np.array(ts) * 1e6
-print(f"configs[4] real-time: 256 sources, B=128, 690 partitions: jf_process_block median {np.median(ts):.1f} us, "
-      f"p99 {np.percentile(ts, 99):.1f} us (block period 2902 us); FDL read per block {S*690*1024/1e6:.0f} MB "
-      f"-> {S*690*1024/np.median(ts)/1e6:.2f} TB/s if it were all the time")
-e.close()
+S, B = int(os.environ.get("JF_RV_SOURCES", "256")), 128
+for uniform in (False, True):
+    e = jf.Engine(B, 512, S, hrir=hrir)
+    e.set_reverb_partitioning(1 if uniform else 0)
+    for s in range(S):
+        e.set_signal(s, np.random.default_rng(1234 + s).uniform(-.5, .5, 44100).astype(np.float32))
+        e.set_spherical(s, -40 + (s * 7) % 121, (s * 37) % 360, 1.0)
+    e.set_reverb(ir, 0.5)
+    out = np.zeros(2 * B, np.float32)
+    fp = out.ctypes.data_as(jf._f)
+    L = jf.lib()
+    for k in range(64):
+        L.jf_process_block(e.h, fp)
+    ts = []
+    for k in range(64, 64 + 1600):
+        if k % 7 == 0:      # sources move now and then, as they would
+            for s in range(0, S, 5):
+                e.set_spherical(s, -40 + (s * 7) % 121, (s * 37 + k) % 360, 1.0)
+        t0 = time.perf_counter(); L.jf_process_block(e.h, fp); ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    n, head, big, taps = e.reverb_partitions()
+    print(f"configs[4] real-time, {S} sources, B = 128, {n} partitions of 128 as {head} x 128" + (f" + {big} x {taps}" if big else "")
+          + f": jf_process_block mean {ts.mean():.1f} us, median {np.median(ts):.1f}, p99 {np.percentile(ts, 99):.1f}, max {ts.max():.1f}"
+          f" (block period 2902 us)")
+    if big:
+        cyc = ts.reshape(-1, 16)      # block j of the cycle: j = 15 forms X_m behind its head, j = 0 forms TAIL(m) in front of it
+        print("   by place in the 16-block cycle (median us):", " ".join(f"{v:.0f}" for v in np.median(cyc, axis=0)))
+    e.close()
