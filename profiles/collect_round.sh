@@ -1,10 +1,10 @@
 #!/bin/bash
 # copies the summaries of gpurun_out/final_<tag>/ (written by round_profile.sh on the GPU box) into profiles/<tag>/
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 S=gpurun_out/final_$TAG; D=profiles/$TAG
 mkdir -p $D
-for f in bench bench_stationary bench_reverb bench_reverb_realtime bench_reverb_realtime_512src_hbm bench_reverb_realtime_4s_hbm bench_soak_20000_steps bench_2rank_gloo_rehearsal; do
+for f in bench bench_driver_shape bench_stationary bench_move_every_172 bench_reverb bench_reverb_realtime bench_reverb_realtime_512src_hbm bench_reverb_realtime_4s_hbm bench_soak_20000_steps bench_2rank_gloo_rehearsal; do
   [ -s $S/$f.json ] && tail -n 1 $S/$f.json > $D/$f.json
 done
 sed -i "/^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl/d" $S/ctest_bench.txt 2>/dev/null

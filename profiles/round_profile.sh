@@ -1,13 +1,15 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench lines (default / stationary / reverb / reverb real-time), rocprofv3 kernel
 # stats of the same commands, PMC passes of the fused kernel.   usage (through gpurun): bash profiles/round_profile.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $REPO
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_shape.json 2>> $OUT/bench.err; echo "bench as the driver runs it rc=$?"
 timeout -k 10 300 python3 bench.py --stationary > $OUT/bench_stationary.json 2>> $OUT/bench.err; echo "bench stationary rc=$?"
+timeout -k 10 300 python3 bench.py --move-every 172 > $OUT/bench_move_every_172.json 2>> $OUT/bench.err; echo "bench move-every 172 rc=$?"
 timeout -k 10 300 python3 bench.py --reverb --steps 256 --warmup 128 > $OUT/bench_reverb.json 2>> $OUT/bench.err; echo "bench reverb rc=$?"
 timeout -k 10 300 python3 bench.py --reverb --realtime --steps 2000 --warmup 500 > $OUT/bench_reverb_realtime.json 2>> $OUT/bench.err; echo "bench reverb realtime rc=$?"
 # the same kernel with a delay line larger than the 256 MiB Infinity Cache: the HBM-bound measurement
