@@ -412,9 +412,11 @@ def main():
         # JF_NO_EVENTS=1, profiles/r03_experiments.md): the fused launch is timed at every EVENT_STRIDE-th step of the timed
         # region, and its average is over those launches ("launches_timed").  With the reverb every kernel of such a step
         # is timed (eight records).
-        # (a short run -- the driver's --steps 20 -- would rest on two or three timed launches: below eight of them every
-        # launch is timed instead, and the 7 us per record pair are in ms_per_step)
-        stride = args.event_stride if K >= 8 * args.event_stride else 1
+        # A short run -- the driver's --steps 20 -- would rest on two or three timed launches at that stride: the stride is
+        # shortened until at least eight launches are timed (every 2nd of 20; every one below 16 steps).  Around EVERY launch
+        # the records cost 12 us of a 0.25 ms step (measured: 0.2585 against 0.2465 ms, profiles/r04/bench_driver_shape.json of
+        # the first collection), which is in ms_per_step and `value`: no more of them than the average needs.
+        stride = max(1, min(args.event_stride, K // 8))
         eng.profile_set_stride(stride)
     t0 = time.perf_counter()
     for i in range(prewarm + W, prewarm + W + K):

@@ -818,7 +818,7 @@ def test_whole_bench_under_the_launcher_with_one_rank():
     assert out["comm"]["backend"] == "RCCL"
     # the communication fraction of SURVEY.md 8(d) config 4 is MEASURED (events around the collective), also with one rank
     assert out["comm"]["ms_per_collective"] > 0 and 0 < out["comm"]["fraction"] < 1.0, out["comm"]
-    assert out["roofline"]["launches_timed"] == 8      # a short run times every launch
+    assert out["roofline"]["launches_timed"] == 8      # a short run is timed at a shorter stride: never fewer than eight launches
     assert "prewarm_policy" in out and "frac_reference_algorithm" not in out["roofline"]
     n_cpu = len(os.sched_getaffinity(0))
     assert out["cpu_baseline"]["cores"] > 1 or n_cpu == 1
