@@ -142,6 +142,11 @@ struct FusedParams {
                // where descriptors are built in-kernel (real-time kernel, the pair kernel's trailing workgroups)
     const int *order;  // [S] pair kernel: unit u works on sources order[G u .. G u + G - 1] (identity unless the engine sorted)
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
+    // Distance factors of the sources whose DISTANCE stays the same over the whole uploaded trajectory (dist_table_kernel):
+    // dtab[s][q][lane] = what distance_factors() hands lane `lane` for bin lane + 64 q, dconst[s] != 0 where the table is
+    // valid.  Null: every item evaluates its factors (per-block calls, positions that are not a window of the trajectory).
+    const float2 *dtab = nullptr;
+    const int *dconst = nullptr;
     // fused_pair_kernel only: workgroups n_pair_wgs .. gridDim.x - 1 prepare the descriptors of the window that FOLLOWS this
     // run in the uploaded trajectory (prep_kernel's work, 512 items per workgroup) while the last pairs finish
     int n_pair_wgs = 0;                // workgroups that work on units (set by launch_fused)

@@ -694,8 +694,19 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     float2 dq[8];
     const float sinv = inv_frac * (1.0f / 2048.0f);
     float d512x;
+    // A source whose distance does not change over the uploaded trajectory has its factors in a table (FusedParams::dtab:
+    // the values distance_factors() produces, stored once by dist_table_kernel): eight 8-byte loads instead of ~180 vector
+    // instructions.  Wave-uniform.
+    const bool d_tab = P.dconst != nullptr && (P.mode & kModeBasic) == 0 && as_const(P.dconst)[s] != 0;
+    auto load_factors = [&]() {
+        const float2 *t = P.dtab + (size_t)s * 512 + lane;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dq[q] = t[64 * q];
+        d512x = dq[0].x;  // on lane 0 (distance_factors)
+    };
     if (D_EARLY) {
-        distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
+        if (d_tab) load_factors();
+        else distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (b == P.K - 1) {
@@ -718,7 +729,10 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
-    if (!D_EARLY) distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
+    if (!D_EARLY) {
+        if (d_tab) load_factors();
+        else distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++) xd[q] = cmul_pk(X[q], dq[q]);
     const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
@@ -1097,12 +1111,12 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
         P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
         P.n_pair_wgs = q->n_pair_wgs, P.prep_pos = q->prep_pos, P.prep_desc = q->prep_desc, P.prep_K = q->prep_K;
-        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick;
+        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick, P.dtab = q->dtab, P.dconst = q->dconst;
 #pragma unroll
         for (int i = 0; i < kNumElev + 1; i++) P.rt.offset[i] = q->rt.offset[i];
 #pragma unroll
         for (int i = 0; i < kNumElev; i++) P.rt.inc[i] = q->rt.inc[i];
-        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
+        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
                           sizeof(RingTable) == (2 * kNumElev + 1) * 4 + 4 + 8,
                       "a field was added to FusedParams / RingTable: reload it here too");
     };
@@ -1665,6 +1679,21 @@ JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float
     return c1 ? 1 : c4 ? 4 : 2;
 }
 
+// GPUSoundSource.cu:81-90: r' = |coords| / 5, frac = 1 + fsvs r'^2 -> the phase step per bin as a 64-bit fraction of a turn and
+// 1 / frac.  False for NaN / infinite coordinates (the item is then silent).
+JF_DEV bool dist_terms(float x, float y, float z, unsigned long long &c_fix, float &inv_frac) {
+    float r = sqrtf(x * x + y * y + z * z);
+    r /= 5;
+    const float fsvs = (float)(44100.0 / 343.0);
+    const float frac = 1 + fsvs * (float)((double)r * (double)r);
+    // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+    double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
+    c -= floor(c);
+    c_fix = (unsigned long long)(c * 18446744073709551616.0);
+    inv_frac = 1.0f / frac;
+    return (frac >= 1.0f) && (frac < 3.0e38f);
+}
+
 // Descriptor of one work item from its latched position record and the position of the block
 // before (GPUSoundSource.cu:81-90 and :325-335).
 JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi, x, y, z */, float old_ele,
@@ -1702,20 +1731,7 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
             d.w_old[t] = 0.0f;
         }
     }
-    // GPUSoundSource.cu:81-90
-    const float x = p[2], y = p[3], z = p[4];
-    float r = sqrtf(x * x + y * y + z * z);
-    r /= 5;
-    const float fsvs = (float)(44100.0 / 343.0);
-    const float frac = 1 + fsvs * (float)((double)r * (double)r);
-    {
-        // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-        double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
-        c -= floor(c);
-        d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
-    }
-    d.inv_frac = 1.0f / frac;
-    if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
+    if (!dist_terms(p[2], p[3], p[4], d.c_fix, d.inv_frac)) d.n_new = 0;  // NaN / inf coordinates
     d.flags = 0;
 }
 
@@ -1817,20 +1833,7 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         d.inv_frac = 1.0f;
     } else {
         if (moved && n_other == 0) n = 0;  // the old position is not interpolable
-        // GPUSoundSource.cu:81-90
-        const float x = p[2], y = p[3], z = p[4];
-        float r = sqrtf(x * x + y * y + z * z);
-        r /= 5;
-        const float fsvs = (float)(44100.0 / 343.0);
-        const float frac = 1 + fsvs * (float)((double)r * (double)r);
-        {
-            // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-            double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
-            c -= floor(c);
-            d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
-        }
-        d.inv_frac = 1.0f / frac;
-        if (!(frac >= 1.0f) || !(frac < 3.0e38f)) n = 0;  // NaN / inf coordinates
+        if (!dist_terms(p[2], p[3], p[4], d.c_fix, d.inv_frac)) n = 0;  // NaN / inf coordinates
     }
     if (canon) {
         // Layout for fused_pair_kernel.  A source that did not move carries its new set as its old set (inside a
@@ -2101,6 +2104,40 @@ __global__ __launch_bounds__(64) void table_interp_build_kernel(const RingTable 
     }
 }
 
+// The distance factors of every source whose distance is the same in ALL blocks of the uploaded trajectory (pos
+// [total][S][5]): one wave per source compares the blocks' coordinates bit for bit with block 0's and, if none differs,
+// stores what distance_factors() yields -- the kernels then load it (FusedParams::dtab) instead of evaluating ~180 vector
+// instructions per source-block; the values are the same bits.  What generateDistanceFactor (kernels.cu:116-125) recomputes
+// for every block and source is computed here once per source and trajectory.
+__global__ __launch_bounds__(64) void dist_table_kernel(const float *__restrict__ pos, int total, int S,
+                                                       const float2 *__restrict__ twg, float2 *__restrict__ dtab,
+                                                       int *__restrict__ dconst) {
+    __shared__ float2 s_tw[kTwPack];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
+    __syncthreads();
+    const int s = blockIdx.x;
+    const float *p0 = pos + (size_t)s * 5;
+    const unsigned x0 = __float_as_uint(p0[2]), y0 = __float_as_uint(p0[3]), z0 = __float_as_uint(p0[4]);
+    bool same = true;
+    for (int b = lane; b < total; b += 64) {
+        const float *p = pos + ((size_t)b * S + s) * 5;
+        same = same && __float_as_uint(p[2]) == x0 && __float_as_uint(p[3]) == y0 && __float_as_uint(p[4]) == z0;
+    }
+    unsigned long long c_fix;
+    float inv_frac;
+    const bool ok = dist_terms(p0[2], p0[3], p0[4], c_fix, inv_frac);
+    const bool use = __all(same) && ok;
+    if (lane == 0) dconst[s] = use ? 1 : 0;
+    if (!use) return;
+    float2 dq[8];
+    float d512x;
+    // exactly item_finish's call: 1/N and the split pass's 1/2 ride on 1/frac
+    distance_factors((unsigned)(c_fix >> 32), (unsigned)c_fix, inv_frac * (1.0f / 2048.0f), lane, dq, d512x, s_tw);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dtab[(size_t)s * 512 + 64 * q + lane] = dq[q];
+}
+
 // parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
 __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict__ win,
                                                        const float2 *__restrict__ twg,
@@ -2204,6 +2241,12 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
                               hipStream_t st) {
     hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_table(const float *d_pos, int total, int S, const float2 *d_tw, float2 *d_dtab, int *d_dconst,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(dist_table_kernel, dim3(S), dim3(64), 0, st, d_pos, total, S, d_tw, d_dtab, d_dconst);
     return hipGetLastError();
 }
 
