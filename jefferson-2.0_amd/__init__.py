@@ -97,7 +97,7 @@ _SIGS = {
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_distance_table": (C.c_int, [C.c_void_p, C.c_int]),
-    "jf_debug_distance_table_sources": (C.c_int, [C.c_void_p]),
+    "jf_debug_distance_table_share": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
     "jf_debug_set_interp_share": (C.c_int, [C.c_void_p, C.c_int]),
@@ -408,8 +408,9 @@ class Engine:
     def set_distance_table(self, on):
         self._chk(lib().jf_debug_set_distance_table(self.h, int(bool(on))))
 
-    def distance_table_sources(self):
-        n = lib().jf_debug_distance_table_sources(self.h)
+    def distance_table_share(self):
+        """thousandths of the uploaded trajectory's items that read their distance factors from a table"""
+        n = lib().jf_debug_distance_table_share(self.h)
         if n < 0:
             self._chk(n)
         return n

@@ -694,12 +694,13 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     float2 dq[8];
     const float sinv = inv_frac * (1.0f / 2048.0f);
     float d512x;
-    // A source whose distance does not change over the uploaded trajectory has its factors in a table (FusedParams::dtab:
-    // the values distance_factors() produces, stored once by dist_table_kernel): eight 8-byte loads instead of ~180 vector
+    // The factors by table where the trajectory's upload has made one for this item's |coords| (FusedParams::dtab: the values
+    // distance_factors() produces, stored once by dist_table_kernel): eight 8-byte loads instead of ~180 vector
     // instructions.  Wave-uniform.
-    const bool d_tab = P.dconst != nullptr && (P.mode & kModeBasic) == 0 && as_const(P.dconst)[s] != 0;
+    const int d_var = P.dvar != nullptr && (P.mode & kModeBasic) == 0 ? (int)as_const(P.dvar)[(size_t)b * P.S + s] : 255;
+    const bool d_tab = d_var != 255;
     auto load_factors = [&]() {
-        const float2 *t = P.dtab + (size_t)s * 512 + lane;
+        const float2 *t = P.dtab + ((size_t)s * kDistVariants + d_var) * 512 + lane;
 #pragma unroll
         for (int q = 0; q < 8; q++) dq[q] = t[64 * q];
         d512x = dq[0].x;  // on lane 0 (distance_factors)
@@ -1111,7 +1112,7 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
         P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
         P.n_pair_wgs = q->n_pair_wgs, P.prep_pos = q->prep_pos, P.prep_desc = q->prep_desc, P.prep_K = q->prep_K;
-        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick, P.dtab = q->dtab, P.dconst = q->dconst;
+        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick, P.dtab = q->dtab, P.dvar = q->dvar;
 #pragma unroll
         for (int i = 0; i < kNumElev + 1; i++) P.rt.offset[i] = q->rt.offset[i];
 #pragma unroll
@@ -2104,38 +2105,75 @@ __global__ __launch_bounds__(64) void table_interp_build_kernel(const RingTable 
     }
 }
 
-// The distance factors of every source whose distance is the same in ALL blocks of the uploaded trajectory (pos
-// [total][S][5]): one wave per source compares the blocks' coordinates bit for bit with block 0's and, if none differs,
-// stores what distance_factors() yields -- the kernels then load it (FusedParams::dtab) instead of evaluating ~180 vector
-// instructions per source-block; the values are the same bits.  What generateDistanceFactor (kernels.cu:116-125) recomputes
-// for every block and source is computed here once per source and trajectory.
+// Distance factors by table (FusedParams::dtab, dvar): one wave per source over the uploaded trajectory pos [total][S][5].
+// The factors depend on |coords| alone (GPUSoundSource.cu:81-90 -> dist_terms), which takes few distinct float32 values per
+// source: up to kDistVariants of them are found (in order of first appearance), every block is given the number of its
+// value -- or 255: evaluate in the kernel, as before --, and a table is stored for each value: what distance_factors() yields,
+// the same bits the kernels would compute.  What generateDistanceFactor (kernels.cu:116-125) recomputes for every block and
+// source is computed here once per distinct distance.
 __global__ __launch_bounds__(64) void dist_table_kernel(const float *__restrict__ pos, int total, int S,
                                                        const float2 *__restrict__ twg, float2 *__restrict__ dtab,
-                                                       int *__restrict__ dconst) {
+                                                       unsigned char *__restrict__ dvar) {
     __shared__ float2 s_tw[kTwPack];
     const int lane = threadIdx.x;
     for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
     __syncthreads();
     const int s = blockIdx.x;
-    const float *p0 = pos + (size_t)s * 5;
-    const unsigned x0 = __float_as_uint(p0[2]), y0 = __float_as_uint(p0[3]), z0 = __float_as_uint(p0[4]);
-    bool same = true;
-    for (int b = lane; b < total; b += 64) {
+    unsigned long long vc[kDistVariants];
+    float vf[kDistVariants];
+    int nv = 0;
+    auto terms_of = [&](int b, unsigned long long &c, float &f) {
         const float *p = pos + ((size_t)b * S + s) * 5;
-        same = same && __float_as_uint(p[2]) == x0 && __float_as_uint(p[3]) == y0 && __float_as_uint(p[4]) == z0;
-    }
-    unsigned long long c_fix;
-    float inv_frac;
-    const bool ok = dist_terms(p0[2], p0[3], p0[4], c_fix, inv_frac);
-    const bool use = __all(same) && ok;
-    if (lane == 0) dconst[s] = use ? 1 : 0;
-    if (!use) return;
-    float2 dq[8];
-    float d512x;
-    // exactly item_finish's call: 1/N and the split pass's 1/2 ride on 1/frac
-    distance_factors((unsigned)(c_fix >> 32), (unsigned)c_fix, inv_frac * (1.0f / 2048.0f), lane, dq, d512x, s_tw);
+        return dist_terms(p[2], p[3], p[4], c, f);
+    };
+    auto variant_of = [&](bool ok, unsigned long long c, float f) {
+        int v = 255;
 #pragma unroll
-    for (int q = 0; q < 8; q++) dtab[(size_t)s * 512 + 64 * q + lane] = dq[q];
+        for (int i = 0; i < kDistVariants; i++)
+            if (ok && v == 255 && i < nv && c == vc[i] && __float_as_uint(f) == __float_as_uint(vf[i])) v = i;
+        return v;
+    };
+#pragma unroll 1
+    for (int round = 0; round < kDistVariants; round++) {
+        // first block (lowest index) whose value is usable and not among the variants found so far
+        int first = 0x7fffffff;
+        for (int b = lane; b < total; b += 64) {
+            unsigned long long c;
+            float f;
+            const bool ok = terms_of(b, c, f);
+            if (ok && variant_of(ok, c, f) == 255 && b < first) first = b;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) first = min(first, __shfl_xor(first, m));
+        if (first == 0x7fffffff) break;
+        unsigned long long c;
+        float f;
+        (void)terms_of(first, c, f);  // wave-uniform
+        // round is < kDistVariants; written without a run-time array index (scratch memory otherwise)
+#pragma unroll
+        for (int i = 0; i < kDistVariants; i++)
+            if (i == round) {
+                vc[i] = c;
+                vf[i] = f;
+            }
+        nv = round + 1;
+    }
+    for (int b = lane; b < total; b += 64) {
+        unsigned long long c;
+        float f;
+        const bool ok = terms_of(b, c, f);
+        dvar[(size_t)b * S + s] = (unsigned char)variant_of(ok, c, f);
+    }
+#pragma unroll
+    for (int i = 0; i < kDistVariants; i++) {
+        if (i >= nv) break;
+        float2 dq[8];
+        float d512x;
+        // exactly item_finish's call: 1/N and the split pass's 1/2 ride on 1/frac
+        distance_factors((unsigned)(vc[i] >> 32), (unsigned)vc[i], vf[i] * (1.0f / 2048.0f), lane, dq, d512x, s_tw);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dtab[((size_t)s * kDistVariants + i) * 512 + 64 * q + lane] = dq[q];
+    }
 }
 
 // parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
@@ -2244,9 +2282,9 @@ hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw,
     return hipGetLastError();
 }
 
-hipError_t launch_dist_table(const float *d_pos, int total, int S, const float2 *d_tw, float2 *d_dtab, int *d_dconst,
+hipError_t launch_dist_table(const float *d_pos, int total, int S, const float2 *d_tw, float2 *d_dtab, unsigned char *d_dvar,
                              hipStream_t st) {
-    hipLaunchKernelGGL(dist_table_kernel, dim3(S), dim3(64), 0, st, d_pos, total, S, d_tw, d_dtab, d_dconst);
+    hipLaunchKernelGGL(dist_table_kernel, dim3(S), dim3(64), 0, st, d_pos, total, S, d_tw, d_dtab, d_dvar);
     return hipGetLastError();
 }
 
