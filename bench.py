@@ -338,8 +338,6 @@ def main():
     eng = jf.Engine(B, 512, S, hrir=hrir, device=local_rank, max_batch_blocks=KB)
     for s, sid in enumerate(src_ids):
         eng.set_signal(s, wl.source_signal_and_start(sid)[0])
-    if os.environ.get("JF_DTAB") is not None:       # tuning runs: distance-factor tables off (0) / on
-        eng.set_distance_table(os.environ["JF_DTAB"] != "0")
     if os.environ.get("JF_SOURCE_GROUP"):
         eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
     if ir is not None:
@@ -592,7 +590,6 @@ def main():
                                    + (" (stationary variant)" if args.stationary else "")
                                    + (f" (VARIANT: the sources move every {args.move_every}-th block)" if args.move_every != 1 else "")
                                    + (" (TUNING VARIANT: every source at elevation 5)" if narrow else ""),
-                       "distance_tables": {"share_of_items_thousandths": eng.distance_table_share()},
                        "interp_table": {"setting": ["off", "always", "per run"][eng.interp_table()],
                                         "rows_read_by_the_timed_runs": eng.last_run_used_rows()},
                        "sources_per_gpu": S, "block": B, "blocks_per_step": KB, "source_group": G,

@@ -314,15 +314,6 @@ int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
-/* The 513 distance factors of a block (generateDistanceFactor, kernels.cu:116-125: recomputed by the reference for every block
- * and source) depend on |coords| alone, which takes few distinct float32 values per source over a trajectory: one if the
- * source stays, two or three when it moves in azimuth only (its rounded Cartesian coordinates make the norm flicker by an
- * ulp).  jf_batch_upload_positions finds up to four distinct values per source and evaluates a table for each; runs of that
- * trajectory load the factors (4 KB per item, cache-resident) instead of evaluating them.  The same bits either way; items
- * whose value has no table evaluate as before.  on = 0 switches the tables off (default on).
- * jf_debug_distance_table_share: thousandths of the uploaded trajectory's items that read a table (0 when switched off). */
-int jf_debug_set_distance_table(jf_engine *e, int on);
-int jf_debug_distance_table_share(jf_engine *e);
 /* Partitioning of the convolution reverb, in effect from the next jf_reverb_set_ir: 0 = by the response's length (default:
  * non-uniform from 48 partitions of frames_per_buffer on, unless jf_debug_set_reverb_form pins a uniform form), 1 = uniform
  * (one partition per block: P multiply-accumulates per bin and block), 2 = non-uniform (a head of 16 partitions of one

@@ -96,8 +96,6 @@ _SIGS = {
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
-    "jf_debug_set_distance_table": (C.c_int, [C.c_void_p, C.c_int]),
-    "jf_debug_distance_table_share": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
     "jf_debug_set_interp_share": (C.c_int, [C.c_void_p, C.c_int]),
@@ -404,16 +402,6 @@ class Engine:
 
     def last_run_used_rows(self):
         return bool(lib().jf_debug_last_run_used_rows(self.h))
-
-    def set_distance_table(self, on):
-        self._chk(lib().jf_debug_set_distance_table(self.h, int(bool(on))))
-
-    def distance_table_share(self):
-        """thousandths of the uploaded trajectory's items that read their distance factors from a table"""
-        n = lib().jf_debug_distance_table_share(self.h)
-        if n < 0:
-            self._chk(n)
-        return n
 
     def set_interp_share(self, sixteenths):
         self._chk(lib().jf_debug_set_interp_share(self.h, int(sixteenths)))

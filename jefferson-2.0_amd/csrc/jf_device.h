@@ -36,7 +36,6 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 // pre-interpolated rows behind the 710 measured ones (see htab above)
 constexpr int kInterpEleMin = -40, kInterpEleMax = 90, kInterpAzi = 360;
 constexpr int kInterpRows = (kInterpEleMax - kInterpEleMin + 1) * kInterpAzi;  // 47 160
-constexpr int kDistVariants = 4;  // distance-factor tables per source (FusedParams::dtab)
 constexpr int kModeBasic = 1, kModeCorrected = 2, kModeInterpRows = 4;  // bits of the kernels' `mode`
 // bits 8..12 of `mode`: of 16 MOVING sources, how many read pre-interpolated rows (sources that do not move always do).
 // Rows of moving sources stream from HBM, the measured rows and their weights cost vector instructions: the share
@@ -143,14 +142,6 @@ struct FusedParams {
                // where descriptors are built in-kernel (real-time kernel, the pair kernel's trailing workgroups)
     const int *order;  // [S] pair kernel: unit u works on sources order[G u .. G u + G - 1] (identity unless the engine sorted)
     int *err;  // host-mapped word: set to 1 if a pair hand-off of fused_pair_kernel ever times out (never, by construction)
-    // Distance factors by table (dist_table_kernel, at jf_batch_upload_positions): a source's |coords| takes few distinct
-    // float32 values over a trajectory -- one if it stays or moves on a sphere exactly, two or three when its rounded
-    // Cartesian coordinates make the norm flicker by an ulp -- and the factors depend on nothing else.  dtab[s][v][q][lane] =
-    // what distance_factors() hands lane `lane` for bin lane + 64 q with the v-th distinct value of source s (v < kDistVariants);
-    // dvar[b * S + s] = v for the window's block b, or 255: evaluate (more distinct values than tables, unusable
-    // coordinates).  Null: every item evaluates its factors (per-block calls, positions that are not a window of the trajectory).
-    const float2 *dtab = nullptr;
-    const unsigned char *dvar = nullptr;
     // fused_pair_kernel only: workgroups n_pair_wgs .. gridDim.x - 1 prepare the descriptors of the window that FOLLOWS this
     // run in the uploaded trajectory (prep_kernel's work, 512 items per workgroup) while the last pairs finish
     int n_pair_wgs = 0;                // workgroups that work on units (set by launch_fused)

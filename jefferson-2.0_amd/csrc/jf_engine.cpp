@@ -21,8 +21,6 @@
 namespace jf {
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
 hipError_t launch_table_interp_build(const RingTable &rt, int corrected, float4 *d_htab, hipStream_t st);
-hipError_t launch_dist_table(const float *d_pos, int total, int S, const float2 *d_tw, float2 *d_dtab, unsigned char *d_dvar,
-                             hipStream_t st);
 hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
                                float *d_w, int *d_nt, int n, int corrected, hipStream_t st);
@@ -108,12 +106,6 @@ struct jf_engine {
     float *d_traj = nullptr;    // [total][S][5]
     short *d_pick = nullptr;    // nearest-azimuth table of the index/weight kernels (RingTable::pick)
     RingTable rt{};             // ring_table() + this engine's device table
-    // Distance factors by table (FusedParams::dtab, dvar; dist_table_kernel at jf_batch_upload_positions): runs of the uploaded
-    // trajectory load them instead of evaluating them
-    float2 *d_dtab = nullptr;          // [S][kDistVariants][512]
-    unsigned char *d_dvar = nullptr;   // [traj_blocks][S] which table a block's item reads (255: none)
-    int dvar_blocks = 0;               // blocks d_dvar has room for
-    bool dtab_use = true;       // jf_debug_set_distance_table
     int *d_order = nullptr;     // [S] processing order of the pair kernel (a permutation of the sources)
     std::vector<int> order;     // host copy
     bool sorted_order = false;  // d_order is not the identity
@@ -445,10 +437,6 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     P.mode = mode_now;
     P.err = e->hd_err;
     P.order = e->d_order;
-    // the trajectory's distance tables: only for windows of the trajectory they were built from
-    const bool dtab = e->dtab_use && first_block >= 0 && e->d_dtab != nullptr;
-    P.dtab = dtab ? e->d_dtab : nullptr;
-    P.dvar = dtab ? e->d_dvar + (size_t)first_block * e->S : nullptr;
     // the window that follows in the trajectory, if there is a whole one: its descriptors are prepared by this run --
     // inside the pair kernel's own launch (trailing workgroups, in the kernel's tail), else inside the mix launch
     const bool ahead_ok = e->prep_ahead && e->profiling < 2 && first_block >= 0 && first_block + 2 * K <= e->traj_blocks;
@@ -579,8 +567,6 @@ void destroy_engine(jf_engine *e) {
     (void)hipFree(e->d_pos_rt);
     (void)hipFree(e->d_traj);
     (void)hipFree(e->d_order);
-    (void)hipFree(e->d_dtab);
-    (void)hipFree(e->d_dvar);
     (void)hipFree(e->d_pick);
     if (e->h_pos_pinned) (void)hipHostFree(e->h_pos_pinned);
     if (e->h_out_pinned) (void)hipHostFree(e->h_out_pinned);
@@ -1219,17 +1205,6 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     }
     e->traj_blocks = total_blocks;
     JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
-    // the distance factors of the sources that keep their distance throughout (FusedParams::dtab)
-    if (!e->d_dtab) JF_HIP(e, hipMalloc(&e->d_dtab, sizeof(float2) * 512 * kDistVariants * (size_t)e->S));
-    if (total_blocks > e->dvar_blocks) {
-        (void)hipFree(e->d_dvar);
-        e->d_dvar = nullptr;
-        e->dvar_blocks = 0;
-        JF_HIP(e, hipMalloc(&e->d_dvar, (size_t)total_blocks * e->S));
-        e->dvar_blocks = total_blocks;
-    }
-    JF_HIP(e, launch_dist_table(e->d_traj, total_blocks, e->S, e->d_twpack, e->d_dtab, e->d_dvar, e->stream));
-    JF_HIP(e, hipStreamSynchronize(e->stream));
     // how many items of every block move (their (ele, azi) differ from the block before; block 0 counts as staying):
     // what decides whether a run reads pre-interpolated rows (jf_engine::interp_use)
     e->traj_moved.assign((size_t)total_blocks + 1, 0u);
@@ -1410,28 +1385,6 @@ int jf_debug_set_interp_table(jf_engine *e, int on) {
     if (on && !e->interp_built) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
     e->interp_use = on;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
     return JF_OK;
-    });
-}
-
-int jf_debug_set_distance_table(jf_engine *e, int on) {
-    return jf_guard([&]() -> int {
-    if (!e) return JF_ERR_ARG;
-    e->dtab_use = on != 0;
-    return JF_OK;
-    });
-}
-
-int jf_debug_distance_table_share(jf_engine *e) {
-    return jf_guard([&]() -> int {
-    DeviceGuard bind(e);
-    if (!e) return JF_ERR_ARG;
-    if (!e->d_dvar || !e->dtab_use || e->traj_blocks <= 0) return 0;
-    std::vector<unsigned char> c((size_t)e->traj_blocks * e->S);
-    JF_HIP(e, hipStreamSynchronize(e->stream));
-    JF_HIP(e, hipMemcpy(c.data(), e->d_dvar, c.size(), hipMemcpyDeviceToHost));
-    long long n = 0;
-    for (unsigned char v : c) n += v != 255;
-    return (int)(n * 1000 / (long long)c.size());
     });
 }
 

@@ -694,20 +694,8 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
     float2 dq[8];
     const float sinv = inv_frac * (1.0f / 2048.0f);
     float d512x;
-    // The factors by table where the trajectory's upload has made one for this item's |coords| (FusedParams::dtab: the values
-    // distance_factors() produces, stored once by dist_table_kernel): eight 8-byte loads instead of ~180 vector
-    // instructions.  Wave-uniform.
-    const int d_var = P.dvar != nullptr && (P.mode & kModeBasic) == 0 ? (int)as_const(P.dvar)[(size_t)b * P.S + s] : 255;
-    const bool d_tab = d_var != 255;
-    auto load_factors = [&]() {
-        const float2 *t = P.dtab + ((size_t)s * kDistVariants + d_var) * 512 + lane;
-#pragma unroll
-        for (int q = 0; q < 8; q++) dq[q] = t[64 * q];
-        d512x = dq[0].x;  // on lane 0 (distance_factors)
-    };
     if (D_EARLY) {
-        if (d_tab) load_factors();
-        else distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
+        distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (b == P.K - 1) {
@@ -730,10 +718,7 @@ JF_DEV bool item_finish(const FusedParams &P, const ItemDesc *dp, const float *p
 
     float2 X[8];
     rfft1024_wave(z, X, buf, s_tw, lane);
-    if (!D_EARLY) {
-        if (d_tab) load_factors();
-        else distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
-    }
+    if (!D_EARLY) distance_factors(c_hi, c_lo, sinv, lane, dq, d512x, s_tw);
 #pragma unroll
     for (int q = 0; q < 8; q++) xd[q] = cmul_pk(X[q], dq[q]);
     const float2 x0 = make_float2(X[0].x * sinv, X[0].y * d512x);
@@ -1112,12 +1097,12 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
         P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
         P.n_pair_wgs = q->n_pair_wgs, P.prep_pos = q->prep_pos, P.prep_desc = q->prep_desc, P.prep_K = q->prep_K;
-        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick, P.dtab = q->dtab, P.dvar = q->dvar;
+        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick;
 #pragma unroll
         for (int i = 0; i < kNumElev + 1; i++) P.rt.offset[i] = q->rt.offset[i];
 #pragma unroll
         for (int i = 0; i < kNumElev; i++) P.rt.inc[i] = q->rt.inc[i];
-        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
+        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
                           sizeof(RingTable) == (2 * kNumElev + 1) * 4 + 4 + 8,
                       "a field was added to FusedParams / RingTable: reload it here too");
     };
@@ -1680,21 +1665,6 @@ JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float
     return c1 ? 1 : c4 ? 4 : 2;
 }
 
-// GPUSoundSource.cu:81-90: r' = |coords| / 5, frac = 1 + fsvs r'^2 -> the phase step per bin as a 64-bit fraction of a turn and
-// 1 / frac.  False for NaN / infinite coordinates (the item is then silent).
-JF_DEV bool dist_terms(float x, float y, float z, unsigned long long &c_fix, float &inv_frac) {
-    float r = sqrtf(x * x + y * y + z * z);
-    r /= 5;
-    const float fsvs = (float)(44100.0 / 343.0);
-    const float frac = 1 + fsvs * (float)((double)r * (double)r);
-    // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
-    double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
-    c -= floor(c);
-    c_fix = (unsigned long long)(c * 18446744073709551616.0);
-    inv_frac = 1.0f / frac;
-    return (frac >= 1.0f) && (frac < 3.0e38f);
-}
-
 // Descriptor of one work item from its latched position record and the position of the block
 // before (GPUSoundSource.cu:81-90 and :325-335).
 JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi, x, y, z */, float old_ele,
@@ -1732,7 +1702,20 @@ JF_DEV void make_desc(const RingTable &rt, int mode, const float *p /* ele, azi,
             d.w_old[t] = 0.0f;
         }
     }
-    if (!dist_terms(p[2], p[3], p[4], d.c_fix, d.inv_frac)) d.n_new = 0;  // NaN / inf coordinates
+    // GPUSoundSource.cu:81-90
+    const float x = p[2], y = p[3], z = p[4];
+    float r = sqrtf(x * x + y * y + z * z);
+    r /= 5;
+    const float fsvs = (float)(44100.0 / 343.0);
+    const float frac = 1 + fsvs * (float)((double)r * (double)r);
+    {
+        // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+        double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
+        c -= floor(c);
+        d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
+    }
+    d.inv_frac = 1.0f / frac;
+    if (!(frac >= 1.0f) || !(frac < 3.0e38f)) d.n_new = 0;  // NaN / inf coordinates
     d.flags = 0;
 }
 
@@ -1834,7 +1817,20 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         d.inv_frac = 1.0f;
     } else {
         if (moved && n_other == 0) n = 0;  // the old position is not interpolable
-        if (!dist_terms(p[2], p[3], p[4], d.c_fix, d.inv_frac)) n = 0;  // NaN / inf coordinates
+        // GPUSoundSource.cu:81-90
+        const float x = p[2], y = p[3], z = p[4];
+        float r = sqrtf(x * x + y * y + z * z);
+        r /= 5;
+        const float fsvs = (float)(44100.0 / 343.0);
+        const float frac = 1 + fsvs * (float)((double)r * (double)r);
+        {
+            // phase step per bin in turns, as a 64-bit fraction (double keeps 52+ fractional bits here)
+            double c = (double)fsvs * (double)r * (1.0 / 513.0);  // 1e-16 relative: far below the 2^-32 turn the phase word keeps
+            c -= floor(c);
+            d.c_fix = (unsigned long long)(c * 18446744073709551616.0);
+        }
+        d.inv_frac = 1.0f / frac;
+        if (!(frac >= 1.0f) || !(frac < 3.0e38f)) n = 0;  // NaN / inf coordinates
     }
     if (canon) {
         // Layout for fused_pair_kernel.  A source that did not move carries its new set as its old set (inside a
@@ -2105,77 +2101,6 @@ __global__ __launch_bounds__(64) void table_interp_build_kernel(const RingTable 
     }
 }
 
-// Distance factors by table (FusedParams::dtab, dvar): one wave per source over the uploaded trajectory pos [total][S][5].
-// The factors depend on |coords| alone (GPUSoundSource.cu:81-90 -> dist_terms), which takes few distinct float32 values per
-// source: up to kDistVariants of them are found (in order of first appearance), every block is given the number of its
-// value -- or 255: evaluate in the kernel, as before --, and a table is stored for each value: what distance_factors() yields,
-// the same bits the kernels would compute.  What generateDistanceFactor (kernels.cu:116-125) recomputes for every block and
-// source is computed here once per distinct distance.
-__global__ __launch_bounds__(64) void dist_table_kernel(const float *__restrict__ pos, int total, int S,
-                                                       const float2 *__restrict__ twg, float2 *__restrict__ dtab,
-                                                       unsigned char *__restrict__ dvar) {
-    __shared__ float2 s_tw[kTwPack];
-    const int lane = threadIdx.x;
-    for (int j = lane; j < kTwPack; j += 64) s_tw[j] = twg[j];
-    __syncthreads();
-    const int s = blockIdx.x;
-    unsigned long long vc[kDistVariants];
-    float vf[kDistVariants];
-    int nv = 0;
-    auto terms_of = [&](int b, unsigned long long &c, float &f) {
-        const float *p = pos + ((size_t)b * S + s) * 5;
-        return dist_terms(p[2], p[3], p[4], c, f);
-    };
-    auto variant_of = [&](bool ok, unsigned long long c, float f) {
-        int v = 255;
-#pragma unroll
-        for (int i = 0; i < kDistVariants; i++)
-            if (ok && v == 255 && i < nv && c == vc[i] && __float_as_uint(f) == __float_as_uint(vf[i])) v = i;
-        return v;
-    };
-#pragma unroll 1
-    for (int round = 0; round < kDistVariants; round++) {
-        // first block (lowest index) whose value is usable and not among the variants found so far
-        int first = 0x7fffffff;
-        for (int b = lane; b < total; b += 64) {
-            unsigned long long c;
-            float f;
-            const bool ok = terms_of(b, c, f);
-            if (ok && variant_of(ok, c, f) == 255 && b < first) first = b;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) first = min(first, __shfl_xor(first, m));
-        if (first == 0x7fffffff) break;
-        unsigned long long c;
-        float f;
-        (void)terms_of(first, c, f);  // wave-uniform
-        // round is < kDistVariants; written without a run-time array index (scratch memory otherwise)
-#pragma unroll
-        for (int i = 0; i < kDistVariants; i++)
-            if (i == round) {
-                vc[i] = c;
-                vf[i] = f;
-            }
-        nv = round + 1;
-    }
-    for (int b = lane; b < total; b += 64) {
-        unsigned long long c;
-        float f;
-        const bool ok = terms_of(b, c, f);
-        dvar[(size_t)b * S + s] = (unsigned char)variant_of(ok, c, f);
-    }
-#pragma unroll
-    for (int i = 0; i < kDistVariants; i++) {
-        if (i >= nv) break;
-        float2 dq[8];
-        float d512x;
-        // exactly item_finish's call: 1/N and the split pass's 1/2 ride on 1/frac
-        distance_factors((unsigned)(vc[i] >> 32), (unsigned)vc[i], vf[i] * (1.0f / 2048.0f), lane, dq, d512x, s_tw);
-#pragma unroll
-        for (int q = 0; q < 8; q++) dtab[((size_t)s * kDistVariants + i) * 512 + 64 * q + lane] = dq[q];
-    }
-}
-
 // parity tap: unnormalised spectra of arbitrary windows with the same LDS FFT
 __global__ __launch_bounds__(64) void rfft_debug_kernel(const float *__restrict__ win,
                                                        const float2 *__restrict__ twg,
@@ -2279,12 +2204,6 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
 hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
                               hipStream_t st) {
     hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
-    return hipGetLastError();
-}
-
-hipError_t launch_dist_table(const float *d_pos, int total, int S, const float2 *d_tw, float2 *d_dtab, unsigned char *d_dvar,
-                             hipStream_t st) {
-    hipLaunchKernelGGL(dist_table_kernel, dim3(S), dim3(64), 0, st, d_pos, total, S, d_tw, d_dtab, d_dvar);
     return hipGetLastError();
 }
 
