@@ -1535,9 +1535,13 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         if (e->rv_P > 0) {
             const ReverbPlan &pl = e->last_plan;
             const std::string b1 = std::to_string(e->rv_B1);
+            auto per_wg = [&](int n) { return std::string(n * e->S >= 1024 ? ",2>;" : ",1>;"); };  // transforms per workgroup
             auto products = [&](const ReverbBigParams &g) {
                 return g.n_prod > 0 ? "reverb_big_mac_kernel<" + b1 + "," + (g.n_prod >= 4 ? "16" : "1") + ">;reverb_big_ifft_kernel<" +
-                                          b1 + ">;" : std::string();
+                                          b1 + per_wg(g.n_prod) : std::string();
+            };
+            auto transforms = [&](const ReverbBigParams &g) {
+                return g.n_tr > 0 ? "reverb_big_fft_kernel<" + b1 + per_wg(g.n_tr) : std::string();
             };
             const int tile = e->B == 256 ? 8 : 16, grp = e->B == 256 ? 2 : 4;
             auto stage_b = [&](int form) {
@@ -1549,12 +1553,12 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             if (pl.big) k += products(pl.tail_early);
             if (e->last_rv_form == 4) {
                 k += stage_b(4);
-                if (pl.big && pl.transforms.n_tr > 0) k += "reverb_big_fft_kernel<" + b1 + ">;";
+                if (pl.big) k += transforms(pl.transforms);
             } else {
                 k += "reverb_fft_kernel<" + bs + ">;";
                 if (pl.big) {
                     if (pl.n_ranges > 1) k += stage_b(pl.forms[0]);
-                    if (pl.transforms.n_tr > 0) k += "reverb_big_fft_kernel<" + b1 + ">;";
+                    k += transforms(pl.transforms);
                     k += products(pl.middle) + products(pl.tail_late);
                     k += stage_b(pl.forms[pl.n_ranges > 1 ? 1 : 0]);
                 } else {

@@ -620,98 +620,139 @@ struct BigTwiddles {
     }
 };
 
-// one pass with the twiddles given (w[r - 1] for r = 1 .. R - 1), butterfly j of the pass
-template <int NPT, int R, int DIR>
-JF_DEV void big_pass(const float2 *a, float2 *b, const float2 *w, int Ns, int j) {
-    const int k = j & (Ns - 1);
-    float2 v[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) v[r] = a[rv_at<true>(j + r * (NPT / R))];
-#pragma unroll
-    for (int r = 1; r < R; r++) v[r] = DIR > 0 ? rv_mul(v[r], w[r - 1]) : rv_mulc(v[r], w[r - 1]);
-    rv_fftR<R, DIR>(v);
-    const int j0 = (j - k) * R + k;
-#pragma unroll
-    for (int r = 0; r < R; r++) b[rv_at<true>(j0 + r * Ns)] = v[r];
-}
-
-// The input comes in REGISTERS: v[r] = x[tid + r NPT / 8] of threads tid < NPT / 8 (the first pass needs no twiddles and
-// reads nothing from LDS: the caller loads straight from global memory).  Returns the buffer (a or b, padded layout rv_at<true>)
-// that holds the result in natural order.
-template <int NPT, int DIR, int NT>
-JF_DEV float2 *cfft_wg(float2 (&v)[8], float2 *a, float2 *b, const BigTwiddles<NPT, NT> &tw, int tid) {
+// NTR transforms of NPT points at once by one workgroup, IN PLACE in NTR buffers of LDS (padded layout rv_at<true>): the
+// twiddles depend on the thread and the pass only, so the transforms share them (registers, loads) and the barriers -- and
+// since every thread has read its butterflies' inputs before any thread writes (a barrier between), one buffer per transform
+// is enough.  The input comes in REGISTERS: v[t][r] = x_t[tid + r NPT / 8] of threads tid < NPT / 8 (the first pass needs no
+// twiddles and reads nothing from LDS: the caller loads straight from global memory).  The results lie in buf[t] in natural order.
+template <int NPT, int DIR, int NT, int NTR, int LEN>
+JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwiddles<NPT, NT> &tw, int tid) {
     const bool on = tid < NPT / 8;
-    if (on) {
-        rv_fft8<DIR>(v);
+    auto store = [&](int j, int Ns) {  // Stockham: butterfly j's outputs go to j0 + r Ns
+        const int k = j & (Ns - 1), j0 = (j - k) * 8 + k;
 #pragma unroll
-        for (int r = 0; r < 8; r++) a[rv_at<true>(8 * tid + r)] = v[r];
+        for (int t = 0; t < NTR; t++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) buf[t][rv_at<true>(j0 + r * Ns)] = v[t][r];
+    };
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < NTR; t++) rv_fft8<DIR>(v[t]);
+        store(tid, 1);
     }
     __syncthreads();
-    if (on) big_pass<NPT, 8, DIR>(a, b, tw.w8[0], 8, tid);
-    __syncthreads();
-    if (on) big_pass<NPT, 8, DIR>(b, a, tw.w8[1], 64, tid);
-    __syncthreads();
-    constexpr int RL = BigTwiddles<NPT, NT>::RL;
 #pragma unroll
-    for (int u = 0; u < BigTwiddles<NPT, NT>::NL; u++) big_pass<NPT, RL, DIR>(a, b, tw.wl[u], 512, tid + u * NT);
+    for (int p = 0; p < 2; p++) {
+        const int Ns = p ? 64 : 8;
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < NTR; t++) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[t][r] = buf[t][rv_at<true>(tid + r * (NPT / 8))];
+#pragma unroll
+                for (int r = 1; r < 8; r++) v[t][r] = DIR > 0 ? rv_mul(v[t][r], tw.w8[p][r - 1]) : rv_mulc(v[t][r], tw.w8[p][r - 1]);
+                rv_fft8<DIR>(v[t]);
+            }
+        }
+        __syncthreads();  // every input of the pass has been read
+        if (on) store(tid, Ns);
+        __syncthreads();
+    }
+    // last pass: radix RL, NL butterflies per thread (RL NL = NPT / NT <= 8 values: the registers of v[t] again)
+    constexpr int RL = BigTwiddles<NPT, NT>::RL, NL = BigTwiddles<NPT, NT>::NL;
+    static_assert(RL * NL <= 8, "the registers of v[t] hold the last pass's values");
+#pragma unroll
+    for (int t = 0; t < NTR; t++)
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int j = tid + u * NT;
+            float2 x[RL];
+#pragma unroll
+            for (int r = 0; r < RL; r++) x[r] = buf[t][rv_at<true>(j + r * (NPT / RL))];
+#pragma unroll
+            for (int r = 1; r < RL; r++) x[r] = DIR > 0 ? rv_mul(x[r], tw.wl[u][r - 1]) : rv_mulc(x[r], tw.wl[u][r - 1]);
+            rv_fftR<RL, DIR>(x);
+#pragma unroll
+            for (int r = 0; r < RL; r++) v[t][u * RL + r] = x[r];
+        }
     __syncthreads();
-    return b;
+#pragma unroll
+    for (int t = 0; t < NTR; t++)
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int j = tid + u * NT, k = j & 511, j0 = (j - k) * RL + k;
+#pragma unroll
+            for (int r = 0; r < RL; r++) buf[t][rv_at<true>(j0 + r * 512)] = v[t][u * RL + r];
+        }
+    __syncthreads();
 }
 
 constexpr int kBigThreads = 256;
 
 // X_m of transform i of the launch (m = first + i) for source s: spectrum of the 2 B1 dry samples of big blocks m - 2, m - 1
-// into fdl1 (packed: bin 0 = (X[0], X[B1])).
-template <int B1>
+// into fdl1 (packed: bin 0 = (X[0], X[B1])).  NTR transforms per workgroup (items g = NTR blockIdx + t of the n_tr S).
+template <int B1, int NTR>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
+    __shared__ float2 s_buf[NTR][rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
-    const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
     BigTwiddles<B1, kBigThreads> tw;
     tw.load(P.tw1, tid);
-    // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
-    // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
-    const float *ring = P.dryring + (size_t)s * P.Rn * B1;
-    const int Rd = P.Rn * B1;
-    const SrcSignal sg = P.dry[s];
-    const int L = sg.length, dc0 = P.dry_count_in[s];
-    const int rel0 = P.tr_rel_first + i * B1;
-    // signal index of the first sample at or behind the call's start (one division per workgroup, none per sample: the
-    // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
-    const int first_in = rel0 < 0 ? 0 : rel0;
-    const unsigned start = (unsigned)(((long long)dc0 + first_in) % L);
-    float2 v[8];  // z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8: the first pass's input
+    const int n_items = P.n_tr * P.S;
+    float2 v[NTR][8];  // z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8: the first pass's input
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-        const int rel = rel0 + 2 * m;  // even; the ring / signal boundary (rel = 0) never splits a pair
-        if (rel < 0) {
-            int pos = P.dry_pos0 + rel;
-            pos = pos < 0 ? pos + Rd : pos;
-            v[r] = *reinterpret_cast<const float2 *>(ring + pos);
-        } else {
-            unsigned i0 = start + (unsigned)(rel - first_in);
+    for (int t = 0; t < NTR; t++) {
+        const int g = min((int)blockIdx.x * NTR + t, n_items - 1);  // (an odd last item is done twice)
+        const int i = g / P.S, s = g - i * P.S;
+        // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
+        // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
+        const float *ring = P.dryring + (size_t)s * P.Rn * B1;
+        const int Rd = P.Rn * B1;
+        const SrcSignal sg = P.dry[s];
+        const int L = sg.length, dc0 = P.dry_count_in[s];
+        const int rel0 = P.tr_rel_first + i * B1;
+        // signal index of the first sample at or behind the call's start (one division per item, none per sample: the
+        // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
+        const int first_in = rel0 < 0 ? 0 : rel0;
+        const unsigned start = (unsigned)(((long long)dc0 + first_in) % L);
 #pragma unroll
-            for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
-            const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
-            v[r] = make_float2(sg.ptr[i0], sg.ptr[i1]);
+        for (int r = 0; r < 8; r++) {
+            const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+            const int rel = rel0 + 2 * m;  // even; the ring / signal boundary (rel = 0) never splits a pair
+            if (rel < 0) {
+                int pos = P.dry_pos0 + rel;
+                pos = pos < 0 ? pos + Rd : pos;
+                v[t][r] = *reinterpret_cast<const float2 *>(ring + pos);
+            } else {
+                unsigned i0 = start + (unsigned)(rel - first_in);
+#pragma unroll
+                for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
+                const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
+                v[t][r] = make_float2(sg.ptr[i0], sg.ptr[i1]);
+            }
         }
     }
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(v, s_a, s_b, tw, tid);
-    const int slot = (P.tr_slot_first + i) % P.R1;
-    float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
-    for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 zk = Z[rv_at<true>(q)];
-        const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
-        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-        const float2 wo = rv_mulc(o, P.tw1[q]);
-        float2 x = make_float2(e.x + wo.y, e.y - wo.x);
-        if (q == 0) {
-            x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
-            P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
+    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, tid);
+#pragma unroll
+    for (int t = 0; t < NTR; t++) {
+        const int g = (int)blockIdx.x * NTR + t;
+        if (g >= n_items) break;
+        const int i = g / P.S, s = g - i * P.S;
+        const float2 *Z = s_buf[t];
+        const int slot = (P.tr_slot_first + i) % P.R1;
+        float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
+        for (int q = tid; q < B1; q += kBigThreads) {
+            const float2 zk = Z[rv_at<true>(q)];
+            const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
+            const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+            const float2 wo = rv_mulc(o, P.tw1[q]);
+            float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+            if (q == 0) {
+                x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
+                P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
+            }
+            out[q] = x;
         }
-        out[q] = x;
     }
 }
 
@@ -779,67 +820,80 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
         if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
 }
 
-// Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.
-template <int B1>
+// Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.  NTR products
+// per workgroup (items g = NTR blockIdx + t of the n_prod S).
+template <int B1, int NTR>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
+    __shared__ float2 s_buf[NTR][rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
-    const int i = blockIdx.x / P.S, s = blockIdx.x - i * P.S;
-    const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
     BigTwiddles<B1, kBigThreads> tw;
     tw.load(P.tw1, tid);
-    // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes over
-    // the partitions (thread 0, which owns bin 0 below, is one of them)
-    float2 y0 = make_float2(0.f, 0.f);
-    if (tid < 64) {
-        const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
-        const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
-        for (int q = tid; q < P.n_part; q += 64) {
-            int slot = (P.anchor_slot_first + i - q) % P.R1;
-            if (slot < 0) slot += P.R1;
-            const float2 x = x0[slot], h = h0[q];
-            y0.x += x.x * h.x;
-            y0.y += x.y * h.y;
-        }
+    const int n_items = P.n_prod * P.S;
+    float2 v[NTR][8];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            y0.x += __shfl_xor(y0.x, m);
-            y0.y += __shfl_xor(y0.y, m);
+    for (int t = 0; t < NTR; t++) {
+        const int g = min((int)blockIdx.x * NTR + t, n_items - 1);
+        const int i = g / P.S, s = g - i * P.S;
+        const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
+        // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
+        // over the partitions (thread 0, which owns bin 0 below, is one of them)
+        float2 y0 = make_float2(0.f, 0.f);
+        if (tid < 64) {
+            const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
+            const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
+            for (int q = tid; q < P.n_part; q += 64) {
+                int slot = (P.anchor_slot_first + i - q) % P.R1;
+                if (slot < 0) slot += P.R1;
+                const float2 x = x0[slot], h = h0[q];
+                y0.x += x.x * h.x;
+                y0.y += x.y * h.y;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                y0.x += __shfl_xor(y0.x, m);
+                y0.y += __shfl_xor(y0.y, m);
+            }
+        }
+        // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
+        // memory into the first pass's registers: q = tid + r B1 / 8
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+            const float2 yk = y[q];
+            const float2 ym = y[(B1 - q) & (B1 - 1)];
+            if (q == 0) {
+                v[t][r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
+            } else {
+                const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+                const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+                const float2 o = rv_mul(d, P.tw1[q]);
+                v[t][r] = make_float2(e.x - o.y, e.y + o.x);
+            }
         }
     }
-    // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
-    // memory into the first pass's registers: q = tid + r B1 / 8
-    float2 v[8];
+    cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, tid);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-        const float2 yk = y[q];
-        const float2 ym = y[(B1 - q) & (B1 - 1)];
-        if (q == 0) {
-            v[r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
+    for (int t = 0; t < NTR; t++) {
+        const int g = (int)blockIdx.x * NTR + t;
+        if (g >= n_items) break;
+        const int i = g / P.S, s = g - i * P.S;
+        const float2 *zt = s_buf[t];
+        // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
+        if (!P.to_wet) {
+            float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
+            for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_at<true>(m)];
         } else {
-            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-            const float2 o = rv_mul(d, P.tw1[q]);
-            v[r] = make_float2(e.x - o.y, e.y + o.x);
-        }
-    }
-    const float2 *zt = cfft_wg<B1, +1, kBigThreads>(v, s_a, s_b, tw, tid);
-    // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
-    if (!P.to_wet) {
-        float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
-        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_at<true>(m)];
-    } else {
-        // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
-        const int c0 = P.st_in[s].count;
-        float *wet = P.wet + (size_t)s * P.Wr;
-        for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
-            const int n = 2 * m - B1;                   // sample inside the big block
-            const int kb = n / P.B;                      // (B is a power of two or 192: the compiler cannot know; once per pair)
-            const int k = P.wet_k0 + P.M * i + kb;       // block of the call
-            int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
-            w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
-            *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_at<true>(m)];
+            // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
+            const int c0 = P.st_in[s].count;
+            float *wet = P.wet + (size_t)s * P.Wr;
+            for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
+                const int n = 2 * m - B1;                   // sample inside the big block
+                const int kb = n / P.B;                      // (once per pair)
+                const int k = P.wet_k0 + P.M * i + kb;       // block of the call
+                int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
+                w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
+                *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_at<true>(m)];
+            }
         }
     }
 }
@@ -849,12 +903,12 @@ template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float *__restrict__ ir, int n_ir, int t0, float scale,
                                                                    const float2 *__restrict__ tw1, float2 *__restrict__ hspec1,
                                                                    float2 *__restrict__ h0 /* [P1] compact bin-0 pairs */) {
-    __shared__ float2 s_a[rv_buf_len<true>(B1)], s_b[rv_buf_len<true>(B1)];
+    __shared__ float2 s_buf[1][rv_buf_len<true>(B1)];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
     tw.load(tw1, tid);
-    float2 v[8];
+    float2 v[1][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
@@ -862,9 +916,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
         const long long i0 = (long long)t0 + (long long)q0 * B1 + n, i1 = i0 + 1;
         const float a0 = (n < B1 && i0 < n_ir) ? ir[i0] : 0.0f;
         const float a1 = (n + 1 < B1 && i1 < n_ir) ? ir[i1] : 0.0f;
-        v[r] = make_float2(a0, a1);
+        v[0][r] = make_float2(a0, a1);
     }
-    const float2 *Z = cfft_wg<B1, -1, kBigThreads>(v, s_a, s_b, tw, tid);
+    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, tid);
+    const float2 *Z = s_buf[0];
     for (int q = tid; q < B1; q += kBigThreads) {
         const float2 zk = Z[rv_at<true>(q)];
         const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
@@ -1004,9 +1059,12 @@ hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int
     return hipGetLastError();
 }
 
+// two transforms per workgroup (shared twiddles and barriers) once there are enough of them to fill the GPU
 template <int B1>
 static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
-    hipLaunchKernelGGL(reverb_big_fft_kernel<B1>, dim3(P.n_tr * P.S), dim3(kBigThreads), 0, st, P);
+    const int n = P.n_tr * P.S;
+    if (n >= 1024) hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 2>), dim3((n + 1) / 2), dim3(kBigThreads), 0, st, P);
+    else hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 1>), dim3(n), dim3(kBigThreads), 0, st, P);
 }
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
@@ -1018,7 +1076,9 @@ static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
     } else {
         hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(per_spec * P.n_prod * P.S), dim3(64 * kBigMacWaves), 0, st, P);
     }
-    hipLaunchKernelGGL(reverb_big_ifft_kernel<B1>, dim3(P.n_prod * P.S), dim3(kBigThreads), 0, st, P);
+    const int n = P.n_prod * P.S;
+    if (n >= 1024) hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 2>), dim3((n + 1) / 2), dim3(kBigThreads), 0, st, P);
+    else hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 1>), dim3(n), dim3(kBigThreads), 0, st, P);
 }
 static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {

@@ -252,7 +252,9 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
             assert "reverb_mac_tiled_kernel<128,16>" in ks, ks
         else:
             # calls of whole big blocks: the big partitions form every block's wet signal, no block goes through the head
-            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in ks and "reverb_big_fft_kernel<2048>" in ks, ks
+            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in ks, ks
+            # (256 sources x 16 big blocks: two transforms per workgroup; 256 x 2: one)
+            assert f"reverb_big_fft_kernel<2048,{2 if K >= 64 else 1}>" in ks and f"reverb_big_ifft_kernel<2048,{2 if K >= 64 else 1}>" in ks, ks
             assert not any(k.startswith("reverb_mac") for k in ks), ks
         parts.append(e.read_device(e.partial_device_ptr(), (K, S, 2 * B)))
         mixes.append(e.read_device(e.mix_device_ptr(), (K, 2 * B)))

@@ -269,10 +269,10 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
     for _ in range(16):
         e.process_block()
     ks = e.last_kernels()          # the 16th block completes a big block: its spectrum is formed behind the head
-    assert ks[:2] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048>"], ks
+    assert ks[:2] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048,1>"], ks
     e.process_block()
     ks = e.last_kernels()          # the 17th block is the first of big block 1: TAIL(1) in front of the head
-    assert ks[:3] == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048>", "reverb_mac_kernel<128,1,true>"], ks
+    assert ks[:3] == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048,1>", "reverb_mac_kernel<128,1,true>"], ks
     e.process_block()
     assert not any(k.startswith("reverb_big") for k in e.last_kernels())
     e.close()
