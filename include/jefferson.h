@@ -333,10 +333,6 @@ int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big
 int jf_debug_set_interp_table(jf_engine *e, int on);
 /* 1 if the last batch run's descriptors could name pre-interpolated rows (the kernel instantiation that reads them ran). */
 int jf_debug_last_run_used_rows(const jf_engine *e);
-/* Of 16 sources that MOVE in a block, how many read pre-interpolated rows (0..16; sources that do not move always do).
- * A moving source's rows stream from HBM while the measured rows stay in the caches but cost the weighting: the share
- * balances memory bandwidth against vector instructions.  Results are bit-identical whatever it is. */
-int jf_debug_set_interp_share(jf_engine *e, int sixteenths);
 /* The setting above (0, 1 or 2); 0 for an engine without the rows. */
 int jf_debug_interp_table(const jf_engine *e);
 /* How many of the first n_items descriptors of the last batch run (items b * n_sources + s) carry any bit of `mask` in

@@ -98,7 +98,6 @@ _SIGS = {
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
-    "jf_debug_set_interp_share": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
     "jf_debug_count_desc_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jf_debug_read_table_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f]),
@@ -402,9 +401,6 @@ class Engine:
 
     def last_run_used_rows(self):
         return bool(lib().jf_debug_last_run_used_rows(self.h))
-
-    def set_interp_share(self, sixteenths):
-        self._chk(lib().jf_debug_set_interp_share(self.h, int(sixteenths)))
 
     def interp_table(self):
         """0 = off / not built, 1 = always, 2 = decided per run"""

@@ -37,10 +37,6 @@ constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
 constexpr int kInterpEleMin = -40, kInterpEleMax = 90, kInterpAzi = 360;
 constexpr int kInterpRows = (kInterpEleMax - kInterpEleMin + 1) * kInterpAzi;  // 47 160
 constexpr int kModeBasic = 1, kModeCorrected = 2, kModeInterpRows = 4;  // bits of the kernels' `mode`
-// bits 8..12 of `mode`: of 16 MOVING sources, how many read pre-interpolated rows (sources that do not move always do).
-// Rows of moving sources stream from HBM, the measured rows and their weights cost vector instructions: the share
-// balances the two (results are bit-identical whatever it is).
-constexpr int kModeShareShift = 8, kModeShareMask = 31;
 // Tuning knobs of the fused kernel (overridable at build time for A/B runs):
 // waves (= work items) per workgroup, and the minimum waves per SIMD the register
 // allocator must leave room for (__launch_bounds__ second argument; 0 = unconstrained).

@@ -77,7 +77,6 @@ struct jf_engine {
     // items moving (profiles/r04/interp_table.md).  Runs of an uploaded trajectory take the rows unless more than
     // kInterpMovedMax of their items move; calls without a trajectory take them.
     int interp_use = 0;
-    int interp_share = 16;      // of 16 moving sources, how many read them (jf_debug_set_interp_share; tuning)
     std::vector<unsigned> traj_moved;  // [traj_blocks + 1] prefix counts of the uploaded trajectory's items that move
     bool last_rows = false;     // the last batch run's descriptors could name pre-interpolated rows
     float2 *d_tw = nullptr;
@@ -405,7 +404,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
         rows = moved <= kInterpMovedMax;
     }
     e->last_rows = rows;
-    const int mode_now = kernel_mode(e) | (rows ? (kModeInterpRows | (e->interp_share << kModeShareShift)) : 0);
+    const int mode_now = kernel_mode(e) | (rows ? kModeInterpRows : 0);
     // per-kernel timing (profiling >= 2) keeps prep and mix as launches of their own
     const bool have = e->ahead.valid && e->profiling < 2 && first_block >= 0 && e->ahead.first == first_block &&
                       e->ahead.K == K && e->ahead.mode == mode_now && e->ahead.canon == canon &&
@@ -627,8 +626,6 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             e->interp_built = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
             e->interp_use = e->interp_built ? 2 : 0;
             if (env && e->interp_built && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
-            const char *sh = getenv("JF_INTERP_SHARE");  // tuning runs
-            if (sh && atoi(sh) >= 0 && atoi(sh) <= 16) e->interp_share = atoi(sh);
         }
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + (e->interp_built ? kInterpRows : 0)) * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
@@ -1384,14 +1381,6 @@ int jf_debug_set_interp_table(jf_engine *e, int on) {
     if (on < 0 || on > 2) return fail(e, JF_ERR_ARG, "0 = never, 1 = always, 2 = decided per run");
     if (on && !e->interp_built) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
     e->interp_use = on;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
-    return JF_OK;
-    });
-}
-
-int jf_debug_set_interp_share(jf_engine *e, int sixteenths) {
-    return jf_guard([&]() -> int {
-    if (!e || sixteenths < 0 || sixteenths > 16) return JF_ERR_ARG;
-    e->interp_share = sixteenths;
     return JF_OK;
     });
 }

@@ -1057,9 +1057,6 @@ JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
-#ifndef JF_PRE_TOUCH
-#define JF_PRE_TOUCH 0  // 1: the pre-interpolated rows of the next two half-filters are touched a source ahead (see there)
-#endif
 #ifndef JF_PAIR_OVERLAP
 #define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
                            // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
@@ -1298,30 +1295,6 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
             int count0, L;
             item_gather<NOUT>(P, b, src, opaque(lane), z, count0, L);
             JF_EXP_PHASE(0);  // own source: descriptor and signal records, window requests
-#if JF_PRE_TOUCH
-            // Pre-interpolated rows come from HBM (386 MB: no cache holds them), and a half-filter asks for them only when
-            // it needs them.  One lane per 128-byte line, this wave's half of the two rows of MY source (filtered a forward
-            // transform from now) and of the source the PARTNER is starting on (filtered a whole source from now) are
-            // touched here, behind the window requests: the filters then find them in the L2.  The loaded words are kept
-            // until the own filter's loads have returned (younger requests: no extra wait).
-            float touch_a = 0.0f, touch_b = 0.0f;
-            {
-                const int ln = opaque(lane);
-                const unsigned sub = (unsigned)qb * 1024u + (unsigned)(ln & 31) * 128u;
-                const char *tab = reinterpret_cast<const char *>(P.htab);
-                if (dp->flags & 4) {
-                    const unsigned row = ln < 32 ? (unsigned)dp->rows_old[0] : (unsigned)dp->rows_new[0];
-                    touch_a = *reinterpret_cast<const float *>(tab + ((size_t)row * 8192u + sub));
-                }
-                if (2 * j + (half ^ 1) < G) {
-                    const ItemDesc JF_CONST_AS *pd = as_const(db + ord[2 * j + (half ^ 1)]);
-                    if (pd->flags & 4) {
-                        const unsigned row = ln < 32 ? (unsigned)pd->rows_old[0] : (unsigned)pd->rows_new[0];
-                        touch_b = *reinterpret_cast<const float *>(tab + ((size_t)row * 8192u + sub));
-                    }
-                }
-            }
-#endif
 #if JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) take_partner_source(jp++);
 #endif
@@ -1364,9 +1337,6 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
                 });
                 JF_EXP_PHASE(3);  // own source's two half-filters
             }
-#if JF_PRE_TOUCH
-            asm volatile("; touched rows" ::"v"(touch_a), "v"(touch_b));
-#endif
 #if !JF_PAIR_OVERLAP
             if (jp < j && jp < n_his) {
                 take_partner_source(jp++);
@@ -1770,10 +1740,7 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
         const float e_in = old_half ? old_ele : ele, a_in = old_half ? old_azi : azi;
         // A whole-degree position inside the pre-interpolated part of the table (jf_device.h: htab) is ONE row with weight 1:
         // the row holds the weighted sum the rule below would ask for, formed by the same operations in the same order.
-        // Of the sources that move in this block only a share takes the rows (jf_device.h: kModeShareShift), chosen by
-        // source index so that all blocks of a source agree (block b's new row is block b + 1's old row).
-        const bool share_ok = !moved || ((s * 11) & 15) < ((mode >> kModeShareShift) & kModeShareMask);
-        pre = canon && (mode & kModeInterpRows) != 0 && share_ok && e_in >= (float)kInterpEleMin &&
+        pre = canon && (mode & kModeInterpRows) != 0 && e_in >= (float)kInterpEleMin &&
               e_in <= (float)kInterpEleMax && a_in >= 0.0f && a_in < (float)kInterpAzi && floorf(e_in) == e_in &&
               floorf(a_in) == a_in;
         int n_in;

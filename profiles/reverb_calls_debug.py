@@ -1,6 +1,8 @@
+"""Which blocks of a run of calls does the non-uniformly partitioned reverb get wrong?  (How the fut-ring collision of round 4 was found:
+runs of calls of several shapes against the float64 model, per-block errors.)  usage: python profiles/reverb_calls_debug.py [B]"""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from jf_load import jf
 import model64
