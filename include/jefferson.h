@@ -320,6 +320,11 @@ int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, 
  * block + partitions of 16 blocks for the rest: P / 16 + 16; Gardner's zero-latency scheme with two sizes).  The reference's
  * own form is one product over the whole signal (cudaPart.cu:87-153).  Same results to float32 rounding. */
 int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
+/* The schedule of the non-uniformly partitioned reverb for a call of K blocks that starts at absolute block j0, with big blocks
+ * of M blocks and TAIL formed up to big block fut_m (host logic only: no engine, no GPU; tests/test_reverb_plan.py replays
+ * runs of calls against a model of the rings).  out = {m_lo, n_tr, ma, n_mid, n_ranges, kb0, kn0, kb1, kn1, copy_lo, copy_hi,
+ * skip_lo, skip_hi, tail_early (-1: none), tail_late (-1: none), new fut_m} -- jf_host.h: ReverbSchedule. */
+int jf_debug_reverb_schedule(long long j0, int K, int M, long long fut_m, long long out[16]);
 /* Returns the number of partitions of frames_per_buffer the impulse response has (0: stage off); *head = partitions of that
  * size in use, *big = partitions of *big_taps taps behind them (0, 0: uniform partitioning). */
 int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps);

@@ -98,6 +98,7 @@ _SIGS = {
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
+    "jf_debug_reverb_schedule": (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_longlong)]),
     "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
     "jf_debug_count_desc_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "jf_debug_read_table_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f]),
@@ -170,6 +171,17 @@ def interpolation(ele, azi, flags=0):
     rc = lib().jf_interpolation_ex(ele, azi, flags, _ip(idx), _fp(om)) if flags else \
         lib().jf_interpolation(ele, azi, _ip(idx), _fp(om))
     return None if rc else (idx, om)
+
+
+def reverb_schedule(j0, K, M, fut_m):
+    """jf_debug_reverb_schedule as a dict (host logic only)"""
+    out = (C.c_longlong * 16)()
+    rc = lib().jf_debug_reverb_schedule(j0, K, M, fut_m, out)
+    if rc:
+        raise JfError(rc, "reverb_schedule")
+    names = ("m_lo", "n_tr", "ma", "n_mid", "n_ranges", "kb0", "kn0", "kb1", "kn1", "copy_lo", "copy_hi", "skip_lo", "skip_hi",
+             "tail_early", "tail_late", "fut_m")
+    return {n: int(v) for n, v in zip(names, out)}
 
 
 def pick_hrtf(ele, azi):

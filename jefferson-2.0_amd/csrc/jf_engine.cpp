@@ -263,7 +263,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     plan.big = e->rv_P1 > 0;
     if (plan.big) {
         // Absolute block indices j0 .. j1 - 1; big block m = blocks 16 m .. 16 m + 15.
-        const long long j0 = e->rv_blocks, j1 = j0 + K;
+        const long long j0 = e->rv_blocks;
         const int B1 = e->rv_B1, R1 = e->rv_R1, Rn = e->rv_Rn, Fn = e->rv_Fn, M = e->rv_M;
         R.dryring = e->d_rv_dryring;
         R.Rd = Rn * B1;
@@ -294,40 +294,29 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         G.M = M;
         G.NP = e->rv_P1 + 17;
         auto mod = [](long long a, int n) { return (int)(((a % n) + n) % n); };
-        // X_m is formed in the call that takes in block 16 m - 1:  j0 < 16 m <= j1
-        const long long m_lo = j0 / M + 1, m_hi = j1 / M;
+        const ReverbSchedule sc = host_reverb_schedule(j0, K, M, e->rv_fut_m);  // which X_m, FULL, TAIL and ranges: jf_host.cpp
+        e->rv_fut_m = sc.fut_m;
         plan.transforms = G;
-        plan.transforms.n_tr = m_hi >= m_lo ? (int)(m_hi - m_lo + 1) : 0;
-        plan.transforms.tr_slot_first = mod(m_lo, R1);
-        plan.transforms.tr_rel_first = (int)((m_lo - 2) * B1 - j0 * e->B);
-        // big blocks that lie inside the call: m = ma .. m_hi - 1, their wet signal is FULL(m), anchored at X_{m+1}
-        const long long ma = (j0 + M - 1) / M;
-        const int n_mid = m_hi > ma ? (int)(m_hi - ma) : 0;
+        plan.transforms.n_tr = sc.n_tr;
+        plan.transforms.tr_slot_first = mod(sc.m_lo, R1);
+        plan.transforms.tr_rel_first = (int)((sc.m_lo - 2) * B1 - j0 * e->B);
+        const int n_mid = sc.n_mid;
         plan.middle = G;
         plan.middle.n_prod = n_mid;
-        plan.middle.anchor_slot_first = mod(ma + 1, R1);
+        plan.middle.anchor_slot_first = mod(sc.ma + 1, R1);  // FULL(m) is anchored at X_{m+1}
         plan.middle.h_first = 0;
         plan.middle.n_part = e->rv_P1 + 1;
         plan.middle.to_wet = 1;
-        plan.middle.wet_k0 = (int)(ma * M - j0);
-        // the other blocks go through the uniform stage (head) + TAIL of their big block
-        if (n_mid > 0) {
-            plan.n_ranges = 2;
-            plan.kb[0] = 0;
-            plan.kn[0] = (int)(ma * M - j0);
-            plan.kb[1] = (int)(m_hi * M - j0);
-            plan.kn[1] = K - plan.kb[1];
-            // of the middle's blocks only the last 15 are transformed (the state the next blocks read)
-            R.copy_lo = plan.kn[0];
-            R.copy_hi = plan.kb[1] - (M - 1);
-            // ... and only the last whole big block is copied to the dry ring (later calls' transforms reach back two big blocks)
-            R.skip_lo = R.copy_lo;
-            R.skip_hi = std::max(R.copy_lo, plan.kb[1] - M);
-        } else {
-            plan.n_ranges = 1;
-            plan.kb[0] = 0;
-            plan.kn[0] = K;
+        plan.middle.wet_k0 = (int)(sc.ma * M - j0);
+        plan.n_ranges = sc.n_ranges;
+        for (int r = 0; r < 2; r++) {
+            plan.kb[r] = sc.kb[r];
+            plan.kn[r] = sc.kn[r];
         }
+        R.copy_lo = sc.copy_lo;
+        R.copy_hi = sc.copy_hi;
+        R.skip_lo = sc.skip_lo;
+        R.skip_hi = sc.skip_hi;
         auto tail_for = [&](long long m) {
             ReverbBigParams T = G;
             T.n_prod = 1;
@@ -340,19 +329,8 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         };
         plan.tail_early = G;
         plan.tail_late = G;
-        // TAIL of the big block the call starts in, if one of its blocks goes through the uniform stage and nobody has formed
-        // it yet (its X_m are all there: the block before it has been taken in)
-        const long long mb = j0 / M;
-        if (plan.kn[0] > 0 && e->rv_fut_m < mb) {
-            plan.tail_early = tail_for(mb);
-            e->rv_fut_m = mb;
-        }
-        // ... and of the big block the call ends in, if the call reaches into it behind a boundary it has passed itself
-        const bool late = n_mid > 0 ? plan.kn[1] > 0 : (m_hi > mb && j1 > m_hi * M);
-        if (late && e->rv_fut_m < m_hi) {
-            plan.tail_late = tail_for(m_hi);
-            e->rv_fut_m = m_hi;
-        }
+        if (sc.tail_early >= 0) plan.tail_early = tail_for(sc.tail_early);
+        if (sc.tail_late >= 0) plan.tail_late = tail_for(sc.tail_late);
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
@@ -1418,6 +1396,15 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
     e->rv_partitioning = how;  // in effect from the next jf_reverb_set_ir
     return JF_OK;
     });
+}
+
+int jf_debug_reverb_schedule(long long j0, int K, int M, long long fut_m, long long out[16]) {
+    if (!out || K <= 0 || M <= 0 || j0 < 0) return JF_ERR_ARG;
+    const ReverbSchedule s = host_reverb_schedule(j0, K, M, fut_m);
+    const long long v[16] = {s.m_lo, s.n_tr, s.ma, s.n_mid, s.n_ranges, s.kb[0], s.kn[0], s.kb[1], s.kn[1], s.copy_lo, s.copy_hi,
+                             s.skip_lo, s.skip_hi, s.tail_early, s.tail_late, s.fut_m};
+    for (int i = 0; i < 16; i++) out[i] = v[i];
+    return JF_OK;
 }
 
 int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps) {

@@ -376,6 +376,52 @@ void dfft(std::vector<double> &re, std::vector<double> &im, int sign) {
 }
 }  // namespace
 
+ReverbSchedule host_reverb_schedule(long long j0, int K, int M, long long fut_m) {
+    ReverbSchedule s{};
+    const long long j1 = j0 + K;
+    // X_m is formed in the call that takes in block M m - 1:  j0 < M m <= j1
+    s.m_lo = j0 / M + 1;
+    const long long m_hi = j1 / M;
+    s.n_tr = m_hi >= s.m_lo ? (int)(m_hi - s.m_lo + 1) : 0;
+    // big blocks that lie inside the call: m = ma .. m_hi - 1, their wet signal is FULL(m), anchored at X_{m+1}
+    s.ma = (j0 + M - 1) / M;
+    s.n_mid = m_hi > s.ma ? (int)(m_hi - s.ma) : 0;
+    // the other blocks go through the uniform stage (head) + TAIL of their big block
+    if (s.n_mid > 0) {
+        s.n_ranges = 2;
+        s.kb[0] = 0;
+        s.kn[0] = (int)(s.ma * M - j0);
+        s.kb[1] = (int)(m_hi * M - j0);
+        s.kn[1] = K - s.kb[1];
+        // of the middle's blocks only the last M - 1 are transformed (the state the next blocks read) ...
+        s.copy_lo = s.kn[0];
+        s.copy_hi = s.kb[1] - (M - 1);
+        // ... and only the last whole big block is copied to the dry ring (later calls' transforms reach back two big blocks)
+        s.skip_lo = s.copy_lo;
+        s.skip_hi = s.copy_lo > s.kb[1] - M ? s.copy_lo : s.kb[1] - M;
+    } else {
+        s.n_ranges = 1;
+        s.kb[0] = 0;
+        s.kn[0] = K;
+    }
+    s.tail_early = s.tail_late = -1;
+    s.fut_m = fut_m;
+    // TAIL of the big block the call starts in, if one of its blocks goes through the uniform stage and nobody has formed it
+    // yet (its X_m are all there: the block before it has been taken in)
+    const long long mb = j0 / M;
+    if (s.kn[0] > 0 && s.fut_m < mb) {
+        s.tail_early = mb;
+        s.fut_m = mb;
+    }
+    // ... and of the big block the call ends in, if the call reaches into it behind a boundary it has passed itself
+    const bool late = s.n_mid > 0 ? s.kn[1] > 0 : (m_hi > mb && j1 > m_hi * M);
+    if (late && s.fut_m < m_hi) {
+        s.tail_late = m_hi;
+        s.fut_m = m_hi;
+    }
+    return s;
+}
+
 float host_reverb_rms_gain(const float *x, size_t n, const float *ir, size_t n_ir) {
     // cudaPart.cu:170-186 PadData: both padded to new_size = n + (n_ir - n_ir/2); the product of
     // the two new_size-point spectra is a CIRCULAR convolution of that length (the tail wraps).

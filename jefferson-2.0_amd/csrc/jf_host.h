@@ -28,6 +28,25 @@ int load_hrir_dir(const char *dir, std::vector<float> *hrir, int *taps, std::str
 // rms(x) / rms(x (*) ir) with the padding and circular length of cudaPart.cu:170-186, in double.
 float host_reverb_rms_gain(const float *x, size_t n, const float *ir, size_t n_ir);
 
+// What the non-uniformly partitioned reverb does in a call of K blocks that starts at absolute block j0 (big blocks of M blocks;
+// fut_m: TAIL has been formed for every big block up to this one) -- the schedule only, no GPU state (ReverbBigParams in
+// jf_device.h explains X_m, TAIL, FULL).  The engine turns it into kernel parameters; tests/test_reverb_plan.py replays runs
+// of calls against a model of the rings.
+struct ReverbSchedule {
+    long long m_lo;        // transforms X_m for m = m_lo .. m_lo + n_tr - 1 (those with j0 < M m <= j0 + K)
+    int n_tr;
+    long long ma;          // whole big blocks inside the call: ma .. ma + n_mid - 1, formed by FULL
+    int n_mid;
+    int n_ranges;          // block ranges that go through the uniform stage (head) + TAIL: [kb, kb + kn)
+    int kb[2], kn[2];
+    int copy_lo, copy_hi;  // blocks of the call that only copy their samples to the dry ring
+    int skip_lo, skip_hi;  // blocks the transform kernel does not visit at all
+    long long tail_early;  // TAIL(m) to form before anything else (-1: none) ...
+    long long tail_late;   // ... and behind the transforms (-1: none)
+    long long fut_m;       // the new value of fut_m
+};
+ReverbSchedule host_reverb_schedule(long long j0, int K, int M, long long fut_m);
+
 int wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate, std::string *err);
 int wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate,
                        std::string *err);
