@@ -53,8 +53,8 @@ def _replay(jf, sizes, M, P1, max_k):
                         continue
                     assert small.get((head + k - p) % Rg) == jj, ("small spectrum missing", j, jj, small.get((head + k - p) % Rg))
                 m = j // M
-                if m > 0:
-                    assert fut.get(m % Fn) == m, ("fut place holds another big block's TAIL", j, m, fut.get(m % Fn))
+                # (big block 0 has no TAIL: its place must still hold the zeros of the reset)
+                assert fut.get(m % Fn) == (m if m > 0 else None), ("fut place holds another big block's TAIL", j, m, fut.get(m % Fn))
                 assert j not in wet_by
                 wet_by[j] = "head+tail"
 
