@@ -605,7 +605,15 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             e->interp_use = e->interp_built ? 2 : 0;
             if (env && e->interp_built && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
         }
-        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + (e->interp_built ? kInterpRows : 0)) * 512));
+        if (e->interp_built &&
+            hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + kInterpRows) * 512) != hipSuccess) {
+            // no room for the 386 MB of pre-interpolated rows: the engine works without them (per-block weighting)
+            (void)hipGetLastError();
+            e->d_htab = nullptr;
+            e->interp_built = false;
+            e->interp_use = 0;
+        }
+        if (!e->d_htab) JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
         for (int i = 0; i < 2; i++) {
