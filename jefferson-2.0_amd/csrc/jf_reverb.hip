@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbParams P) {
 // (red, red + stride, ...), untangle the packed real spectrum, inverse FFT, write the wet block.
 // FIX0: the partial spectra treated the packed pair in bin 0 as a complex number; the true pair
 // (sum_p X0[k-p] .* H0[p]) is formed here from the compact copies, lanes over the partitions.
+// tw: exp(+2 pi i j / 1024), j < 1024 -- P.tw, or a copy of it in LDS
 template <int B, int NW, bool FIX0 = false>
-JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const ReverbParams &P, int s, int k, int lane) {
+JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const ReverbParams &P, int s, int k, int lane,
+                       const float2 *tw) {
     // Y[q] (packed), then Z[q] = E + j O with E = (Y[q] + conj Y[B-q])/2, O = conj(W^q) (Y[q] - conj Y[B-q])/2
     float2 *ybuf = fftbuf, *zbuf = fftbuf + B;
     for (int q = lane; q < B; q += 64) {
@@ -332,13 +334,13 @@ JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const Reve
         } else {
             const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
             const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-            const float2 o = rv_mul(d, P.tw[q * (512 / B)]);  // W^-q = exp(+2 pi i q / 2B)
+            const float2 o = rv_mul(d, tw[q * (512 / B)]);  // W^-q = exp(+2 pi i q / 2B)
             z = make_float2(e.x - o.y, e.y + o.x);
         }
         zbuf[q] = z;
     }
     JF_RV_SYNC();
-    const float2 *zt = cfft_small<B, +1>(zbuf, ybuf, P.tw, lane);
+    const float2 *zt = cfft_small<B, +1>(zbuf, ybuf, tw, lane);
     // overlap-save: time samples B..2B-1 = z[m], m >= B/2 (even, odd interleaved)
     const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
     float *wet = P.wet + (size_t)s * P.Wr;
@@ -374,6 +376,16 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     __shared__ float2 s_red[kMacWaves][T][B];
     __shared__ float2 s_fft[T][2 * B];
     __shared__ float2 s_x0[FUSE ? B : 1];
+    // one-block calls: the two transforms of the block are this kernel's chain, and each of their passes reads twiddles --
+    // from LDS (staged by the 1024 threads, one entry each), not from global memory
+    __shared__ float2 s_tw[FUSE ? 1024 : 1];
+    const float2 *tw = P.tw;
+    if (FUSE) {
+        s_tw[threadIdx.x] = P.tw[threadIdx.x];
+        static_assert(!FUSE || 64 * kMacWaves == 1024, "one twiddle per thread");
+        __syncthreads();
+        tw = s_tw;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int SG = P.S / T;
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     }
     const bool transformer = FUSE && wave == kMacWaves - 1;
     if (transformer) {
-        rv_forward<B>(P, k, s0, s_fft[0], s_fft[0] + B, lane, s_x0, P.tw);
+        rv_forward<B>(P, k, s0, s_fft[0], s_fft[0] + B, lane, s_x0, tw);
         JF_RV_SYNC();
         // partition 0: the spectrum just made, from LDS
         const float2 *hp = hs;
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(64 * kMacWaves) void reverb_mac_kernel(const Reverb
     }
     __syncthreads();
     if (wave >= T) return;
-    mac_finish<B, kMacWaves>(&s_red[0][wave][0], T * B, s_fft[wave], P, s0 + wave, k, lane);
+    mac_finish<B, kMacWaves>(&s_red[0][wave][0], T * B, s_fft[wave], P, s0 + wave, k, lane, tw);
 }
 
 // Batch form of stage B (many blocks per call): one workgroup per (source, KB consecutive blocks).
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
     __syncthreads();
 #pragma unroll 1
     for (int i = wave; i < KB; i += kTileWaves)
-        if (k0 + i < P.kb + P.kn) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane);
+        if (k0 + i < P.kb + P.kn) mac_finish<B, NC, true>(&s_red[0][i][0], KB * B, s_fft[wave], P, s, k0 + i, lane, P.tw);
 }
 
 // ------------------------------------------------- big partitions (level 1) --
