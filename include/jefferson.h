@@ -282,7 +282,7 @@ int jf_debug_source_order(const jf_engine *e, int *order);
  * forms add the same products in different associations. */
 int jf_debug_set_reverb_form(jf_engine *e, int form);
 /* Per-block calls (jf_process_block / jf_submit_block / jf_callback) with at most n sources use the
- * one-launch real-time kernel (descriptors + spatialisation + mix per workgroup of 16 sources, pinned host
+ * one-launch real-time kernel (descriptors + spatialisation + mix per workgroup of 8 sources -- 16 beyond 512 --, pinned host
  * I/O, the workgroups' blocks added on the host in order); above that, the batch pipeline with one block.
  * Default 8192; 0 disables the real-time kernel. */
 int jf_debug_set_rt_max_sources(jf_engine *e, int n);

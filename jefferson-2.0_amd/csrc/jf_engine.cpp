@@ -34,6 +34,7 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
 hipError_t launch_mix(const float *d_partial, float *d_mix, int S, int K, int B, hipStream_t st);
 hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, int K, int B, const RingTable &rt, int mode,
                            const float *d_pos_next, ItemDesc *d_desc_next, int S, int K_next, int canon, hipStream_t st);
+int rt_waves_per_wg(int n_sources);
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
                            int n_wgs, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
@@ -60,7 +61,7 @@ struct EventPair {
 
 constexpr double kInterpMovedMax = 0.30;  // jf_engine::interp_use == 2: largest share of moving items a run may have to take the rows
 constexpr long kRtPollNs = 2000000;  // jf_collect_block polls the real-time kernel's completion words for at most this long
-constexpr int kRtMaxWgs = 128;  // workgroups (16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
+constexpr int kRtMaxWgs = 128;  // workgroups (8 or 16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
 
 struct jf_engine {
     jf_config cfg{};
@@ -927,8 +928,10 @@ int jf_submit_block(jf_engine *e) {
             P.err = e->hd_err;
             P.order = e->d_order;
             P.mode = kernel_mode(e);
-            // one 16-wave workgroup per 16 sources (at most kRtMaxWgs = 2048 sources: beyond that a wave takes several)
-            int wgs = (e->S + 15) / 16;
+            // a wave per source, 8 or 16 waves to the workgroup (jf_kernels.hip: rt_block_kernel); at most kRtMaxWgs workgroups
+            // = 2048 sources: beyond that a wave takes several
+            const int rtw = rt_waves_per_wg(e->S);
+            int wgs = (e->S + rtw - 1) / rtw;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
             e->rt_seq = e->rt_seq == 0x7fffffff ? 1 : e->rt_seq + 1;
             JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, e->hd_done, e->rt_seq, wgs, e->stream));
@@ -1554,7 +1557,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         const int n_part = e->last_group > 0 ? e->S / e->last_group : e->S;
         const std::string mix_name = (n_part == 16 || n_part == 32 || n_part == 64)
                                          ? ";mix_few_kernel<" + std::to_string(n_part / 16) + ">" : std::string(";mix_kernel");
-        if (e->last_rt) k += "rt_block_kernel<" + nb + ">";
+        if (e->last_rt) k += "rt_block_kernel<" + nb + "," + std::to_string(rt_waves_per_wg(e->S)) + ">";
         else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb +
                   (e->last_fused_prep ? ">+prep" : ">") + (e->last_mix_prep ? ";mix_prep_kernel" : mix_name);
         e->kernels = k;

@@ -1933,19 +1933,24 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
 
 // ------------------------------------------------------- real-time kernel --
 // One audio block for up to a few hundred sources in ONE launch (the per-block call of the reference's
-// audio callback): workgroup g of n, wave w takes sources 16 g + w, + 16 n, ...; lane 0 builds the
+// audio callback): workgroup g of n, wave w takes sources RTW g + w, + RTW n, ...; lane 0 builds the
 // descriptor in LDS (no prep launch), the wave spatialises, the waves' stereo blocks are summed
 // in wave order through LDS (no mix launch) and workgroup g writes its sum to out + g B.  pos and out
 // may be host-mapped pinned memory, so a block costs one launch and one synchronisation, no copies;
-// the caller adds the n partial blocks (n = 1 for up to 16 sources).
-constexpr int kRtWaves = 16;
-template <int NOUT>
+// the caller adds the n partial blocks (n = 1 for up to RTW sources).
+// RTW = waves (= sources per turn) of a workgroup: 8 or 16.  Sixteen waves share a compute unit's four SIMDs four
+// to one and a block takes 3-4 us longer than with eight (two to one; four waves, one to one, gain nothing more) -- but every
+// workgroup's partial block crosses PCIe, and from ~1000 sources on the fewer, larger workgroups win
+// (profiles/r04/rt_waves.md: 16 .. 128 sources 22.5-24.4 -> 18.4-21.1 us, 512 equal, 1024 30.9 against 33.6).
+constexpr int kRtWavesFew = 8, kRtWavesMany = 16, kRtFewMaxSources = 512;
+template <int NOUT, int RTW>
 // done (may be null): host-mapped words, one per workgroup; workgroup g stores `seq` into done[g] once its block lies in
 // `out` -- the host then polls these words instead of synchronising the stream (the runtime's completion path costs more
 // than the kernel's arithmetic at one source).
-__global__ __launch_bounds__(64 * kRtWaves) void rt_block_kernel(const FusedParams P, const RingTable rt,
-                                                                 const float *__restrict__ pos,
-                                                                 float2 *__restrict__ out, int *__restrict__ done, int seq) {
+__global__ __launch_bounds__(64 * RTW) void rt_block_kernel(const FusedParams P, const RingTable rt,
+                                                            const float *__restrict__ pos,
+                                                            float2 *__restrict__ out, int *__restrict__ done, int seq) {
+    constexpr int kRtWaves = RTW;
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[kRtWaves * kWaveLds];
     __shared__ ItemDesc s_desc[kRtWaves];
@@ -2282,18 +2287,26 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
     return hipGetLastError();
 }
 
+int rt_waves_per_wg(int n_sources) { return n_sources <= kRtFewMaxSources ? kRtWavesFew : kRtWavesMany; }
+
+// n_wgs workgroups of rt_waves_per_wg(P.S) waves
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
                            int n_wgs, hipStream_t st) {
     if (P.K != 1 || n_wgs < 1) return hipErrorInvalidValue;
-    const dim3 grid(n_wgs), block(64 * kRtWaves);
+    const bool few = rt_waves_per_wg(P.S) == kRtWavesFew;
+    const dim3 grid(n_wgs), block(64 * (few ? kRtWavesFew : kRtWavesMany));
     float2 *o = reinterpret_cast<float2 *>(out);
+#define JF_RT_LAUNCH(NOUT)                                                                                             \
+    if (few) hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesFew>), grid, block, 0, st, P, rt, pos, o, done, seq);  \
+    else hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesMany>), grid, block, 0, st, P, rt, pos, o, done, seq)
     switch (P.B / 64) {
-    case 1: hipLaunchKernelGGL(rt_block_kernel<1>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
-    case 2: hipLaunchKernelGGL(rt_block_kernel<2>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
-    case 3: hipLaunchKernelGGL(rt_block_kernel<3>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
-    case 4: hipLaunchKernelGGL(rt_block_kernel<4>, grid, block, 0, st, P, rt, pos, o, done, seq); break;
+    case 1: JF_RT_LAUNCH(1); break;
+    case 2: JF_RT_LAUNCH(2); break;
+    case 3: JF_RT_LAUNCH(3); break;
+    case 4: JF_RT_LAUNCH(4); break;
     default: return hipErrorInvalidValue;
     }
+#undef JF_RT_LAUNCH
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from jf_load import jf
 hrir = np.load(os.path.join(ROOT, "tests/golden/kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
 sig = (np.load(os.path.join(ROOT, "tests/golden/castanets_441_excerpt_i24.npy")) / 8388608.0).astype(np.float32)
-for S in (1, 8, 64, 256):
+for S in [int(x) for x in os.environ.get("JF_LAT_SOURCES", "1,8,64,256").split(",")]:
     e = jf.Engine(256, 512, S, hrir=hrir)
     for s in range(S):
         e.set_signal(s, sig)

@@ -10,7 +10,7 @@ rng = np.random.default_rng(99)
 ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)
 ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
 S, B = int(os.environ.get("JF_RV_SOURCES", "256")), 128
-for uniform in (False, True):
+for uniform in ((False,) if os.environ.get("JF_RV_ONLY_NONUNIFORM") else (False, True)):
     e = jf.Engine(B, 512, S, hrir=hrir)
     e.set_reverb_partitioning(1 if uniform else 0)
     for s in range(S):
