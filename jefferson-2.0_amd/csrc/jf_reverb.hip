@@ -52,6 +52,31 @@ typedef c2 rv_v2;
 #endif
 }
 
+// The big partitions' products (reverb_big_mac_kernel): the four FMAs of a complex product as two v_pk_fma_f32 with op_sel
+// broadcasts -- the same operations per product and component in the same order, so the sums are the same bit for bit as
+// with four v_fma_f32 (-DJF_RV_BIG_SCALAR_MAC=1).  Round 4, config 5's batch shape, rocprofv3, 320 launches each, twice:
+//   four v_fma_f32, loads scheduled by the compiler           77.4 us   (98 registers)
+//   two v_pk_fma_f32, loads left where the compiler puts them 120.2 us  (it does not move loads across the asm statements:
+//                                                                        every step waited for its own loads)
+//   two v_pk_fma_f32, loads JF_RV_BIG_PREFETCH steps ahead    72.6 / 71.3 / 78.1 us for 2 / 4 / 8 steps (86 registers at 4)
+// What is left is the stream itself: 247 MB of delay line and 67 MB of products per launch at 4.7 TB/s.
+#ifndef JF_RV_BIG_SCALAR_MAC
+#define JF_RV_BIG_SCALAR_MAC 0
+#endif
+#ifndef JF_RV_BIG_PREFETCH
+#define JF_RV_BIG_PREFETCH 4
+#endif
+[[maybe_unused]] JF_DEV c2 pfma_re(c2 x, c2 h, c2 acc) {  // acc + (x.re h.re, x.re h.im)
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(h), "v"(acc));
+    return r;
+}
+[[maybe_unused]] JF_DEV c2 pfma_im_rot(c2 x, c2 h, c2 acc) {  // acc + (-x.im h.im, x.im h.re)
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(h), "v"(acc));
+    return r;
+}
+
 // Wave-private LDS hand-off (see jf_kernels.hip)
 #define JF_RV_SYNC()                                            \
     do {                                                        \
@@ -802,6 +827,7 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
 #pragma unroll
     for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_at(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
     int xslot = slot_of(0);
+#if JF_RV_BIG_SCALAR_MAC
     auto step = [&](int j) {  // j = q mod KB, a constant after unrolling
         const rv_v2 h = load_at(hp);
         xr[(KB - j) % KB] = load_at(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
@@ -820,6 +846,36 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
             acc[i].y = __builtin_fmaf(x.y, h.x, acc[i].y);
         }
     };
+#else
+    // The compiler does not move loads across the asm statements, so the loop fetches D steps ahead itself, in this order
+    // (sched_barrier: nothing crosses)
+    // (past the last group the H pointer stays on the last partition; the X slots just walk on round the ring)
+    constexpr int D = JF_RV_BIG_PREFETCH < KB ? JF_RV_BIG_PREFETCH : KB;
+    static_assert(KB % D == 0, "the queue index of a step is a constant after unrolling");
+    rv_v2 hq[D], xq[D];
+    const int n_steps = (P.n_part + KB - 1) / KB * KB;
+    int q_pf = 0;
+    auto fetch = [&](int d) {
+        hq[d] = load_at(hp);
+        xq[d] = load_at(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
+        xslot = xslot == 0 ? P.R1 - 1 : xslot - 1;
+        if (++q_pf < n_steps) hp += (size_t)B1 * 8;
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d);
+    auto step = [&](int j) {  // j = q mod KB, a constant after unrolling
+        const rv_v2 h = hq[j % D];
+        xr[(KB - j) % KB] = xq[j % D];
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(j % D);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KB; i++) acc[i] = pfma_re(xr[(i + KB - j) % KB], h, acc[i]);
+#pragma unroll
+        for (int i = 0; i < KB; i++) acc[i] = pfma_im_rot(xr[(i + KB - j) % KB], h, acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#endif
     // whole groups of KB partitions, straight-line (loads of later steps may move above earlier multiply-accumulates): the
     // partitions behind the response's last one are zeros (hspec1), the delay-line slots they meet hold older spectra
     for (int q0 = 0; q0 < P.n_part; q0 += KB) {
