@@ -316,17 +316,28 @@ int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, 
 
 /* Partitioning of the convolution reverb, in effect from the next jf_reverb_set_ir: 0 = by the response's length (default:
  * non-uniform from 48 partitions of frames_per_buffer on, unless jf_debug_set_reverb_form pins a uniform form), 1 = uniform
- * (one partition per block: P multiply-accumulates per bin and block), 2 = non-uniform (a head of 16 partitions of one
- * block + partitions of 16 blocks for the rest: P / 16 + 16; Gardner's zero-latency scheme with two sizes).  The reference's
+ * (one partition per block: P multiply-accumulates per bin and block), 2 = non-uniform (a head of 32 partitions of one
+ * block + partitions of 16 blocks for the rest: P / 16 + 30; Gardner's zero-latency scheme with two sizes, the large size
+ * starting two of its partitions into the response, so that its work for a big block can be done a whole big block early).  The reference's
  * own form is one product over the whole signal (cudaPart.cu:87-153).  Same results to float32 rounding. */
 int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
+/* One-block calls with the non-uniformly partitioned reverb (the real-time shape) run the big partitions' kernels on a second
+ * stream, off the block's critical path: when a block completes a big block, the spectrum of that big block, the products of
+ * the big block after the next and their inverse transform are launched there behind the block's spatialiser, sixteen blocks
+ * before their result is first read (jf_engine.cpp: run_reverb_stage).
+ * on = 0: everything in line on the engine's stream, as batch calls, calls with a pinned form and profiled calls do anyway
+ * (the last block of a big block then costs ~9 us more than the others at configs[4], the first ~40 us).  Default 1.  Same
+ * kernels, same order of every sum: bit-identical results. */
+int jf_debug_set_reverb_async(jf_engine *e, int on);
 /* The schedule of the non-uniformly partitioned reverb for a call of K blocks that starts at absolute block j0, with big blocks
  * of M blocks and TAIL formed up to big block fut_m (host logic only: no engine, no GPU; tests/test_reverb_plan.py replays
  * runs of calls against a model of the rings).  out = {m_lo, n_tr, ma, n_mid, n_ranges, kb0, kn0, kb1, kn1, copy_lo, copy_hi,
  * skip_lo, skip_hi, tail_early (-1: none), tail_late (-1: none), new fut_m} -- jf_host.h: ReverbSchedule. */
 int jf_debug_reverb_schedule(long long j0, int K, int M, long long fut_m, long long out[16]);
 /* Returns the number of partitions of frames_per_buffer the impulse response has (0: stage off); *head = partitions of that
- * size in use, *big = partitions of *big_taps taps behind them (0, 0: uniform partitioning). */
+ * size in use (the head: two big partitions' worth), *big = partitions of *big_taps taps behind them (0, 0: uniform
+ * partitioning) -- the decomposition blocks take that go through head + TAIL; whole big blocks inside a batch call are formed
+ * from *big + 2 partitions of *big_taps alone. */
 int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps);
 /* Which batch calls use the pre-interpolated rows (JF_FLAG_NO_INTERP_TABLE above): 0 = none, 1 = all, 2 = decided per run
  * (the default when the rows were built): a run of an uploaded trajectory takes them unless more than 30 % of its items

@@ -97,6 +97,7 @@ _SIGS = {
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_set_reverb_async": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
     "jf_debug_reverb_schedule": (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_longlong)]),
     "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
@@ -384,6 +385,10 @@ class Engine:
     def set_reverb_partitioning(self, how):
         """0 by length, 1 uniform, 2 non-uniform; in effect from the next set_reverb"""
         self._chk(lib().jf_debug_set_reverb_partitioning(self.h, int(how)))
+
+    def set_reverb_async(self, on):
+        """one-block calls: the big partitions' kernels on a second stream (default) or in line"""
+        self._chk(lib().jf_debug_set_reverb_async(self.h, int(bool(on))))
 
     def reverb_partitions(self):
         """(partitions of B the response has, head partitions in use, big partitions, taps per big partition)"""

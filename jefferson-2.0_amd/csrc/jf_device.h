@@ -223,6 +223,7 @@ struct ReverbBigParams {
     int h_first = 0, n_part = 0;
     int to_wet = 0;             // 0: Y_i -> fut ring block (fut_first + i) mod Fn;  1: -> the wet ring, blocks wet_k0 + M i .. + M - 1 of the call
     int fut_first = 0, wet_k0 = 0;
+    int mac_wgs = 0;  // single products: at most this many workgroups, taking the items in turn (0: one per item)
 };
 
 // What the reverb stage does in one call (host side; launch_reverb)

@@ -40,6 +40,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
+hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st);
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
                                 float2 *d_hspec1, hipStream_t st);
 int kernels_build_kind();
@@ -166,11 +167,24 @@ struct jf_engine {
     int rv_M = 0;                // blocks per big block (rv_big_blocks(B)): rv_B1 = rv_M * B
     int rv_P1 = 0, rv_B1 = 0, rv_R1 = 0, rv_Rn = 0, rv_Fn = 0, rv_steps_max = 0;
     long long rv_blocks = 0;     // blocks the stage has processed since it was set up: big block m = blocks 16 m .. 16 m + 15
-    long long rv_fut_m = 0;      // TAIL(m) has been formed for every big block up to this one (big block 0 has none: zeros)
+    long long rv_fut_m = 1;      // TAIL(m) has been formed for every big block up to this one (big blocks 0 and 1 have none: zeros)
     ReverbPlan last_plan;        // what the last call did (jf_debug_last_kernels)
     float2 *d_rv_tw1 = nullptr, *d_rv_hspec1 = nullptr, *d_rv_fdl1 = nullptr, *d_rv_ybig = nullptr;
     float *d_rv_dryring = nullptr, *d_rv_fut = nullptr;
     SrcSignal *d_sigs_wet = nullptr;  // [S] the wet rings as the spatialiser's signals
+    // One-block calls (the real-time shape) keep the big partitions off the block's critical path (run_reverb_stage): their
+    // kernels go to a second stream, d_rv_yacc is that stream's product buffer.
+    int rv_async = 1;            // jf_debug_set_reverb_async
+    hipStream_t rv_side = nullptr;
+    hipEvent_t rv_ev_main = nullptr, rv_ev_side = nullptr;
+    bool rv_side_busy = false;   // work was put on the side stream since the engine's stream last waited for it
+    bool rv_side_urgent = false; // ... some of which the very next block reads
+    float2 *d_rv_yacc = nullptr; // [S][2][B1]
+    std::string last_side;       // the side stream's kernels of the last call (jf_debug_last_kernels)
+    // what the last stage wants run on the side stream once the block's spatialiser has been launched (submit_side)
+    bool side_tr = false;
+    ReverbBigParams side_p[2];   // transforms, products
+    int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow)
 };
 
 namespace {
@@ -262,6 +276,24 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
     R.mac_form = e->rv_form;
     ReverbPlan plan;
     plan.big = e->rv_P1 > 0;
+    // One-block calls -- the real-time shape -- keep the big partitions' kernels off the block's critical path.  The head
+    // covers TWO big blocks of taps (2 M partitions of B), so TAIL(m) = sum_{q >= 2} X_{m+1-q} H'_q needs nothing newer than
+    // X_{m-1}, which exists a whole big block before big block m begins.  When a one-block call completes big block mb, the
+    // transform X_{mb+1}, the products of TAIL(mb + 2) and their inverse transform go to a second stream BEHIND the block's
+    // spatialiser (submit_side); the first block to read the result is seventeen blocks away, and the stage of the next call
+    // that is not such a one-block call -- or the next one that puts work there -- makes the engine's stream wait for that
+    // stream (an event).  (With a head of M partitions TAIL(mb + 1) needed X_{mb+1} and was needed by the very next block: in
+    // line, that block and the one before it cost 40 and 9 us more than the other fourteen at configs[4], 256 sources.)
+    // Calls that pin a form, batch calls and profiled calls do everything in line on the engine's stream.
+    const bool async_ok = plan.big && K == 1 && e->rv_async && e->rv_form == 0 && e->profiling < 2 && e->rv_side != nullptr;
+    const bool completes = plan.big && (e->rv_blocks + K) / e->rv_M > e->rv_blocks / e->rv_M;  // transforms in this call
+    if (e->rv_side_busy && (!async_ok || completes || e->rv_side_urgent)) {
+        JF_HIP(e, hipStreamWaitEvent(e->stream, e->rv_ev_side, 0));
+        e->rv_side_busy = e->rv_side_urgent = false;
+    }
+    ReverbBigParams &s_tr = e->side_p[0], &s_prod = e->side_p[1];
+    e->side_tr = false;
+    e->last_side.clear();
     if (plan.big) {
         // Absolute block indices j0 .. j1 - 1; big block m = blocks 16 m .. 16 m + 15.
         const long long j0 = e->rv_blocks;
@@ -318,12 +350,12 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         R.copy_hi = sc.copy_hi;
         R.skip_lo = sc.skip_lo;
         R.skip_hi = sc.skip_hi;
-        auto tail_for = [&](long long m) {
+        auto tail_for = [&](long long m) {  // TAIL(m) = sum_{q = 2 .. P1} X_{m+1-q} H'_q: the newest spectrum is X_{m-1}
             ReverbBigParams T = G;
             T.n_prod = 1;
-            T.anchor_slot_first = mod(m, R1);
-            T.h_first = 1;
-            T.n_part = e->rv_P1;
+            T.anchor_slot_first = mod(m - 1, R1);
+            T.h_first = 2;
+            T.n_part = e->rv_P1 - 1;
             T.to_wet = 0;
             T.fut_first = mod(m, Fn);
             return T;
@@ -332,14 +364,54 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         plan.tail_late = G;
         if (sc.tail_early >= 0) plan.tail_early = tail_for(sc.tail_early);
         if (sc.tail_late >= 0) plan.tail_late = tail_for(sc.tail_late);
+        if (async_ok && sc.n_tr > 0) {
+            // the block completes big block mb: X_{mb+1} and, with it, TAIL(mb + 2) -- which the block after the next
+            // sixteen is the first to read
+            const long long mb = j0 / M;
+            const std::string b1 = std::to_string(B1);
+            s_tr = plan.transforms;
+            plan.transforms.n_tr = 0;
+            // all 2 B1 samples from the dry ring -- the head kernel has just written this block's there -- and none from the
+            // signal at the play position, which the next call moves on while the side stream may still be reading
+            s_tr.dry_pos0 = (R.dry_pos0 + e->B) % R.Rd;
+            s_tr.tr_rel_first -= e->B;
+            // (if nobody has formed TAIL(mb + 1) -- the run of one-block calls began inside this big block -- both, and the
+            // next call waits for them)
+            const bool both = e->rv_fut_m < mb + 1;
+            s_prod = tail_for(both ? mb + 1 : mb + 2);
+            s_prod.n_prod = both ? 2 : 1;
+            s_prod.ybig = e->d_rv_yacc;
+            s_prod.mac_wgs = both ? 0 : e->rv_side_wgs;
+            e->rv_side_urgent = both;
+            if (e->rv_fut_m < mb + 2) e->rv_fut_m = mb + 2;
+            e->side_tr = true;
+            e->last_side = "reverb_big_fft_kernel<" + b1 + ",1>@side;reverb_big_mac_kernel<" + b1 + ",1>@side;reverb_big_ifft_kernel<" +
+                           b1 + ",1>@side;";
+        }
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
     JF_HIP(e, launch_reverb(R, &plan, e->stream, &e->last_rv_form));
     e->last_plan = plan;
+
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
     e->rv_blocks += K;
+    return JF_OK;
+}
+
+// What run_reverb_stage left for the side stream, submitted once the block's own kernels (the spatialiser's too) are in the
+// engine's stream: the side stream waits for them -- it then works beside what FOLLOWS the block (in real time: nothing; in a
+// run of calls back to back: the next blocks, which find room because its long kernel is launched narrow) -- and the block's
+// own kernels are not held up by it.
+static int submit_side(jf_engine *e) {
+    if (!e->side_tr) return JF_OK;
+    JF_HIP(e, hipEventRecord(e->rv_ev_main, e->stream));
+    JF_HIP(e, hipStreamWaitEvent(e->rv_side, e->rv_ev_main, 0));
+    JF_HIP(e, launch_reverb_big_side(&e->side_p[0], &e->side_p[1], e->rv_side));
+    JF_HIP(e, hipEventRecord(e->rv_ev_side, e->rv_side));
+    e->rv_side_busy = true;
+    e->side_tr = false;
     return JF_OK;
 }
 
@@ -452,7 +524,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     if (timed) e->ev_used++;
     e->cur = p ^ 1;
     e->last_rt = false;
-    return JF_OK;
+    return submit_side(e);
 }
 
 void snapshot_positions(jf_engine *e, float *dst /* [S][5] */) {
@@ -468,7 +540,17 @@ void snapshot_positions(jf_engine *e, float *dst /* [S][5] */) {
     }
 }
 
+// The side stream has nothing in flight any more (host-side wait); what it had promised is forgotten.
+void quiesce_side(jf_engine *e) {
+    if (e->rv_side && e->rv_side_busy) (void)hipStreamSynchronize(e->rv_side);
+    e->rv_side_busy = e->rv_side_urgent = false;
+}
+
 void free_reverb(jf_engine *e) {
+    quiesce_side(e);
+    e->last_side.clear();
+    (void)hipFree(e->d_rv_yacc);
+    e->d_rv_yacc = nullptr;
     (void)hipFree(e->d_rv_hspec);
     (void)hipFree(e->d_rv_fdl);
     (void)hipFree(e->d_rv_wet);
@@ -502,6 +584,7 @@ int reset_sources(jf_engine *e, int src) {
     e->ahead.valid = false;  // the old position of the next block changes
     const size_t s0 = src < 0 ? 0 : (size_t)src, ns = src < 0 ? (size_t)e->S : 1;
     const int p = e->cur;
+    quiesce_side(e);  // (what it has left in the fut ring is zeroed below with the rest)
     JF_HIP(e, hipMemset(e->d_hist[p] + s0 * kN, 0, sizeof(float) * kN * ns));
     JF_HIP(e, hipMemset(e->d_state[p] + s0, 0, sizeof(SrcState) * ns));
     if (e->rv_P > 0) {
@@ -525,6 +608,7 @@ int reset_sources(jf_engine *e, int src) {
 void destroy_engine(jf_engine *e) {
     if (!e) return;
     DeviceGuard bind(e);
+    if (e->rv_side) (void)hipStreamSynchronize(e->rv_side);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_reverb(e);
     for (float *p : e->d_signal)
@@ -555,6 +639,9 @@ void destroy_engine(jf_engine *e) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
+    if (e->rv_ev_main) (void)hipEventDestroy(e->rv_ev_main);
+    if (e->rv_ev_side) (void)hipEventDestroy(e->rv_ev_side);
+    if (e->rv_side) (void)hipStreamDestroy(e->rv_side);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -598,7 +685,17 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
     (void)hipGetDevice(&prev_dev);
     auto body = [&]() -> int {
         JF_HIP(e, hipSetDevice(cfg->device));
-        JF_HIP(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        {
+            // the engine's stream at the highest priority the device offers, the side stream (the reverb's work ahead of time,
+            // run_reverb_stage) at the lowest: where the two meet, the block in hand goes first
+            int lo = 0, hi = 0;
+            JF_HIP(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            JF_HIP(e, hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi));
+            JF_HIP(e, hipStreamCreateWithPriority(&e->rv_side, hipStreamNonBlocking, lo));
+            if (const char *w = getenv("JF_RV_SIDE_WGS")) e->rv_side_wgs = atoi(w);  // tuning runs
+        }
+        JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_main, hipEventDisableTiming));
+        JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_side, hipEventDisableTiming));
         for (int kind = 0; kind < 2; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
         {
             const char *env = getenv("JF_INTERP_TABLE");
@@ -764,6 +861,7 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     DeviceGuard bind(e);
     if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
     JF_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->rv_side && e->rv_side_busy) JF_HIP(e, hipStreamSynchronize(e->rv_side));  // its transforms read the signals
     // The device copy always has length >= PAD_LEN so that the kernel wraps the loop with
     // one conditional subtract: a shorter signal is stored as whole repetitions of itself
     // (the looped stream is identical), an empty one as the shared zero buffer.
@@ -935,6 +1033,10 @@ int jf_submit_block(jf_engine *e) {
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
             e->rt_seq = e->rt_seq == 0x7fffffff ? 1 : e->rt_seq + 1;
             JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, e->hd_done, e->rt_seq, wgs, e->stream));
+            {
+                const int rc = submit_side(e);
+                if (rc) return rc;
+            }
             e->cur = p ^ 1;
             e->last_rt = true;
             e->rt_wgs = wgs;
@@ -1075,7 +1177,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const bool nonuniform = e->rv_partitioning == 2 ||
                             (e->rv_partitioning == 0 && e->rv_form == 0 && P_total >= 3 * rv_big_blocks(B));
     const int M = rv_big_blocks(B);
-    const int P = nonuniform ? M : P_total;
+    const int P = nonuniform ? 2 * M : P_total;  // the head: two big partitions' worth of taps (run_reverb_stage says why)
     const int B1 = M * B;
     const int P1 = nonuniform ? (int)((n_ir > (size_t)B1 ? n_ir - B1 : 0) + B1 - 1) / B1 : 0;
     const int steps_max = e->maxK / M + 1;               // big blocks one call can complete
@@ -1118,6 +1220,7 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
             JF_HIP(e, hipMalloc(&e->d_rv_ybig, sizeof(float2) * S * steps_max * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_dryring, sizeof(float) * S * Rn * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_fut, sizeof(float) * S * Fn * B1));
+            JF_HIP(e, hipMalloc(&e->d_rv_yacc, sizeof(float2) * S * 2 * B1));
             // 1/B1: normalisation of the B1-point inverse used for the 2 B1-point real transform
             // H'_0 .. H'_P1: the response from its first tap on in partitions of B1 (ReverbBigParams)
             JF_HIP(e, launch_reverb_big_ir(d_ir, (int)n_ir, 0, P1 + 1, B1, gain / (float)B1, e->d_rv_tw1, e->d_rv_hspec1, e->stream));
@@ -1144,7 +1247,8 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     e->rv_Rn = Rn;
     e->rv_Fn = Fn;
     e->rv_steps_max = steps_max;
-    e->rv_blocks = e->rv_fut_m = 0;
+    e->rv_blocks = 0;
+    e->rv_fut_m = 1;  // TAIL(0) and TAIL(1) are sums over spectra of the time before the start: the zeros of the reset
     return reset_sources(e, -1);
     });
 }
@@ -1239,6 +1343,7 @@ int jf_synchronize(jf_engine *e) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
+    if (e->rv_side && e->rv_side_busy) JF_HIP(e, hipStreamSynchronize(e->rv_side));
     JF_HIP(e, hipStreamSynchronize(e->stream));
     if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
     return JF_OK;
@@ -1409,6 +1514,14 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
     });
 }
 
+int jf_debug_set_reverb_async(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    e->rv_async = on != 0;  // what the side stream has in flight is waited for by the next call's stage (run_reverb_stage)
+    return JF_OK;
+    });
+}
+
 int jf_debug_reverb_schedule(long long j0, int K, int M, long long fut_m, long long out[16]) {
     if (!out || K <= 0 || M <= 0 || j0 < 0) return JF_ERR_ARG;
     const ReverbSchedule s = host_reverb_schedule(j0, K, M, fut_m);
@@ -1421,7 +1534,7 @@ int jf_debug_reverb_schedule(long long j0, int K, int M, long long fut_m, long l
 int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big_taps) {
     if (!e) return JF_ERR_ARG;
     if (head) *head = e->rv_P;
-    if (big) *big = e->rv_P1;
+    if (big) *big = e->rv_P1 > 0 ? e->rv_P1 - 1 : 0;  // H'_2 .. H'_P1 (H'_0 and H'_1 are the head's taps; FULL uses all)
     if (big_taps) *big_taps = e->rv_B1;
     return e->rv_P_total;
 }
@@ -1553,6 +1666,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
                 }
             }
         }
+        if (e->rv_P > 0) k += e->last_side;
         // launch_mix: few partial blocks per audio block (16, 32 or 64 groups) take the one-thread-per-float form
         const int n_part = e->last_group > 0 ? e->S / e->last_group : e->S;
         const std::string mix_name = (n_part == 16 || n_part == 32 || n_part == 64)

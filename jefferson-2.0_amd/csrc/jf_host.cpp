@@ -393,12 +393,16 @@ ReverbSchedule host_reverb_schedule(long long j0, int K, int M, long long fut_m)
         s.kn[0] = (int)(s.ma * M - j0);
         s.kb[1] = (int)(m_hi * M - j0);
         s.kn[1] = K - s.kb[1];
-        // of the middle's blocks only the last M - 1 are transformed (the state the next blocks read) ...
+        // of the middle's blocks only the last 2 M - 1 are transformed (the state the next blocks read: the head has 2 M
+        // partitions) ...
         s.copy_lo = s.kn[0];
-        s.copy_hi = s.kb[1] - (M - 1);
+        s.copy_hi = s.kb[1] - (2 * M - 1);
+        if (s.copy_hi < s.copy_lo) s.copy_hi = s.copy_lo;
         // ... and only the last whole big block is copied to the dry ring (later calls' transforms reach back two big blocks)
+        // (with the head's 2 M - 1 blocks transformed, which writes them to the dry ring as well, that is all of them)
         s.skip_lo = s.copy_lo;
         s.skip_hi = s.copy_lo > s.kb[1] - M ? s.copy_lo : s.kb[1] - M;
+        if (s.skip_hi > s.copy_hi) s.skip_hi = s.copy_hi;
     } else {
         s.n_ranges = 1;
         s.kb[0] = 0;
@@ -407,7 +411,7 @@ ReverbSchedule host_reverb_schedule(long long j0, int K, int M, long long fut_m)
     s.tail_early = s.tail_late = -1;
     s.fut_m = fut_m;
     // TAIL of the big block the call starts in, if one of its blocks goes through the uniform stage and nobody has formed it
-    // yet (its X_m are all there: the block before it has been taken in)
+    // yet (its X_m are all there -- a whole big block ago, since the head covers two big blocks of taps)
     const long long mb = j0 / M;
     if (s.kn[0] > 0 && s.fut_m < mb) {
         s.tail_early = mb;

@@ -800,12 +800,12 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
 // reverb_big_ifft_kernel recomputes it.
 constexpr int kBigMacWaves = 8;
 template <int B1, int KB>
-__global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const ReverbBigParams P) {
+JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
     constexpr int WGS_PER_SPEC = B1 / (64 * kBigMacWaves);  // workgroups side by side over the bins
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slice = blockIdx.x % WGS_PER_SPEC;
-    const int rest = blockIdx.x / WGS_PER_SPEC;
+    const int slice = item % WGS_PER_SPEC;
+    const int rest = item / WGS_PER_SPEC;
     const int n_tiles = (P.n_prod + KB - 1) / KB;
     const int s = rest / n_tiles, i0 = (rest - s * n_tiles) * KB;  // first product of the tile
     const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
@@ -886,6 +886,21 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
 #pragma unroll
     for (int i = 0; i < KB; i++)
         if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
+}
+
+// One workgroup per item (64 kBigMacWaves bins of one tile of one source) -- or, for single products on the side stream
+// (mac_wgs > 0), that many workgroups taking the items in turn: a launch that does not fill the GPU's wave slots, so that the
+// kernels of the blocks it runs beside find room at once (jf_engine.cpp: run_reverb_stage).
+template <int B1, int KB>
+__global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const ReverbBigParams P) {
+    if constexpr (KB == 1) {
+        constexpr int per_spec = B1 / (64 * kBigMacWaves);
+        const int n_items = per_spec * P.n_prod * P.S;
+#pragma unroll 1
+        for (int item = blockIdx.x; item < n_items; item += gridDim.x) big_mac_item<B1, KB>(P, item);
+    } else {
+        big_mac_item<B1, KB>(P, blockIdx.x);
+    }
 }
 
 // Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.  NTR products
@@ -1142,7 +1157,9 @@ static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
         const int tiles = (P.n_prod + 15) / 16;
         hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec * tiles * P.S), dim3(64 * kBigMacWaves), 0, st, P);
     } else {
-        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(per_spec * P.n_prod * P.S), dim3(64 * kBigMacWaves), 0, st, P);
+        const int n_items = per_spec * P.n_prod * P.S;
+        const int wgs = P.mac_wgs > 0 && P.mac_wgs < n_items ? P.mac_wgs : n_items;
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(wgs), dim3(64 * kBigMacWaves), 0, st, P);
     }
     const int n = P.n_prod * P.S;
     if (n >= 1024) hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 2>), dim3((n + 1) / 2), dim3(kBigThreads), 0, st, P);
@@ -1161,6 +1178,14 @@ static void launch_big_products(const ReverbBigParams &P, hipStream_t st) {
     case 2048: launch_big_products_t<2048>(P, st); break;
     default: break;
     }
+}
+
+// The big partitions' work of one-block calls on the engine's side stream (jf_engine.cpp: run_reverb_stage): X_m of the big
+// block just completed, then the products of a TAIL with their inverse transform.
+hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st) {
+    if (transforms && transforms->n_tr > 0) launch_big_transforms(*transforms, st);
+    if (products && products->n_prod > 0) launch_big_products(*products, st);
+    return hipGetLastError();
 }
 
 // form_used: 1, 2, 3 = form of stage B (after reverb_fft_kernel), 4 = form 1 with stage A fused in (no reverb_fft_kernel),

@@ -225,7 +225,7 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     calls so that the delay line, the wet ring and the windows carry over.  form 3 pinned and part = 1: uniform partitions
     (690 multiply-accumulates per bin and block, the tiled kernel over all of them); part = 0, form 0: what the engine
     takes by itself for this response -- partitions of 2048 (44 of them for blocks inside a call of whole big blocks: these
-    calls; 16 of 128 + 43 of 2048 for blocks worked on their own).  Per-source blocks of sampled sources
+    calls; 32 of 128 + 42 of 2048 for blocks worked on their own).  Per-source blocks of sampled sources
     against the float32 C oracle with its reverb stage (jfo_reverb_set_ir) and against gain * float64 convolution ->
     float64 spatialiser model; the mix as the ordered sum of the blocks."""
     B = 128
@@ -241,7 +241,7 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
     for s in range(S):
         e.set_signal(s, sigs[s])
     e.set_reverb(ir, gain)
-    assert e.reverb_partitions() == ((690, 690, 0, 0) if (form or part == 1) else (690, 16, 43, 2048))
+    assert e.reverb_partitions() == ((690, 690, 0, 0) if (form or part == 1) else (690, 32, 42, 2048))
     e.upload_positions(pos)
     parts, mixes = [], []
     for c in range(2):               # two calls: the delay line and the wet ring carry over

@@ -185,7 +185,7 @@ def test_reverb_off_and_unsupported_block(jf, hrir, castanets):
 # ------------------------------------------------------------------------------- non-uniform partitioning --
 @pytest.mark.parametrize("B,n_big,ragged", [(128, 3, 0), (128, 7, 901), (64, 5, 17), (256, 3, 1000)])
 def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, castanets, B, n_big, ragged):
-    """A head of M = 16 (B = 256: 8) partitions of B + partitions of M B behind it (jf_debug_set_reverb_partitioning; the default for long
+    """A head of 2 M = 32 (B = 256: 16) partitions of B + partitions of M B behind it (jf_debug_set_reverb_partitioning; the default for long
     responses) against gain * float64 convolution -> float64 spatialiser model and against the engine with uniform
     partitions, over 70 blocks = four steps of the big partitions, as ONE run of calls of ragged sizes (1, 5, 16, 17, 31
     blocks: steps at the start, in the middle and at the end of a call, calls without any).  The response is n_big big
@@ -210,7 +210,7 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
                 e.set_signal(s_, sigs[s_])
             e.set_reverb(ir, gain)
             n, head, big, taps = e.reverb_partitions()
-            assert n == P and (head, big, taps) == ((M, -(-(n_ir - B1) // B1), B1) if part == 2 else (P, 0, 0))
+            assert n == P and (head, big, taps) == ((2 * M, -(-(n_ir - B1) // B1) - 1, B1) if part == 2 else (P, 0, 0))
             got, b0 = [], 0
             for k in sizes:
                 got.append(e.process_batch(pos[b0:b0 + k]))
@@ -236,7 +236,7 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
     their ends) with the head's form pinned for both: bit-identical -- every block is then head + TAIL(m), and TAIL's products
     are added in the same order whatever the launch.  A batch call of whole big blocks forms their wet signal from the big
     partitions alone (FULL(m): another decomposition): within the float64 tolerance, not bit-identical.  And the 2 s
-    response of configs[4] takes the non-uniform form by default: 16 + 43 partitions instead of 690."""
+    response of configs[4] takes the non-uniform form by default: 32 + 42 partitions instead of 690."""
     B, S, K = 128, 2, 80
     ir = _ir(16 * B * 6 + 333, decay=3.0)
     sigs = [castanets[:9000], castanets[10000:17000]]
@@ -265,13 +265,24 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
     assert not np.array_equal(a, b)
     e = jf.Engine(128, 512, 1, hrir=hrir)
     e.set_reverb(_ir(88200), 1.0)
-    assert e.reverb_partitions() == (690, 16, 43, 2048)
+    assert e.reverb_partitions() == (690, 32, 42, 2048)
     for _ in range(16):
         e.process_block()
-    ks = e.last_kernels()          # the 16th block completes a big block: its spectrum is formed behind the head
+    ks = e.last_kernels()          # the 16th block completes big block 0: X_1, TAIL(2) and its inverse on the side stream
+    assert ks[:4] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048,1>@side", "reverb_big_mac_kernel<2048,1>@side",
+                      "reverb_big_ifft_kernel<2048,1>@side"], ks
+    e.process_block()              # the 17th block is the first of big block 1: nothing but its head
+    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
+    e.set_reverb_async(False)      # from here on everything in line on the engine's stream
+    for _ in range(15):
+        e.process_block()
+    ks = e.last_kernels()          # the 32nd block completes big block 1: X_2 behind the head
     assert ks[:2] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048,1>"], ks
-    e.process_block()
-    ks = e.last_kernels()          # the 17th block is the first of big block 1: TAIL(1) in front of the head
+    e.process_block()              # TAIL(2) is there already (the side stream formed it a big block early)
+    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
+    for _ in range(16):
+        e.process_block()
+    ks = e.last_kernels()          # the 49th block is the first of big block 3: TAIL(3) in front of the head
     assert ks[:3] == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048,1>", "reverb_mac_kernel<128,1,true>"], ks
     e.process_block()
     assert not any(k.startswith("reverb_big") for k in e.last_kernels())
@@ -315,3 +326,75 @@ def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
         e.close()
     assert peak > 0.02
     assert worst <= 2 * (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, peak) * S
+
+
+def test_one_block_calls_with_the_big_partitions_on_the_side_stream(jf, hrir, castanets):
+    """One-block calls put the big partitions' kernels on a second stream (jf_engine.cpp: run_reverb_stage): when a block
+    completes a big block, its spectrum and the TAIL of the big block after the next, a whole big block early.  Against the
+    same calls with everything in line (jf_debug_set_reverb_async 0: the same kernels and sums, bit for bit) and against the
+    float64 model; then a run in which batch calls of ragged sizes, a reset, a new signal and a change of the switch itself
+    fall between the one-block calls -- at the first, the last and a middle block of a big block."""
+    B, S, K = 128, 3, 112
+    ir = _ir(16 * B * 6 + 333, decay=3.0)            # a head of 32 partitions and 5 big ones behind it
+    sigs = [castanets[:9000], castanets[10000:17000], castanets[20000:33000]]
+    pos = _positions(jf, S, K)
+    want = _model(hrir, B, S, K, ir, 0.5, sigs, pos)
+    tol = (2e-7 + 1e-7 * np.sqrt(-(-len(ir) // B))) * max(1.0, np.abs(want).max()) * S
+    assert np.abs(want).max() > 0.02
+
+    def engine(on):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=16)
+        e.set_reverb_partitioning(2)
+        e.set_reverb_async(on)
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+        e.set_reverb(ir, 0.5)
+        return e
+
+    def blocks(e, b0, n):
+        out = []
+        for b in range(b0, b0 + n):
+            for s_ in range(S):
+                e.set_spherical(s_, pos[b, s_, 0], pos[b, s_, 1], 0.5 + 0.4 * s_)
+            out.append(e.process_block())
+        return out
+
+    runs = {}
+    for on in (True, False):
+        e = engine(on)
+        runs[on] = np.array(blocks(e, 0, K))
+        side = [k for k in e.last_kernels() if k.endswith("@side")]
+        assert (len(side) == 3) == on, e.last_kernels()      # block 111 is the last of big block 6
+        e.close()
+    assert np.abs(runs[True] - want).max() <= tol
+    assert np.array_equal(runs[True], runs[False])
+
+    # one-block calls and batch calls interleaved; the switch flipped in mid-stream
+    e = engine(True)
+    got, b0 = [], 0
+    for kind, n in (("one", 16), ("batch", 7), ("one", 9), ("batch", 16), ("one", 1), ("batch", 15), ("one", 17),
+                    ("off", 0), ("one", 20), ("on", 0), ("one", 11)):
+        if kind == "one":
+            got += blocks(e, b0, n)
+        elif kind == "batch":
+            got += list(e.process_batch(pos[b0:b0 + n]))
+        else:
+            e.set_reverb_async(kind == "on")
+        b0 += n
+    e.close()
+    assert b0 == K
+    assert np.abs(np.array(got) - want).max() <= tol
+
+    # a reset and a new signal while the side stream holds promises for the next big block: as the in-line engine
+    outs = []
+    for on in (True, False):
+        e = engine(on)
+        o = blocks(e, 0, 16)             # block 15 puts X_1 and TAIL(2) on the side stream ...
+        o += blocks(e, 16, 3)
+        e.reset(1)                       # ... of which source 1's part must not survive this
+        e.set_signal(2, castanets[40000:47000])
+        o += blocks(e, 19, 45)
+        outs.append(np.array(o))
+        e.close()
+    assert np.abs(outs[0]).max() > 0.02
+    assert np.array_equal(outs[0], outs[1])
