@@ -226,6 +226,38 @@ def single_source_latency_us(jf, hrir):
                     "every block --, B = 256 (configs[1]); host call to host result"}
 
 
+def realtime_reverb_call_us(jf, hrir, S, B, ir, gain):
+    """configs[4] through the real-time ENTRY POINT: one block per jf_process_block call, host call to host result, calls back
+    to back -- the one-launch spatialiser behind the reverb stage's head kernel, the big partitions' work on the engine's
+    second stream.  (The timed region above goes through jf_batch_run with one block per call and HIP events round the
+    stage: a pipelined, profiled run, in which the engine keeps everything in line on one stream.)"""
+    e = jf.Engine(B, 512, S, hrir=hrir)
+    for s in range(S):
+        e.set_signal(s, np.random.default_rng(1234 + s).uniform(-0.5, 0.5, 44100).astype(np.float32))
+        e.set_spherical(s, -40 + (s * 7) % 121, (s * 37) % 360, 1.0)
+    e.set_reverb(ir, gain)
+    out = np.zeros(2 * B, np.float32)
+    fp, call, h = out.ctypes.data_as(jf._f), jf.lib().jf_process_block, e.h
+    t = []
+    for k in range(64 + 1600):
+        if k % 7 == 0:  # a fifth of the sources move now and then, as they would
+            for s in range(0, S, 5):
+                e.set_spherical(s, -40 + (s * 7) % 121, (s * 37 + k) % 360, 1.0)
+        t0 = time.perf_counter()
+        rc = call(h, fp)
+        t.append(time.perf_counter() - t0)
+        if rc != 0:
+            raise RuntimeError(f"jf_process_block returned {rc}")
+    side = any(k.endswith("@side") for k in e.last_kernels())  # call 1664 = the last block of a big block of 16
+    e.close()
+    t = np.array(t[64:]) * 1e6
+    return {"mean": float(t.mean()), "median": float(np.median(t)), "p99": float(np.percentile(t, 99)), "max": float(t.max()),
+            "calls": len(t), "by_place_in_the_cycle_of_16_blocks_median": [float(v) for v in np.median(t.reshape(-1, 16), axis=0)]
+            if B <= 128 else None, "big_partitions_on_the_side_stream": bool(side),
+            "what": f"jf_process_block, {S} sources, B = {B}, {len(ir)} taps of response, calls back to back, a fifth of the "
+                    "sources moves every 7th block; host call to host result"}
+
+
 def spawn_ranks(n, argv):
     """--gpus N without a launcher: start the N ranks as a child (this process has not touched the GPU)."""
     import socket
@@ -626,7 +658,9 @@ def main():
             t = reverb_ms / timed * 1e-3  # average time of the reverb stage's kernels over the steps that were timed
             n_tot, p_head, p_big, big_taps = eng.reverb_partitions()
             std = S == 256 and len(ir) == 88200
-            parts = (f"{p_head} partitions of {B} + {p_big} of {big_taps}" if p_big else f"{P} partitions of {B}")
+            parts = ((f"{p_head} partitions of {B} + {p_big} of {big_taps}" if args.realtime else
+                      f"{p_big + 2} partitions of {big_taps} for the whole big blocks of a call; {p_head} of {B} + {p_big} of {big_taps} "
+                      "for blocks worked on their own") if p_big else f"{P} partitions of {B}")
             out["config"]["workload"] = (("configs[4]: " if std else "configs[4] scaled: ")
                                          + f"{S} sources + {len(ir) / 44100.0:g} s convolution-reverb IR ({P} blocks long), "
                                            f"partitioned overlap-save ({parts}), {B}-sample blocks"
@@ -636,9 +670,9 @@ def main():
                   "avg_stage_ms": t * 1e3, "stage_timing": "HIP events around the stage's kernels on the engine's stream"}
             if p_big:
                 # Non-uniform partitioning (jf_device.h: ReverbBigParams).  Per big block (M blocks) and source: one
-                # transform of 2 B1 samples, P1 + 1 (FULL: blocks inside a batch call) or P1 (TAIL) spectra of the delay
-                # line against as many partition spectra, one inverse; blocks worked on their own add the head's M
-                # partitions of B.  The stage is bound by the delay-line stream (HBM): bytes below are ALGORITHMIC --
+                # transform of 2 B1 samples, p_big + 2 (FULL: blocks inside a batch call -- all the big partitions) or p_big
+                # (TAIL: those behind the head) spectra of the delay line against as many partition spectra, one inverse;
+                # blocks worked on their own add the head's 2 M partitions of B.  The stage is bound by the delay-line stream (HBM): bytes below are ALGORITHMIC --
                 # every spectrum a product needs counted once per tile of 16 products (the kernel keeps a sliding window).
                 M, B1 = big_taps // B, big_taps
                 if args.realtime:
@@ -649,12 +683,13 @@ def main():
                     flops = 8.0 * macs + S * (2 * 5 * B1 * np.log2(B1) / M + 2 * 5 * B * np.log2(B))
                     fdl_bytes = S * (p_big + 1) * B1 * 8
                 else:
+                    p_full = p_big + 2
                     nb_big = KB // M   # whole big blocks per call (KB is a multiple of M: the bench's calls are aligned)
-                    fdl_read = S * (p_big + 1 + min(nb_big, 16) - 1) * B1 * 8 * (-(-nb_big // 16))
-                    rb = fdl_read + (p_big + 1) * B1 * 8 + 3 * S * nb_big * B1 * 8 + 2 * S * KB * B * 4
-                    macs = S * nb_big * (p_big + 1) * B1
+                    fdl_read = S * (p_full + min(nb_big, 16) - 1) * B1 * 8 * (-(-nb_big // 16))
+                    rb = fdl_read + p_full * B1 * 8 + 3 * S * nb_big * B1 * 8 + 2 * S * KB * B * 4
+                    macs = S * nb_big * p_full * B1
                     flops = 8.0 * macs + 2 * S * nb_big * 5 * B1 * np.log2(B1)
-                    fdl_bytes = S * (p_big + 1 + nb_big) * B1 * 8
+                    fdl_bytes = S * (p_full + nb_big) * B1 * 8
                 gbs = rb / t / 1e9 if t > 0 else 0.0
                 rv.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                            "traffic": None, "algorithmic_bytes_per_step": rb, "delay_line_bytes_read_per_step": fdl_read,
@@ -708,6 +743,11 @@ def main():
                 out["single_source_block_latency_us"] = single_source_latency_us(jf, hrir)
             except Exception as ex:
                 out["single_source_block_latency_us"] = {"error": str(ex)}
+        if world == 1 and ir is not None and args.realtime:
+            try:
+                out["realtime_call_us"] = realtime_reverb_call_us(jf, hrir, S, B, ir, RV_GAIN)
+            except Exception as ex:
+                out["realtime_call_us"] = {"error": str(ex)}
         if not args.no_cpu_baseline:
             all_ids = np.arange(0, world * S)
             nb = max(KB + 4, min(args.cpu_sample_blocks, max(KB + 4, 262144 // len(all_ids))))
