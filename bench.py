@@ -348,6 +348,16 @@ def main():
                 dist.init_process_group(backend, rank=rank, world_size=world)
 
     from jf_load import jf
+    # The rank's host thread on the NUMA node its GPU hangs off (include/jefferson.h: jf_pin_thread_to_device; what
+    # `numactl --cpunodebind` does for a launcher that does not): launches, the poll of the per-block legs and the pinned
+    # buffers stay on one socket.  JF_NO_PIN=1 leaves the thread where the system put it; the line says which.
+    host_info = {"numa_node_of_gpu": None, "thread_pinned_to_it": False}
+    try:
+        host_info["numa_node_of_gpu"] = jf.device_numa_node(local_rank)
+        if not os.environ.get("JF_NO_PIN"):
+            host_info["thread_pinned_to_it"] = bool(jf.pin_thread_to_device(local_rank))
+    except jf.JfError:
+        pass
     wl = load_workload()
     gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
     hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
@@ -616,7 +626,7 @@ def main():
                                "region: the first ~100 steps after an idle GPU run 10-15 % slower (clock ramp), so `value` is "
                                "a warmed steady-state figure; prewarm_steps = max(0, 256 - warmup) of them are this script's own"),
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "host": host_info,
             "config": {"workload": "configs[2]: 1024 concurrent moving sources per GPU, 256-sample blocks, "
                                    "N=1024 overlap-save, KEMAR 710x2 table"
                                    + (" (stationary variant)" if args.stationary else "")

@@ -107,6 +107,21 @@ void jf_engine_destroy(jf_engine *e);
 /* Text of the last error on this engine (or of the last failed create when e == NULL). */
 const char *jf_last_error(const jf_engine *e);
 
+/*
+ * Where the audio thread should run.  The per-block calls are host call -> one or two launches -> blocks written to pinned
+ * host memory -> the host's poll: on a two-socket host every step of that crosses the sockets when the calling thread runs
+ * on the other one than the GPU hangs off.  Measured (MI355X on a 2 x EPYC 9575F host, profiles/r04/rt_numa.md): 15.8 against
+ * 16.9-17.8 us per block for one source, 22.6 against 25.8-27.8 us for 256.  The reference leaves its callback where PortAudio
+ * starts it (Audio.cu:94-175); a host that cares pins the thread that calls jf_process_block / jf_callback.
+ *   jf_device_numa_node: *node = NUMA node of HIP device `device` (from its PCI address, sysfs), -1 if the system does not
+ *     say; JF_ERR_DEVICE if there is no such device.
+ *   jf_pin_thread_to_device: restricts the CALLING thread to the CPUs of that node (sched_setaffinity; nothing else in the
+ *     library touches affinities).  JF_ERR_STATE if the node or its CPUs are not known, or none of them is allowed to this
+ *     process.  Call it before jf_engine_create, so that the engine's pinned buffers are first touched from there too.
+ */
+int jf_device_numa_node(int device, int *node);
+int jf_pin_thread_to_device(int device);
+
 int jf_frames_per_buffer(const jf_engine *e); /* FRAMES_PER_BUFFER */
 int jf_pad_len(const jf_engine *e);           /* PAD_LEN */
 int jf_num_sources(const jf_engine *e);       /* Data::num_sources (DataTag.cuh:14) */

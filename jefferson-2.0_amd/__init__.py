@@ -98,6 +98,8 @@ _SIGS = {
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_async": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_device_numa_node": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "jf_pin_thread_to_device": (C.c_int, [C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
     "jf_debug_reverb_schedule": (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_longlong)]),
     "jf_debug_last_run_used_rows": (C.c_int, [C.c_void_p]),
@@ -138,6 +140,20 @@ def _fp(a):
 def _ip(a):
     assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(_i)
+
+
+def device_numa_node(device=0):
+    """NUMA node of HIP device `device` (-1: the system does not say)."""
+    n = C.c_int(-1)
+    rc = lib().jf_device_numa_node(int(device), C.byref(n))
+    if rc:
+        raise JfError(rc, (lib().jf_last_error(None) or b"").decode())
+    return n.value
+
+
+def pin_thread_to_device(device=0):
+    """Restrict the calling thread to the CPUs of the device's NUMA node (include/jefferson.h); False if that is not possible."""
+    return lib().jf_pin_thread_to_device(int(device)) == 0
 
 
 def position_from_spherical(ele, azi, r):

@@ -2,7 +2,9 @@
 // One engine = one GPU (one process per GPU in multi-GPU runs).  No CPU
 // fallback: every processing entry point runs the HIP kernels or fails.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <math.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1336,6 +1338,67 @@ int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) 
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
     return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix,
                       first_block);
+    });
+}
+
+int jf_device_numa_node(int device, int *node) {
+    return jf_guard([&]() -> int {
+    if (!node) return JF_ERR_ARG;
+    *node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, JF_ERR_DEVICE, "no such HIP device");
+    }
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);  // sysfs spells the address in lower case
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE *f = fopen(path.c_str(), "r")) {
+        int n = -1;
+        if (fscanf(f, "%d", &n) == 1) *node = n;
+        fclose(f);
+    }
+    return JF_OK;
+    });
+}
+
+int jf_pin_thread_to_device(int device) {
+    return jf_guard([&]() -> int {
+    int node = -1;
+    const int rc = jf_device_numa_node(device, &node);
+    if (rc != JF_OK) return rc;
+    if (node < 0) return fail(nullptr, JF_ERR_STATE, "the system does not say which NUMA node the device is on");
+    // /sys/devices/system/node/node<N>/cpulist: "0-63,128-191"
+    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return fail(nullptr, JF_ERR_STATE, "no CPU list for the device's NUMA node");
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return fail(nullptr, JF_ERR_STATE, "no CPU list for the device's NUMA node");
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return fail(nullptr, JF_ERR_STATE, "sched_getaffinity failed");
+    int n_set = 0;
+    for (const char *p = line; *p;) {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, &want);
+                n_set++;
+            }
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+    }
+    if (n_set == 0) return fail(nullptr, JF_ERR_STATE, "none of the CPUs of the device's NUMA node is allowed to this process");
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return fail(nullptr, JF_ERR_STATE, "sched_setaffinity failed");
+    return JF_OK;
     });
 }
 

@@ -20,6 +20,8 @@
  *                  [--dwell 172] [--rounds 72] [--step 5] [--radius 0.5] [--latency] [--script debugmode2]
  *   --latency  use jf_callback (the CUDA path's one-block latency, Audio.cu:104-117)
  *              instead of jf_process_block (the CPU path's ordering)
+ *   --no-pin   leave the thread where the system put it (default: jf_pin_thread_to_device -- on a two-socket host a block
+ *              costs 1-5 us more from the socket the GPU does not hang off)
  *   --batch N  hand the engine N callbacks at a time (jf_process_batch: the same blocks, the positions the
  *              audio thread would have latched given up front) -- what an offline render should use: a
  *              single source cannot fill a GPU one block at a time
@@ -74,13 +76,14 @@ static double now_s(void) {
 int main(int argc, char **argv) {
     if (argc < 4) {
         fprintf(stderr, "usage: %s <hrir_dir> <in.wav> <out.wav> [--block B] [--azi A] [--ele E] "
-                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N] [--script debugmode2]\n", argv[0]);
+                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N] [--script debugmode2] [--no-pin]\n", argv[0]);
         return 2;
     }
-    int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0, script = 0;
+    int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0, script = 0, pin = 1;
     float azi = 3, ele = 5, step = 5, radius = 0.5f;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--latency")) latency = 1;
+        else if (!strcmp(argv[i], "--no-pin")) pin = 0;
         else if (i + 1 < argc && !strcmp(argv[i], "--block")) block = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--batch")) batch = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--azi")) azi = (float)atof(argv[++i]);
@@ -103,6 +106,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "input: %s\n", jf_last_error(NULL));
         return 1;
     }
+    if (pin && jf_pin_thread_to_device(0) != JF_OK) fprintf(stderr, "not pinned: %s\n", jf_last_error(NULL));
     jf_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.frames_per_buffer = block;

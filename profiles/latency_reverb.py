@@ -5,6 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jf_load import jf
+if not os.environ.get("JF_NO_PIN"):
+    jf.pin_thread_to_device(0)   # the audio thread on the GPU's NUMA node (include/jefferson.h; profiles/r04/rt_numa.md)
 hrir = np.load(os.path.join(ROOT, "tests/golden/kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
 rng = np.random.default_rng(99)
 ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)

@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jf_load import jf
 if os.environ.get("JF_LIB", "").endswith("_prev.so"):
-    jf._SIGS.pop("jf_debug_set_reverb_async", None)
+    for name in ("jf_debug_set_reverb_async", "jf_device_numa_node", "jf_pin_thread_to_device"):
+        jf._SIGS.pop(name, None)
+elif not os.environ.get("JF_NO_PIN"):
+    jf.pin_thread_to_device(0)
 hrir = np.load(os.path.join(ROOT, "tests/golden/kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
 rng = np.random.default_rng(99)
 ir = rng.standard_normal(88200) * np.exp(-6.9 * np.arange(88200) / 88200.0)

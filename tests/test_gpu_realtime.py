@@ -191,3 +191,34 @@ def test_completion_words_under_load_every_block_checked(jf, hrir, castanets):
     ref.close()
     assert loud > 0.05
     assert worst <= TOL32 * 16 * max(1.0, loud)
+
+
+def test_the_calling_thread_can_be_put_on_the_gpus_numa_node():
+    """jf_device_numa_node / jf_pin_thread_to_device (include/jefferson.h): the node the system reports for the device (or -1)
+    and, where it reports one, an affinity mask inside that node's CPUs afterwards -- in a child process, so that the test
+    runner's own affinity stays what it was.  A device that does not exist is an error, not a guess."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ('import os, sys\nsys.path.insert(0, %r)\nfrom jf_load import jf\n'
+            'n = jf.device_numa_node(0)\nbefore = os.sched_getaffinity(0)\nok = jf.pin_thread_to_device(0)\n'
+            'after = os.sched_getaffinity(0)\nprint(n, int(ok), len(before), len(after), int(after <= before))\n'
+            'if n >= 0 and ok:\n'
+            '    lst = open("/sys/devices/system/node/node%%d/cpulist" %% n).read().strip()\n'
+            '    cpus = set()\n'
+            '    for part in lst.split(","):\n'
+            '        a, _, b = part.partition("-")\n'
+            '        cpus |= set(range(int(a), int(b or a) + 1))\n'
+            '    print(int(after <= cpus))\n'
+            'try:\n    jf.device_numa_node(99)\n    print("NOERR")\nexcept jf.JfError as ex:\n    print("ERR", ex.code)\n' % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    lines = r.stdout.decode().split("\n")
+    n, ok, n_before, n_after, inside = (int(x) for x in lines[0].split())
+    assert n >= -1 and inside == 1 and 1 <= n_after <= n_before
+    if n >= 0 and ok:
+        assert lines[1].strip() == "1"          # only CPUs of the device's node are left
+        assert lines[2].startswith("ERR")
+    else:
+        assert n_after == n_before              # nothing was changed
+        assert lines[1].startswith("ERR")
