@@ -186,7 +186,8 @@ struct jf_engine {
     // what the last stage wants run on the side stream once the block's spatialiser has been launched (submit_side)
     bool side_tr = false;
     ReverbBigParams side_p[2];   // transforms, products
-    int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow)
+    int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
+                                 // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md)
 };
 
 namespace {
@@ -694,7 +695,6 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             JF_HIP(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
             JF_HIP(e, hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi));
             JF_HIP(e, hipStreamCreateWithPriority(&e->rv_side, hipStreamNonBlocking, lo));
-            if (const char *w = getenv("JF_RV_SIDE_WGS")) e->rv_side_wgs = atoi(w);  // tuning runs
         }
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_main, hipEventDisableTiming));
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_side, hipEventDisableTiming));
