@@ -10,8 +10,8 @@ sys.path.insert(0, ROOT)
 from jf_load import jf
 hrir = np.load(os.path.join(ROOT, "tests/golden/kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
 rng = np.random.default_rng(4)
-S, B, N = int(os.environ.get("JF_SOAK_SOURCES", "64")), 128, int(os.environ.get("JF_SOAK_CALLS", "20000"))
-ir = rng.standard_normal(16 * B * 9 + 55) * np.exp(-5.0 * np.arange(16 * B * 9 + 55) / (16 * B * 9))
+S, B, N = int(os.environ.get("JF_SOAK_SOURCES", "64")), int(os.environ.get("JF_SOAK_BLOCK", "128")), int(os.environ.get("JF_SOAK_CALLS", "20000"))
+ir = rng.standard_normal(16 * 128 * 9 + 55) * np.exp(-5.0 * np.arange(16 * 128 * 9 + 55) / (16 * 128 * 9))
 ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
 sigs = [rng.uniform(-.5, .5, 5000 + 37 * s).astype(np.float32) for s in range(S)]
 engines = []
@@ -64,4 +64,4 @@ while calls < N:
         print(f"{calls} calls, {blocks} blocks, {side} hand-overs to the side stream, peak {peak:.3f}, {time.time() - t0:.0f} s", flush=True)
 for e in engines:
     e.close()
-print(f"identical bit for bit: {calls} calls, {blocks} blocks, {S} sources, {side} hand-overs to the side stream, peak |y| {peak:.3f}")
+print(f"identical bit for bit: B = {B}, {calls} calls, {blocks} blocks, {S} sources, {side} hand-overs to the side stream, peak |y| {peak:.3f}")
