@@ -188,10 +188,12 @@ struct ReverbParams {
 //   X_m   = spectrum of the dry samples of big blocks m - 2 and m - 1 (absolute block indices 16 (m - 2) .. 16 m - 1), formed
 //           as soon as block 16 m - 1 has been taken in;
 //   H'_0  = spectrum of the response's first B1 taps, H'_1 .. H'_P1 = of the B1-tap partitions behind them.
-// A block that is worked on its own (per-block calls, the ragged ends of batch calls) gets taps [0, B1) from the uniform stage
-// above -- M partitions of B, no latency -- and the rest from  TAIL(m) = sum_{q < P1} X_{m-q} H'_{1+q}, the B1 samples the
-// partitions behind the head contribute to big block m, which depend only on samples before it (Gardner's zero-latency scheme
-// with two sizes): per block P1 / 16 + 16 multiply-accumulates per bin instead of P = 16 P1 + 16.  A big block that lies
+// A block that is worked on its own (per-block calls, the ragged ends of batch calls) gets taps [0, 2 B1) from the uniform
+// stage above -- the head: 2 M partitions of B, no latency -- and the rest from  TAIL(m) = sum_{q = 2 .. P1} X_{m+1-q} H'_q, the
+// B1 samples the partitions behind the head contribute to big block m (Gardner's zero-latency scheme with two sizes): per block
+// (P1 - 1) / 16 + 32 multiply-accumulates per bin instead of P = 16 (P1 + 1).  TAIL(m) needs nothing newer than X_{m-1}, which
+// exists a whole big block before big block m begins: that slack is what lets one-block calls form it on a second stream
+// (jf_engine.cpp: run_reverb_stage).  A big block that lies
 // INSIDE a batch call needs no head at all:  FULL(m) = sum_{q <= P1} X_{m+1-q} H'_q  is its whole wet signal (uniform
 // partitioning at the big size; its input is all there), one transform pair per 16 blocks instead of 16 pairs.
 // blocks per big block: B1 = rv_big_blocks(B) * B is 1024 or 2048 taps (a transform of 2 B1 points by one workgroup in LDS)

@@ -13,10 +13,10 @@
 // Spectra are stored packed: B complex per partition, bin 0 holding (X[0].re, X[B].re).
 //
 // NON-UNIFORM PARTITIONING (round 4; ReverbBigParams in jf_device.h): for a long impulse response the stage above is only
-// the HEAD -- the first M = 16 partitions of B -- and the rest of the response is cut into partitions of B1 = 16 B
-// taps: every 16 blocks one transform of 2 B1 samples, P1 = ceil((n_ir - B1) / B1) multiply-accumulates per bin (43
-// instead of 690 x 16 for the 2 s response at B = 128) and one inverse give the tail's contribution to the NEXT 16 blocks
-// (reverb_big_*), which the head's finishing step adds.  The reference's own form is ONE product over the whole signal
+// the HEAD -- the first 2 M = 32 partitions of B -- and the rest of the response is cut into partitions of B1 = 16 B
+// taps: every 16 blocks one transform of 2 B1 samples, P1 - 1 multiply-accumulates per bin (P1 = ceil((n_ir - B1) / B1): 42
+// instead of 690 x 16 for the 2 s response at B = 128) and one inverse give the tail's contribution to the 16 blocks of the
+// big block AFTER the next (reverb_big_*), which the head's finishing step adds.  The reference's own form is ONE product over the whole signal
 // (cudaPart.cu:87-153: ~log N work per sample); uniform partitions cost P operations per sample, two sizes P / 16 + 16.
 #include <hip/hip_runtime.h>
 
