@@ -245,8 +245,15 @@ float jf_reverb_rms_gain(const float *signal, size_t n, const float *ir, size_t 
  * reference's audio thread would have read from each source at each block
  * (crossfade state carries across blocks and across calls).
  * out_mix: [n_blocks][2 * frames_per_buffer] host buffer.
+ * Afterwards the sources stand where the last callback read them, as they would had the setters been called before each
+ * block (jf_sources_set_latched with the last block's records): a per-block call that follows continues from there, not from
+ * what the setters held before the batch.  (Setter calls from another thread DURING the batch are overwritten by this.)
  */
 int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *out_mix);
+/* Every source's position := its latched record {ele, azi, x, y, z} in records[n_sources][JF_POS_FLOATS] -- what n_sources
+ * setter calls with these (already rounded) values leave behind.  jf_batch_run, whose positions live on the device, does
+ * not move the sources; a host that follows it with per-block calls says where they stand with this or with the setters. */
+int jf_sources_set_latched(jf_engine *e, const float *records);
 
 /*
  * Device-resident form: positions are uploaded once, then any window of them

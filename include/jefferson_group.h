@@ -80,7 +80,8 @@ int jf_group_process_block(jf_group *g, float *out);
  * out_mix [n_blocks][2 * frames_per_buffer] on the host.  Every engine processes its shard with no
  * host <-> device traffic besides its positions; the per-GPU mixes [n][2B] are summed by RCCL
  * (ncclReduce(sum, float32) to the first GPU, enqueued on each engine's stream behind its kernels), and
- * the first GPU's result is copied out.  n_blocks may exceed max_batch_blocks (processed in runs).
+ * the first GPU's result is copied out.  n_blocks may exceed max_batch_blocks (processed in runs).  Afterwards the sources
+ * stand where the last callback read them (jefferson.h: jf_process_batch).
  */
 int jf_group_process_batch(jf_group *g, int n_blocks, const float *positions, float *out_mix);
 

@@ -98,6 +98,7 @@ _SIGS = {
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_async": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_sources_set_latched": (C.c_int, [C.c_void_p, _f]),
     "jf_device_numa_node": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "jf_pin_thread_to_device": (C.c_int, [C.c_int]),
     "jf_debug_reverb_partitions": (C.c_int, [C.c_void_p, _i, _i, _i]),
@@ -313,6 +314,12 @@ class Engine:
         mix = np.zeros((K, 2 * self.B), np.float32)
         self._chk(lib().jf_process_batch(self.h, K, _fp(pos), _fp(mix)))
         return mix
+
+    def set_latched(self, records):
+        """every source's position := its latched record [S][5] (what S setter calls leave behind)"""
+        records = np.ascontiguousarray(records, np.float32)
+        assert records.shape == (self.S, 5)
+        self._chk(lib().jf_sources_set_latched(self.h, _fp(records)))
 
     def upload_positions(self, pos):
         pos = np.ascontiguousarray(pos, np.float32)

@@ -1429,6 +1429,19 @@ int jf_process_batch(jf_engine *e, int n_blocks, const float *positions, float *
         JF_HIP(e, hipStreamSynchronize(e->stream));
         if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
     }
+    // n_blocks callbacks have run: the sources stand where the last of them read them
+    return jf_sources_set_latched(e, positions + (size_t)(n_blocks - 1) * e->S * JF_POS_FLOATS);
+    });
+}
+
+int jf_sources_set_latched(jf_engine *e, const float *records) {
+    return jf_guard([&]() -> int {
+    if (!e || !records) return JF_ERR_ARG;
+    std::lock_guard<std::mutex> lk(e->pos_mu);
+    for (int s = 0; s < e->S; s++) {
+        const float *r = records + (size_t)s * JF_POS_FLOATS;
+        e->pos[s] = HostPos{r[0], r[1], sqrtf(r[2] * r[2] + r[3] * r[3] + r[4] * r[4]), r[2], r[3], r[4]};
+    }
     return JF_OK;
     });
 }

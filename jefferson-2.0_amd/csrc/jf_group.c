@@ -424,6 +424,9 @@ int jf_group_process_batch(jf_group *g, int n_blocks, const float *positions, fl
         rc = jf_group_batch_fetch(g, out_mix + (size_t)b0 * 2 * g->B);
         if (rc != JF_OK) return rc;
     }
+    /* as jf_process_batch: the sources stand where the last callback read them */
+    const float *last = positions + (size_t)(n_blocks - 1) * g->S * JF_POS_FLOATS;
+    for (int i = 0; i < g->n; i++) JG_ENG(g, i, jf_sources_set_latched(g->eng[i], last + (size_t)g->lo[i] * JF_POS_FLOATS));
     return JF_OK;
 }
 

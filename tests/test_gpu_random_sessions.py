@@ -1,0 +1,189 @@
+"""Random sessions: long seeded sequences of everything a host can do to an engine -- setters (spherical and cartesian, whole
+and fractional degrees, positions outside the measured range), new signals (longer and shorter than a block, empty), resets,
+pause, the FD_BASIC switch, per-block calls, batch calls of ragged sizes, the callback's one-block-late ordering -- applied
+to the HIP engine and to the C oracle in lockstep, every block compared.  The engine-only knobs (real-time kernel or batch
+pipeline for per-block calls, the pre-interpolated rows, the source grouping, the reverb's side stream and partitioning) are
+flipped in mid-session as well: they must never change a result beyond float32 rounding.  What the scenario tests check one
+at a time is checked here in the orders nobody thought of."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 4e-7
+
+
+def _signal(rng, castanets):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        return np.zeros(0, np.float32)                                   # empty: silence
+    if kind == 1:
+        n = int(rng.integers(1, 200))                                    # shorter than a block: wraps several times in it
+    else:
+        n = int(rng.integers(300, 9000))
+    a = int(rng.integers(0, len(castanets) - n))
+    return (0.4 * castanets[a:a + n] + 0.05 * rng.uniform(-1, 1, n)).astype(np.float32)
+
+
+def _move(rng, eng, ora, s, log=None):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        ele, azi, r = float(rng.integers(-40, 91)), float(rng.integers(0, 360)), float(rng.uniform(0.2, 3.0))
+    elif kind == 1:
+        ele, azi, r = float(rng.uniform(-60, 100)), float(rng.uniform(-20, 380)), float(rng.uniform(0.05, 6.0))  # fractional, outside
+    # The engine's setters refuse what the index/weight rule cannot place (elevations outside (-50, 90]: JF_ERR_RANGE, the
+    # source stays where it was) -- the reference would read its tables out of bounds there; the oracle is only told what
+    # the engine accepted.
+    if kind <= 1:
+        rc = eng.set_spherical(s, ele, azi, r)
+        if rc == 0:
+            ora.set_spherical(s, ele, azi, r)
+        else:
+            assert rc == -2 and not (-50 < round(ele) <= 90), (rc, ele)       # JF_ERR_RANGE
+        if log is not None:
+            log.append(f"sph s{s} {ele:.3f} {azi:.3f} {r:.3f} rc={rc}")
+    else:
+        x, y, z = (float(v) for v in rng.uniform(-2, 2, 3))
+        if abs(x) + abs(y) + abs(z) < 0.05:
+            z = 1.0
+        rc = eng.set_cartesian(s, x, y, z)
+        if rc == 0:
+            ora.set_cartesian(s, x, y, z)
+        if log is not None:
+            log.append(f"cart s{s} {x:.3f} {y:.3f} {z:.3f} rc={rc}")
+
+
+@pytest.mark.parametrize("seed,B,S,reverb", [(1, 256, 5, 0), (2, 128, 9, 0), (3, 128, 4, 2500), (4, 128, 3, 16 * 128 * 3 + 77), (5, 64, 6, 0)])
+def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S, reverb):
+    rng = np.random.default_rng(1000 + seed)
+    eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=24)
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        sig = _signal(rng, castanets) if s else (0.4 * castanets[:7000]).astype(np.float32)
+        eng.set_signal(s, sig)
+        ora.set_signal(s, sig)
+    P = 0
+    if reverb:
+        ir = (rng.standard_normal(reverb) * np.exp(-4.0 * np.arange(reverb) / reverb)).astype(np.float32)
+        ir /= np.sqrt((ir ** 2).sum())
+        eng.set_reverb(ir, 0.5)
+        ora.set_reverb(ir, 0.5)
+        P = -(-reverb // B)
+    tol_rel = (TOL32 + (2e-7 + 1e-7 * np.sqrt(P) if P else 0.0)) * S
+    worst = peak = 0.0
+    blocks = 0
+    paused = False
+    log = []
+    for step in range(170):
+        op = rng.integers(0, 100)
+        if op < 30:
+            for s in rng.integers(0, S, int(rng.integers(1, S + 1))):
+                _move(rng, eng, ora, int(s), log)
+        elif op < 36:
+            s = int(rng.integers(0, S))
+            sig = _signal(rng, castanets)
+            eng.set_signal(s, sig)
+            ora.set_signal(s, sig)
+            log.append(f"signal s{s} n={len(sig)}")
+        elif op < 40:
+            s = int(rng.integers(0, S))
+            eng.reset(s)
+            ora.reset(s)
+            log.append(f"reset s{s}")
+        elif op < 44:
+            m = int(rng.integers(0, 2))
+            eng.set_mode(m)
+            ora.set_mode(m)
+            log.append(f"mode {m}")
+        elif op < 48:
+            paused = not paused
+            eng.set_pause(paused)
+            log.append(f"pause {paused}")
+        elif op < 53:      # engine-only knobs: results must not care
+            k = rng.integers(0, 5)
+            log.append(f"knob {int(k)}")
+            if k == 0:
+                eng.set_rt_max_sources(int(rng.choice([0, 2, 8192])))
+            elif k == 1:
+                eng.set_interp_table(int(rng.integers(0, 3)))
+            elif k == 2:
+                eng.set_source_group(int(rng.choice([1, 1, S])) if S % 2 else int(rng.choice([1, 2, S])))
+            elif k == 3 and reverb:
+                eng.set_reverb_async(bool(rng.integers(0, 2)))
+            elif k == 4:
+                eng.set_prep_ahead(bool(rng.integers(0, 2)))
+        # then always some audio
+        if rng.random() < 0.25 and not paused:
+            K = int(rng.integers(1, 25))
+            pos = np.zeros((K, S, 5), np.float32)
+            cur = [eng.get_position(s)[[0, 1, 3, 4, 5]] for s in range(S)]     # {ele, azi, r, x, y, z} -> the latched record
+            for k in range(K):
+                for s in range(S):
+                    if rng.random() < 0.3:
+                        cur[s] = jf.position_from_spherical(float(rng.integers(-40, 91)), float(rng.integers(0, 360)), float(rng.uniform(0.2, 3.0)))
+                    pos[k, s] = cur[s]
+            got = eng.process_batch(pos)
+            want = ora.process_batch(pos)
+            log.append(f"batch K={K}")
+        else:
+            got = eng.process_block()[None]
+            want = np.zeros_like(got) if paused else ora.process_block()[None]
+            log.append("block " + ";".join(eng.last_kernels()[-2:]))
+        blocks += len(got)
+        peak = max(peak, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        if err > tol_rel * max(1.0, float(np.abs(want).max())):
+            print("\n".join(log[-40:]))     # (pytest shows it with the failure)
+        assert err <= tol_rel * max(1.0, float(np.abs(want).max())), (seed, step, int(op), err)
+    eng.close()
+    ora.close()
+    assert blocks > 300 and peak > 0.02, (blocks, peak)
+
+
+@pytest.mark.parametrize("seed,B,S", [(11, 256, 3), (12, 128, 20)])
+def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S):
+    """jf_callback hands out the block submitted by the PREVIOUS call (Audio.cu:104-117): the oracle's block k against the
+    engine's call k + 1, with setters, resets, new signals, the mode switch and pause falling between the calls."""
+    rng = np.random.default_rng(2000 + seed)
+    eng = jf.Engine(B, 512, S, hrir=hrir)
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        sig = (0.4 * castanets[1000 * s:1000 * s + 6000]).astype(np.float32)
+        eng.set_signal(s, sig)
+        ora.set_signal(s, sig)
+    prev = np.zeros(2 * B, np.float32)        # intermediate[] before the first block
+    paused = False
+    peak = 0.0
+    for step in range(220):
+        op = rng.integers(0, 100)
+        if op < 40:
+            for s in rng.integers(0, S, 2):
+                _move(rng, eng, ora, int(s))
+        elif op < 45:
+            s = int(rng.integers(0, S))
+            sig = _signal(rng, castanets)
+            eng.set_signal(s, sig)
+            ora.set_signal(s, sig)
+        elif op < 49:
+            s = int(rng.integers(0, S))
+            eng.reset(s)
+            ora.reset(s)
+        elif op < 53:
+            m = int(rng.integers(0, 2))
+            eng.set_mode(m)
+            ora.set_mode(m)
+        elif op < 57:
+            paused = not paused
+            eng.set_pause(paused)
+        got = eng.callback()
+        assert np.abs(got - prev).max() <= TOL32 * S * max(1.0, float(np.abs(prev).max())), (seed, step, int(op))
+        prev = np.zeros(2 * B, np.float32) if paused else ora.process_block()
+        peak = max(peak, float(np.abs(prev).max()))
+    rc, last = eng.collect_block()
+    assert rc == 0 and np.abs(last - prev).max() <= TOL32 * S * max(1.0, float(np.abs(prev).max()))
+    eng.close()
+    ora.close()
+    assert peak > 0.02

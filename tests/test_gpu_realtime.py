@@ -222,3 +222,42 @@ def test_the_calling_thread_can_be_put_on_the_gpus_numa_node():
     else:
         assert n_after == n_before              # nothing was changed
         assert lines[1].startswith("ERR")
+
+
+def test_per_block_calls_continue_from_where_a_batch_call_left_the_sources(jf, hrir, castanets):
+    """jf_process_batch is n callbacks in one call: afterwards the sources stand where the last of them read them (as if the
+    setters had been called before each block), so a per-block call that follows WITHOUT a setter call continues from there --
+    no crossfade back to what the setters held before the batch.  Found by tests/test_gpu_random_sessions.py: the engine used
+    to keep the pre-batch positions.  jf_sources_set_latched is the same thing said explicitly; jf_batch_run leaves the sources
+    alone."""
+    S, B, K = 3, 256, 5
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    o = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        sig = 0.3 * castanets[2000 * s: 2000 * s + 9000]
+        e.set_signal(s, sig)
+        o.set_signal(s, sig)
+        e.set_spherical(s, 0, 10 * s, 1.0)
+        o.set_spherical(s, 0, 10 * s, 1.0)
+    pos = np.zeros((K, S, 5), np.float32)
+    for k in range(K):
+        for s in range(S):
+            pos[k, s] = jf.position_from_spherical(20 + 5 * s, 100 + 30 * s + 7 * k, 0.8)
+    assert np.abs(e.process_batch(pos) - o.process_batch(pos)).max() <= TOL32 * S
+    for s in range(S):
+        assert np.array_equal(e.get_position(s)[[0, 1, 3, 4, 5]], pos[K - 1, s])      # {ele, azi, r, x, y, z}
+    a, b = e.process_block(), o.process_block()          # no setter call in between
+    assert np.abs(b).max() > 0.002 and np.abs(a - b).max() <= TOL32 * S
+    # the same through the explicit entry point, after a run of an uploaded trajectory
+    e.upload_positions(pos)
+    e.batch_run(0, K)
+    e.synchronize()
+    want = o.process_batch(pos)
+    assert np.abs(e.read_device(e.mix_device_ptr(), (K, 2 * B)) - want).max() <= TOL32 * S
+    e.set_latched(pos[2])                                 # "the sources stand at block 2's positions"
+    for s in range(S):
+        o.set_spherical(s, 20 + 5 * s, 100 + 30 * s + 7 * 2, 0.8)
+    a, b = e.process_block(), o.process_block()
+    e.close()
+    o.close()
+    assert np.abs(a - b).max() <= TOL32 * S
