@@ -68,14 +68,19 @@ def shard_range(n_total, n_parts, part):
 
 
 class Group:
-    def __init__(self, B, hrtf_len, n_sources, hrir, n_gpus=1, devices=None, max_batch_blocks=1, flags=0):
+    def __init__(self, B, hrtf_len, n_sources, hrir, n_gpus=1, devices=None, max_batch_blocks=1, flags=0, shards_on_device=0):
+        """shards_on_device = n > 0: n shards of the job on device 0 with a host sum instead of RCCL (test support,
+        jf_group_create_shards_on_device)."""
         L = lib()
         cfg = JfConfig(B, hrtf_len, n_sources, 0, max_batch_blocks, flags)
         hrir = np.ascontiguousarray(hrir, np.float32)
         assert hrir.shape[0] == NUM_HRTF and hrir.shape[1] == 2
         h = C.c_void_p()
         dev = (C.c_int * n_gpus)(*devices) if devices is not None else None
-        rc = L.jf_group_create(C.byref(cfg), n_gpus, dev, _fp(hrir), hrir.shape[2], C.byref(h))
+        if shards_on_device > 0:
+            rc = L.jf_group_create_shards_on_device(C.byref(cfg), int(shards_on_device), 0, _fp(hrir), hrir.shape[2], C.byref(h))
+        else:
+            rc = L.jf_group_create(C.byref(cfg), n_gpus, dev, _fp(hrir), hrir.shape[2], C.byref(h))
         if rc:
             raise JfError(rc, L.jf_group_last_error(None).decode())
         self.h, self.B, self.S, self.maxK = h, B, n_sources, max_batch_blocks

@@ -187,3 +187,65 @@ def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S):
     eng.close()
     ora.close()
     assert peak > 0.02
+
+
+@pytest.mark.parametrize("seed,B,S,shards", [(21, 256, 7, 3), (22, 128, 10, 2)])
+def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B, S, shards):
+    """The same through include/jefferson_group.h with several shards of the job on the one device (production code for the
+    sharding, the repack of the positions, the routing of per-source calls by GLOBAL index, the job-wide controls; the wire
+    replaced by a host sum): one job, the C oracle beside it."""
+    import importlib
+    group = importlib.import_module("jefferson_amd.group")       # needs libjefferson_group.so (RCCL at build time)
+    rng = np.random.default_rng(3000 + seed)
+    g = group.Group(B, 512, S, hrir, max_batch_blocks=12, shards_on_device=shards)
+    assert g.num_gpus() == shards
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    for s in range(S):
+        sig = (0.4 * castanets[900 * s:900 * s + 5000 + 31 * s]).astype(np.float32)
+        g.set_signal(s, sig)
+        ora.set_signal(s, sig)
+    paused = False
+    peak = 0.0
+    blocks = 0
+    cur = [None] * S
+    for s in range(S):
+        g.set_spherical(s, 0.0, float(20 * s), 1.0)
+        ora.set_spherical(s, 0.0, float(20 * s), 1.0)
+    for step in range(120):
+        op = rng.integers(0, 100)
+        if op < 35:
+            for s in rng.integers(0, S, 3):
+                _move(rng, g, ora, int(s))
+        elif op < 40:
+            s = int(rng.integers(0, S))
+            sig = _signal(rng, castanets)
+            g.set_signal(s, sig)
+            ora.set_signal(s, sig)
+        elif op < 44:
+            s = int(rng.integers(0, S))
+            g.reset(s)
+            ora.reset(s)
+        elif op < 48:
+            m = int(rng.integers(0, 2))
+            assert g.set_mode(m) == 0
+            ora.set_mode(m)
+        elif op < 52:
+            paused = not paused
+            g.set_pause(paused)
+        if rng.random() < 0.3 and not paused:
+            K = int(rng.integers(1, 20))       # beyond max_batch_blocks: processed in runs
+            pos = np.zeros((K, S, 5), np.float32)
+            for k in range(K):
+                for s in range(S):
+                    pos[k, s] = jf.position_from_spherical(float(rng.integers(-40, 91)), float(rng.integers(0, 360)), float(rng.uniform(0.2, 3.0)))
+            got = g.process_batch(pos)
+            want = ora.process_batch(pos)
+        else:
+            got = g.process_block()[None]
+            want = np.zeros_like(got) if paused else ora.process_block()[None]
+        blocks += len(got)
+        peak = max(peak, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op))
+    assert not g.failed() and blocks > 200 and peak > 0.02
+    g.close()
+    ora.close()
