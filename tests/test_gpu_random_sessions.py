@@ -249,3 +249,76 @@ def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B
     assert not g.failed() and blocks > 200 and peak > 0.02
     g.close()
     ora.close()
+
+
+@pytest.mark.parametrize("seed,B,S,G", [(31, 256, 16, 4), (32, 128, 12, 0), (33, 256, 8, 1)])
+def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets, seed, B, S, G):
+    """jf_batch_upload_positions / jf_batch_run: windows of an uploaded trajectory in and out of order -- a run that follows
+    its predecessor finds its descriptors prepared by it (inside the pair kernel's launch or the mix kernel's), any other run
+    must not -- with everything that may invalidate them in between: another upload, the mode switch, the rows' policy, a
+    reset, per-block calls, a new grouping.  Against the oracle fed the same windows."""
+    rng = np.random.default_rng(4000 + seed)
+    K = 8
+    eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
+    ora = oracle_lib.Engine(B, 512, S, hrir)
+    if G:
+        eng.set_source_group(G)
+    for s in range(S):
+        sig = (0.4 * castanets[700 * s:700 * s + 6000 + 13 * s]).astype(np.float32)
+        eng.set_signal(s, sig)
+        ora.set_signal(s, sig)
+
+    def trajectory(n):
+        ele = rng.integers(-40, 91, S).astype(np.float32)
+        azi0 = rng.integers(0, 360, S)
+        every = rng.integers(1, 5, S)           # some sources move every block, some dwell
+        b = np.arange(n)[:, None]
+        azi = (azi0[None, :] + b // every[None, :]) % 360
+        return jf.positions_from_spherical(np.broadcast_to(ele, (n, S)), azi.astype(np.float32),
+                                           np.broadcast_to(rng.uniform(0.3, 2.5, S).astype(np.float32), (n, S)))
+    pos = trajectory(64)
+    eng.upload_positions(pos)
+    nxt = 0
+    peak = 0.0
+    prepared = 0
+    for step in range(90):
+        op = rng.integers(0, 100)
+        if op < 8:
+            pos = trajectory(int(rng.integers(2, 9)) * K)
+            eng.upload_positions(pos)
+            nxt = 0
+        elif op < 14:
+            m = int(rng.integers(0, 2))
+            eng.set_mode(m)
+            ora.set_mode(m)
+        elif op < 20:
+            eng.set_interp_table(int(rng.integers(0, 3)))
+        elif op < 25:
+            s = int(rng.integers(0, S))
+            eng.reset(s)
+            ora.reset(s)
+        elif op < 30 and G != 1:
+            eng.set_source_group(int(rng.choice([1, 2, 4])))
+        elif op < 35:
+            eng.set_prep_ahead(bool(rng.integers(0, 2)))
+        elif op < 45:                            # a per-block call in between (positions: where the last run left the sources)
+            a, b = eng.process_block(), ora.process_block()
+            assert np.abs(a - b).max() <= TOL32 * S * max(1.0, float(np.abs(b).max())), (seed, step, "block")
+        # a run: mostly the window that follows, sometimes any other
+        n = int(rng.integers(1, K + 1))
+        if rng.random() < 0.25 or nxt + n > len(pos):
+            first = int(rng.integers(0, len(pos) - n + 1))
+        else:
+            first = nxt
+        eng.batch_run(first, n)
+        eng.synchronize()
+        prepared += any("prep" in k and k != "prep_kernel" for k in eng.last_kernels())
+        got = eng.read_device(eng.mix_device_ptr(), (n, 2 * B))
+        want = ora.process_batch(pos[first:first + n])
+        eng.set_latched(pos[first + n - 1])      # jf_batch_run leaves the sources alone: say where they stand
+        nxt = first + n
+        peak = max(peak, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op), first, n, eng.last_kernels())
+    eng.close()
+    ora.close()
+    assert peak > 0.02 and prepared > 5, (peak, prepared)
