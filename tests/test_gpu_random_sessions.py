@@ -55,7 +55,8 @@ def _move(rng, eng, ora, s, log=None):
             log.append(f"cart s{s} {x:.3f} {y:.3f} {z:.3f} rc={rc}")
 
 
-@pytest.mark.parametrize("seed,B,S,reverb", [(1, 256, 5, 0), (2, 128, 9, 0), (3, 128, 4, 2500), (4, 128, 3, 16 * 128 * 3 + 77), (5, 64, 6, 0)])
+@pytest.mark.parametrize("seed,B,S,reverb", [(1, 256, 5, 0), (2, 128, 9, 0), (3, 128, 4, 2500), (4, 128, 3, 16 * 128 * 3 + 77), (5, 64, 6, 0),
+                                                 (6, 192, 4, 0), (7, 256, 40, 0), (8, 256, 6, 8 * 256 * 4 + 5)])
 def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S, reverb):
     rng = np.random.default_rng(1000 + seed)
     eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=24)
