@@ -86,7 +86,9 @@ int host_pick_hrtf(float obj_ele, float obj_azi) {
 }
 
 int host_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
-    if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
+    // (-50, 91): where both truncated elevations name a measured ring.  The setters' whole degrees end at 90; a latched record
+    // may carry 90.x, which the reference's statements place on the 90-degree ring twice (weights 0.x and -0.x)
+    if (!(ele > -50.0f && ele < 91.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
     const int phi0 = (int)ele / 10 * 10;
     const int phi1 = (int)(ele + 9) / 10 * 10;
     int r0 = -1, r1 = -1;

@@ -1588,7 +1588,7 @@ JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[
         if (!dev_interp_corrected(rt, ele, azi, h, om)) return 0;
         return dev_flatten_terms(h[0], h[1], h[2], h[3], om[0], om[1], om[2], om[3], om[4], om[5], rows, w);
     }
-    if (!(ele > -50.0f && ele <= 90.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return 0;
+    if (!(ele > -50.0f && ele < 91.0f) || !(azi > -1.0e6f && azi < 1.0e6f)) return 0;  // as host_interpolation (jf_host.cpp)
     const int phi0 = (int)(ele) / 10 * 10;
     const int phi1 = (int)(ele + 9) / 10 * 10;
     const float omegaE = (ele - phi0) / 10.0f;

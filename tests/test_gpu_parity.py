@@ -77,6 +77,31 @@ def test_interp_kernel_exhaustive(eng256):
     assert bad == 0
 
 
+def test_interp_kernel_fractional_positions(eng256, jf):
+    """The same for positions a latched record may carry but no setter produces: fractional degrees over the whole range and
+    densely round the ends of the range, where the reference's truncating statements decide what is still a position --
+    (-50, 91): an elevation of 90.x lies on the 90-degree ring twice (tests/test_gpu_random_sessions.py found the engine
+    refusing it) -- and the host's twin of the rule (jf_interpolation) with them."""
+    rng = np.random.default_rng(9)
+    eles = np.concatenate([rng.uniform(-52, 93, 20000), rng.uniform(89.5, 91.5, 3000), rng.uniform(-50.5, -48.5, 3000),
+                           np.array([90.0, 90.25, 90.999, 91.0, -49.999, -50.0, -40.0, -39.999, 0.0, -0.5, 0.5])]).astype(np.float32)
+    azis = np.concatenate([rng.uniform(-5, 365, len(eles) - 11), np.array([0, 359.9, 360, 0.1, 5, 355, 180, 6.43, 6.42, 353.6, 0.5])]).astype(np.float32)
+    rows, w, nt = eng256.interp_device(eles, azis)
+    bad = n_valid = 0
+    for i in range(len(eles)):
+        r = oracle_lib.interp(float(eles[i]), float(azis[i]))
+        h = jf.interpolation(float(eles[i]), float(azis[i]))
+        if r is None:
+            bad += (nt[i] != 0) + (h is not None)
+            continue
+        n_valid += 1
+        bad += not (h is not None and np.array_equal(h[0], r[0]) and np.array_equal(h[1], r[1]))
+        orows, ow = oracle_lib.terms(*r)
+        n = len(orows)
+        bad += not (nt[i] == n and np.array_equal(rows[i, :n], orows) and np.array_equal(w[i, :n], ow))
+    assert bad == 0 and n_valid > 20000
+
+
 def test_corrected_rule_kernel_and_end_to_end(jf, hrir, castanets):
     """JF_FLAG_CORRECTED_INTERPOLATION: the kernel's indices/weights bit-exact against the oracle's corrected rule,
     then whole blocks (batch and per-block paths) against the oracle run with the same rule -- including the

@@ -122,8 +122,14 @@ def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S
             cur = [eng.get_position(s)[[0, 1, 3, 4, 5]] for s in range(S)]     # {ele, azi, r, x, y, z} -> the latched record
             for k in range(K):
                 for s in range(S):
-                    if rng.random() < 0.3:
+                    u = rng.random()
+                    if u < 0.3:
                         cur[s] = jf.position_from_spherical(float(rng.integers(-40, 91)), float(rng.integers(0, 360)), float(rng.uniform(0.2, 3.0)))
+                    elif u < 0.38:
+                        # a record need not come from a setter: fractional degrees, now and then a position the rule cannot
+                        # place (a silent item; the block after it fades in from nothing)
+                        ele = float(rng.uniform(-49.4, 90.4)) if u < 0.36 else float(rng.choice([-55.0, 93.5]))
+                        cur[s] = np.array([ele, float(rng.uniform(0, 359.9)), *rng.uniform(-2, 2, 3)], np.float32)
                     pos[k, s] = cur[s]
             got = eng.process_batch(pos)
             want = ora.process_batch(pos)
@@ -141,7 +147,7 @@ def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S
         assert err <= tol_rel * max(1.0, float(np.abs(want).max())), (seed, step, int(op), err)
     eng.close()
     ora.close()
-    assert blocks > 300 and peak > 0.02, (blocks, peak)
+    assert blocks > 200 and peak > 0.02, (blocks, peak)
 
 
 @pytest.mark.parametrize("seed,B,S", [(11, 256, 3), (12, 128, 20)])
