@@ -150,8 +150,8 @@ def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S
     assert blocks > 200 and peak > 0.02, (blocks, peak)
 
 
-@pytest.mark.parametrize("seed,B,S", [(11, 256, 3), (12, 128, 20)])
-def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S):
+@pytest.mark.parametrize("seed,B,S,reverb", [(11, 256, 3, 0), (12, 128, 20, 0), (13, 128, 5, 16 * 128 * 3 + 9)])
+def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S, reverb):
     """jf_callback hands out the block submitted by the PREVIOUS call (Audio.cu:104-117): the oracle's block k against the
     engine's call k + 1, with setters, resets, new signals, the mode switch and pause falling between the calls."""
     rng = np.random.default_rng(2000 + seed)
@@ -161,6 +161,13 @@ def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S):
         sig = (0.4 * castanets[1000 * s:1000 * s + 6000]).astype(np.float32)
         eng.set_signal(s, sig)
         ora.set_signal(s, sig)
+    tol = TOL32 * S
+    if reverb:      # the big partitions' work goes to the side stream a whole big block ahead (16 blocks: 220 calls cross 13 of them)
+        ir = (rng.standard_normal(reverb) * np.exp(-4.0 * np.arange(reverb) / reverb)).astype(np.float32)
+        ir /= np.sqrt((ir ** 2).sum())
+        eng.set_reverb(ir, 0.5)
+        ora.set_reverb(ir, 0.5)
+        tol += (2e-7 + 1e-7 * np.sqrt(-(-reverb // B))) * S
     prev = np.zeros(2 * B, np.float32)        # intermediate[] before the first block
     paused = False
     peak = 0.0
@@ -186,18 +193,18 @@ def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S):
             paused = not paused
             eng.set_pause(paused)
         got = eng.callback()
-        assert np.abs(got - prev).max() <= TOL32 * S * max(1.0, float(np.abs(prev).max())), (seed, step, int(op))
+        assert np.abs(got - prev).max() <= tol * max(1.0, float(np.abs(prev).max())), (seed, step, int(op))
         prev = np.zeros(2 * B, np.float32) if paused else ora.process_block()
         peak = max(peak, float(np.abs(prev).max()))
     rc, last = eng.collect_block()
-    assert rc == 0 and np.abs(last - prev).max() <= TOL32 * S * max(1.0, float(np.abs(prev).max()))
+    assert rc == 0 and np.abs(last - prev).max() <= tol * max(1.0, float(np.abs(prev).max()))
     eng.close()
     ora.close()
     assert peak > 0.02
 
 
-@pytest.mark.parametrize("seed,B,S,shards", [(21, 256, 7, 3), (22, 128, 10, 2)])
-def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B, S, shards):
+@pytest.mark.parametrize("seed,B,S,shards,reverb", [(21, 256, 7, 3, 0), (22, 128, 10, 2, 0), (23, 128, 6, 3, 16 * 128 * 4 + 1)])
+def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B, S, shards, reverb):
     """The same through include/jefferson_group.h with several shards of the job on the one device (production code for the
     sharding, the repack of the positions, the routing of per-source calls by GLOBAL index, the job-wide controls; the wire
     replaced by a host sum): one job, the C oracle beside it."""
@@ -211,10 +218,16 @@ def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B
         sig = (0.4 * castanets[900 * s:900 * s + 5000 + 31 * s]).astype(np.float32)
         g.set_signal(s, sig)
         ora.set_signal(s, sig)
+    tol = TOL32 * S
+    if reverb:
+        ir = (rng.standard_normal(reverb) * np.exp(-4.0 * np.arange(reverb) / reverb)).astype(np.float32)
+        ir /= np.sqrt((ir ** 2).sum())
+        g.set_reverb(ir, 0.5)
+        ora.set_reverb(ir, 0.5)
+        tol += (2e-7 + 1e-7 * np.sqrt(-(-reverb // B))) * S
     paused = False
     peak = 0.0
     blocks = 0
-    cur = [None] * S
     for s in range(S):
         g.set_spherical(s, 0.0, float(20 * s), 1.0)
         ora.set_spherical(s, 0.0, float(20 * s), 1.0)
@@ -252,7 +265,7 @@ def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B
             want = np.zeros_like(got) if paused else ora.process_block()[None]
         blocks += len(got)
         peak = max(peak, float(np.abs(want).max()))
-        assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op))
+        assert np.abs(got - want).max() <= tol * max(1.0, float(np.abs(want).max())), (seed, step, int(op))
     assert not g.failed() and blocks > 200 and peak > 0.02
     g.close()
     ora.close()
@@ -288,7 +301,7 @@ def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets,
     nxt = 0
     peak = 0.0
     prepared = 0
-    for step in range(90):
+    for step in range(60):
         op = rng.integers(0, 100)
         if op < 8:
             pos = trajectory(int(rng.integers(2, 9)) * K)
@@ -328,4 +341,4 @@ def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets,
         assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op), first, n, eng.last_kernels())
     eng.close()
     ora.close()
-    assert peak > 0.02 and prepared > 5, (peak, prepared)
+    assert peak > 0.02 and prepared > 3, (peak, prepared)
