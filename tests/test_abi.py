@@ -376,3 +376,41 @@ def test_group_without_gpu_fails_loudly(jf, hrir):
     with pytest.raises(jf.JfError) as ei:
         grp.Group(256, 512, 2, hrir, n_gpus=3)      # more GPUs than sources
     assert ei.value.code == jf.JF_ERR_ARG
+
+
+def test_every_entry_point_survives_null_arguments():
+    """No exit, no throw and no fault across the ABI (the reference prints and exits, cufftDefines.cuh:69-77): every
+    exported function of both libraries called with a null engine / group and null or zero everything else must come back --
+    with an error code where it has one.  In a child process, each name printed before its call, so that a fault names its
+    function.  No GPU needed (and none touched: a null handle is refused first)."""
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from jf_load import jf
+import importlib
+mods = [(jf, jf.lib(), jf._SIGS)]
+try:
+    grp = importlib.import_module("jefferson_amd.group")
+    mods.append((grp, grp.lib(), grp._SIGS))
+except Exception as ex:      # the group library needs RCCL at build time
+    print("no group library:", ex)
+def zero(t):
+    if t in (C.c_int, C.c_uint, C.c_long, C.c_longlong, C.c_size_t, C.c_ulong):
+        return t(0)
+    if t in (C.c_float, C.c_double):
+        return t(0.0)
+    return None            # pointers of every kind
+n = 0
+for mod, L, sigs in mods:
+    for name, (res, args) in sorted(sigs.items()):
+        print("calling", name, flush=True)
+        r = getattr(L, name)(*[zero(t) for t in args])
+        n += 1
+print("SURVIVED", n)
+''' % ROOT
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "SURVIVED" in out, (out[-600:], r.stderr.decode()[-600:])
+    assert int(out.split("SURVIVED")[1]) >= 80
