@@ -888,3 +888,62 @@ print("STILL WORKS")
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "STILL WORKS" in out, (out[-800:], r.stderr.decode()[-1500:])
+
+
+def test_a_live_group_survives_bad_arguments_and_keeps_working(hrir):
+    """The same for include/jefferson_group.h with a live group (three shards on the one device) behind the handle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import ctypes as C, sys, os, importlib
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+from jf_load import jf
+import oracle_lib
+grp = importlib.import_module("jefferson_amd.group")
+hrir = np.load(os.path.join(%r, "tests/golden/kemar_hrir_710x2x128_i16.npy")).astype(np.float32) / np.float32(32768)
+S = 7
+g = grp.Group(256, 512, S, hrir, max_batch_blocks=4, shards_on_device=3)
+o = oracle_lib.Engine(256, 512, S, hrir)
+rng = np.random.default_rng(2)
+def fresh():
+    for s in range(S):
+        g.reset(s); o.reset(s)
+        sig = rng.uniform(-0.5, 0.5, 5000).astype(np.float32)
+        g.set_signal(s, sig); o.set_signal(s, sig)
+        g.set_spherical(s, 10 * s - 30, 40 * s, 1.0); o.set_spherical(s, 10 * s - 30, 40 * s, 1.0)
+fresh()
+assert np.abs(g.process_block() - o.process_block()).max() < 4e-6
+L = grp.lib()
+skip = {"jf_group_destroy", "jf_group_create", "jf_group_create_shards_on_device", "jf_group_debug_fail_next"}
+n = 0
+for variant in (0, 1, 2):
+    for name, (res, args) in sorted(grp._SIGS.items()):
+        if name in skip or not args or args[0] is not C.c_void_p:
+            continue
+        vals = [g.h]
+        for t in args[1:]:
+            if t in (C.c_int, C.c_uint, C.c_long, C.c_longlong, C.c_size_t, C.c_ulong):
+                vals.append(t([0, -1 if t in (C.c_int, C.c_long, C.c_longlong) else 0, 1 << 20][variant]))
+            elif t in (C.c_float, C.c_double):
+                vals.append(t([0.0, float("nan"), 1e30][variant]))
+            else:
+                vals.append(None)
+        print("calling", name, variant, flush=True)
+        getattr(L, name)(*vals)
+        n += 1
+print("CALLS", n, flush=True)
+assert not g.failed()
+L.jf_group_set_pause(g.h, 0); L.jf_group_set_mode(g.h, 0)
+g.set_reverb(np.zeros(0, np.float32))
+fresh()
+for k in range(3):
+    a, b = g.process_block(), o.process_block()
+    assert np.abs(a - b).max() < 4e-6, (k, np.abs(a - b).max())
+g.close()
+print("STILL WORKS")
+''' % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "STILL WORKS" in out, (out[-800:], r.stderr.decode()[-1500:])
