@@ -947,3 +947,36 @@ print("STILL WORKS")
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "STILL WORKS" in out, (out[-800:], r.stderr.decode()[-1500:])
+
+
+def test_engines_come_and_go_without_leaking_device_memory(jf, hrir, castanets):
+    """Twenty engines created, used (batch and per-block calls, the reverb with its side stream, a new response) and
+    destroyed: the device's free memory afterwards is what it was before the first (each engine holds ~0.4 GB of tables and
+    rings; a leak of any of its buffers, streams or events would show)."""
+    import torch
+    torch.cuda.init()
+    ir = (np.random.default_rng(3).standard_normal(16 * 128 * 3 + 5) * 0.02).astype(np.float32)
+
+    def cycle():
+        e = jf.Engine(128, 512, 24, hrir=hrir, max_batch_blocks=8)
+        for s in range(24):
+            e.set_signal(s, castanets[100 * s:100 * s + 4000])
+        e.set_reverb(ir, 0.5)
+        for _ in range(18):
+            e.process_block()
+        pos = np.zeros((8, 24, 5), np.float32)
+        for k in range(8):
+            for s in range(24):
+                pos[k, s] = jf.position_from_spherical(0, (10 * s + k) % 360, 1.0)
+        e.process_batch(pos)
+        e.set_reverb(ir[:700], 0.5)
+        e.process_block()
+        e.close()
+    cycle()                                  # (the first one also pays for the runtime's own pools)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
