@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import model64
+import oracle_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -398,3 +399,47 @@ def test_one_block_calls_with_the_big_partitions_on_the_side_stream(jf, hrir, ca
         e.close()
     assert np.abs(outs[0]).max() > 0.02
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B", [64, 128])
+def test_nonuniform_rings_wrap_many_times(jf, hrir, castanets, B):
+    """1500 blocks -- ~94 big blocks: every ring of the non-uniform stage (the big partitions' delay line of ~25 slots, the
+    dry ring, the four places of the fut ring, the small delay line, the wet ring) wraps several times -- as one-block calls
+    (side stream) with ragged batch calls strewn in, against the C oracle's uniform stream form block by block."""
+    S = 2
+    ir = _ir(16 * B * 3 + 5, decay=3.0)
+    P = -(-len(ir) // B)
+    e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=40)
+    o = oracle_lib.Engine(B, 512, S, hrir)
+    for s_ in range(S):
+        sig = castanets[5000 * s_: 5000 * s_ + 30000]
+        e.set_signal(s_, sig)
+        o.set_signal(s_, sig)
+    e.set_reverb(ir, 0.6)
+    o.set_reverb(ir, 0.6)
+    assert e.reverb_partitions()[2] > 0          # non-uniform by default at this length
+    rng = np.random.default_rng(77)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * S
+    done = 0
+    worst = peak = 0.0
+    while done < 1500:
+        if rng.random() < 0.1:
+            k = int(rng.integers(2, 41))
+            pos = np.zeros((k, S, 5), np.float32)
+            for b in range(k):
+                for s_ in range(S):
+                    pos[b, s_] = jf.position_from_spherical(10 * s_, (done + b + 90 * s_) % 360, 0.8)
+            got, want = e.process_batch(pos), o.process_batch(pos)
+            done += k
+        else:
+            for s_ in range(S):
+                e.set_spherical(s_, 10 * s_, (done + 90 * s_) % 360, 0.8)
+                o.set_spherical(s_, 10 * s_, (done + 90 * s_) % 360, 0.8)
+            got, want = e.process_block(), o.process_block()
+            done += 1
+        peak = max(peak, float(np.abs(want).max()))
+        worst = max(worst, float(np.abs(got - want).max()))
+        assert np.abs(got - want).max() <= tol * max(1.0, float(np.abs(want).max())), done
+    e.close()
+    o.close()
+    assert peak > 0.05, peak
