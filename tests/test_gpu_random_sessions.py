@@ -56,11 +56,13 @@ def _move(rng, eng, ora, s, log=None):
 
 
 @pytest.mark.parametrize("seed,B,S,reverb", [(1, 256, 5, 0), (2, 128, 9, 0), (3, 128, 4, 2500), (4, 128, 3, 16 * 128 * 3 + 77), (5, 64, 6, 0),
-                                                 (6, 192, 4, 0), (7, 256, 40, 0), (8, 256, 6, 8 * 256 * 4 + 5)])
+                                                 (6, 192, 4, 0), (7, 256, 40, 0), (8, 256, 6, 8 * 256 * 4 + 5), (9, 256, 7, 0)])
 def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S, reverb):
     rng = np.random.default_rng(1000 + seed)
-    eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=24)
+    corrected = seed == 9        # one session under JF_FLAG_CORRECTED_INTERPOLATION (the oracle's mode bit 1)
+    eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=24, flags=jf.JF_FLAG_CORRECTED_INTERPOLATION if corrected else 0)
     ora = oracle_lib.Engine(B, 512, S, hrir)
+    ora.set_mode(2 if corrected else 0)
     for s in range(S):
         sig = _signal(rng, castanets) if s else (0.4 * castanets[:7000]).astype(np.float32)
         eng.set_signal(s, sig)
@@ -96,7 +98,7 @@ def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S
         elif op < 44:
             m = int(rng.integers(0, 2))
             eng.set_mode(m)
-            ora.set_mode(m)
+            ora.set_mode(m | (2 if corrected else 0))
             log.append(f"mode {m}")
         elif op < 48:
             paused = not paused
