@@ -192,6 +192,15 @@ struct jf_engine {
 
 namespace {
 
+// Host -> device copies and memsets of engine state go through the ENGINE'S stream: it is a non-blocking stream, which the null
+// stream's copies and memsets are not ordered with -- a kernel launched right behind a hipMemset of the null stream could run
+// before it (a reset followed at once by a block: found by the random sessions, one run in twelve).  The copy has landed when
+// this returns (the host buffer may be a temporary).
+hipError_t h2d(jf_engine *e, void *dst, const void *src, size_t bytes) {
+    const hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream);
+    return r != hipSuccess ? r : hipStreamSynchronize(e->stream);
+}
+
 int fail(jf_engine *e, int code, const std::string &msg) {
     if (e)
         e->err = msg;
@@ -588,21 +597,21 @@ int reset_sources(jf_engine *e, int src) {
     const size_t s0 = src < 0 ? 0 : (size_t)src, ns = src < 0 ? (size_t)e->S : 1;
     const int p = e->cur;
     quiesce_side(e);  // (what it has left in the fut ring is zeroed below with the rest)
-    JF_HIP(e, hipMemset(e->d_hist[p] + s0 * kN, 0, sizeof(float) * kN * ns));
-    JF_HIP(e, hipMemset(e->d_state[p] + s0, 0, sizeof(SrcState) * ns));
+    JF_HIP(e, hipMemsetAsync(e->d_hist[p] + s0 * kN, 0, sizeof(float) * kN * ns, e->stream));
+    JF_HIP(e, hipMemsetAsync(e->d_state[p] + s0, 0, sizeof(SrcState) * ns, e->stream));
     if (e->rv_P > 0) {
         const size_t B = (size_t)e->B;
-        JF_HIP(e, hipMemset(e->d_rv_fdl + s0 * e->rv_Rg * B, 0, sizeof(float2) * e->rv_Rg * B * ns));
-        JF_HIP(e, hipMemset(e->d_rv_fdl + (size_t)e->S * e->rv_Rg * B + s0 * e->rv_Rg, 0, sizeof(float2) * e->rv_Rg * ns));
-        JF_HIP(e, hipMemset(e->d_rv_wet + s0 * e->rv_Wr, 0, sizeof(float) * e->rv_Wr * ns));
-        JF_HIP(e, hipMemset(e->d_rv_prev[p] + s0 * B, 0, sizeof(float) * B * ns));
-        JF_HIP(e, hipMemset(e->d_rv_count[p] + s0, 0, sizeof(int) * ns));
+        JF_HIP(e, hipMemsetAsync(e->d_rv_fdl + s0 * e->rv_Rg * B, 0, sizeof(float2) * e->rv_Rg * B * ns, e->stream));
+        JF_HIP(e, hipMemsetAsync(e->d_rv_fdl + (size_t)e->S * e->rv_Rg * B + s0 * e->rv_Rg, 0, sizeof(float2) * e->rv_Rg * ns, e->stream));
+        JF_HIP(e, hipMemsetAsync(e->d_rv_wet + s0 * e->rv_Wr, 0, sizeof(float) * e->rv_Wr * ns, e->stream));
+        JF_HIP(e, hipMemsetAsync(e->d_rv_prev[p] + s0 * B, 0, sizeof(float) * B * ns, e->stream));
+        JF_HIP(e, hipMemsetAsync(e->d_rv_count[p] + s0, 0, sizeof(int) * ns, e->stream));
         if (e->rv_P1 > 0) {  // the big partitions' delay line, the dry ring they read and what they have promised the next blocks
             const size_t B1 = (size_t)e->rv_B1;
-            JF_HIP(e, hipMemset(e->d_rv_fdl1 + s0 * e->rv_R1 * B1, 0, sizeof(float2) * e->rv_R1 * B1 * ns));
-            JF_HIP(e, hipMemset(e->d_rv_fdl1 + (size_t)e->S * e->rv_R1 * B1 + s0 * e->rv_R1, 0, sizeof(float2) * e->rv_R1 * ns));
-            JF_HIP(e, hipMemset(e->d_rv_dryring + s0 * e->rv_Rn * B1, 0, sizeof(float) * e->rv_Rn * B1 * ns));
-            JF_HIP(e, hipMemset(e->d_rv_fut + s0 * e->rv_Fn * B1, 0, sizeof(float) * e->rv_Fn * B1 * ns));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_fdl1 + s0 * e->rv_R1 * B1, 0, sizeof(float2) * e->rv_R1 * B1 * ns, e->stream));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_fdl1 + (size_t)e->S * e->rv_R1 * B1 + s0 * e->rv_R1, 0, sizeof(float2) * e->rv_R1 * ns, e->stream));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_dryring + s0 * e->rv_Rn * B1, 0, sizeof(float) * e->rv_Rn * B1 * ns, e->stream));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_fut + s0 * e->rv_Fn * B1, 0, sizeof(float) * e->rv_Fn * B1 * ns, e->stream));
         }
     }
     return JF_OK;
@@ -719,8 +728,8 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         for (int i = 0; i < 2; i++) {
             JF_HIP(e, hipMalloc(&e->d_state[i], sizeof(SrcState) * S));
             JF_HIP(e, hipMalloc(&e->d_hist[i], sizeof(float) * S * kN));
-            JF_HIP(e, hipMemset(e->d_state[i], 0, sizeof(SrcState) * S));
-            JF_HIP(e, hipMemset(e->d_hist[i], 0, sizeof(float) * S * kN));
+            JF_HIP(e, hipMemsetAsync(e->d_state[i], 0, sizeof(SrcState) * S, e->stream));
+            JF_HIP(e, hipMemsetAsync(e->d_hist[i], 0, sizeof(float) * S * kN, e->stream));
         }
         JF_HIP(e, hipMalloc(&e->d_desc, sizeof(ItemDesc) * S * K));
         JF_HIP(e, hipMalloc(&e->d_desc_ahead, sizeof(ItemDesc) * S * K));
@@ -734,14 +743,14 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             for (int r = 0; r < kNumElev; r++)
                 for (int a = 0; a < kPickAzi; a++) pick[(size_t)r * kPickAzi + a] = (short)host_pick_hrtf((float)elev[r], (float)a);
             JF_HIP(e, hipMalloc(&e->d_pick, sizeof(short) * pick.size()));
-            JF_HIP(e, hipMemcpy(e->d_pick, pick.data(), sizeof(short) * pick.size(), hipMemcpyHostToDevice));
+            JF_HIP(e, h2d(e, e->d_pick, pick.data(), sizeof(short) * pick.size()));
             e->rt = ring_table();
             e->rt.pick = e->d_pick;
         }
         JF_HIP(e, hipMalloc(&e->d_order, sizeof(int) * S));
         e->order.resize(S);
         for (size_t s = 0; s < S; s++) e->order[s] = (int)s;
-        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * S, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_order, e->order.data(), sizeof(int) * S));
         // host memory the kernels read and write in place, and whose words the host polls while a kernel runs: mapped AND
         // coherent (fine-grained) explicitly -- not left to the runtime's default or to HIP_HOST_COHERENT
         const unsigned kHostFlags = hipHostMallocMapped | hipHostMallocCoherent;
@@ -758,9 +767,9 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipHostGetDevicePointer((void **)&e->hd_err, e->h_err, 0));
         e->d_signal.assign(S, nullptr);
         JF_HIP(e, hipMalloc(&e->d_zero, sizeof(float) * kN));
-        JF_HIP(e, hipMemset(e->d_zero, 0, sizeof(float) * kN));
+        JF_HIP(e, hipMemsetAsync(e->d_zero, 0, sizeof(float) * kN, e->stream));
         e->h_sigs.assign(S, SrcSignal{e->d_zero, kN, 0});
-        JF_HIP(e, hipMemcpy(e->d_sigs, e->h_sigs.data(), sizeof(SrcSignal) * S, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_sigs, e->h_sigs.data(), sizeof(SrcSignal) * S));
         // SoundSource::SoundSource() defaults (SoundSource.cu:3-16)
         e->pos.assign(S, HostPos{0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.5f});
 
@@ -770,7 +779,7 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             const double a = 2.0 * 3.14159265358979323846264338327950288 * j / 1024.0;
             tw[j] = make_float2((float)cos(a), (float)sin(a));
         }
-        JF_HIP(e, hipMemcpy(e->d_tw, tw.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_tw, tw.data(), sizeof(float2) * 1024));
         // the same values re-laid per FFT pass (jf_device.h kTw*)
         std::vector<float2> pack(kTwPack);
         for (int lane = 0; lane < 64; lane++) {
@@ -784,13 +793,13 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         for (int r = 0; r < 8; r++)
             for (int k = 0; k < 8; k++) pack[kTwWB + 8 * r + k] = tw[(16 * r * k) & 1023];
         JF_HIP(e, hipMalloc(&e->d_twpack, sizeof(float2) * kTwPack));
-        JF_HIP(e, hipMemcpy(e->d_twpack, pack.data(), sizeof(float2) * kTwPack, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_twpack, pack.data(), sizeof(float2) * kTwPack));
 
         // HRTF spectra on the GPU (read_hrtf_signals + transform_hrtfs)
         float *d_hrir = nullptr;
         const size_t hb = sizeof(float) * kNumHrtf * 2 * (size_t)taps;
         JF_HIP(e, hipMalloc(&d_hrir, hb));
-        hipError_t s1 = hipMemcpy(d_hrir, hrir, hb, hipMemcpyHostToDevice);
+        hipError_t s1 = h2d(e, d_hrir, hrir, hb);
         hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_twpack, e->d_htab, e->stream) : s1;
         // ... and the weighted sums of every whole-degree position behind them (same stream: after the rows they read)
         if (s2 == hipSuccess && e->interp_built)
@@ -880,7 +889,7 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
             n_dev = reps * n;
         }
         JF_HIP(e, hipMalloc(&d_new, sizeof(float) * n_dev));
-        hipError_t st = hipMemcpy(d_new, src_host, sizeof(float) * n_dev, hipMemcpyHostToDevice);
+        hipError_t st = h2d(e, d_new, src_host, sizeof(float) * n_dev);
         if (st != hipSuccess) {
             (void)hipFree(d_new);
             JF_HIP(e, st);
@@ -889,12 +898,12 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     if (e->d_signal[src]) (void)hipFree(e->d_signal[src]);
     e->d_signal[src] = d_new;
     e->h_sigs[src] = n ? SrcSignal{d_new, (int)n_dev, 0} : SrcSignal{e->d_zero, kN, 0};
-    JF_HIP(e, hipMemcpy(e->d_sigs + src, &e->h_sigs[src], sizeof(SrcSignal), hipMemcpyHostToDevice));
+    JF_HIP(e, h2d(e, e->d_sigs + src, &e->h_sigs[src], sizeof(SrcSignal)));
     const int zero = 0;  // count = 0 (cudaPart.cu:198-199 run with a fresh source)
     if (e->rv_P > 0)  // the play position of the dry signal lives in the reverb stage
-        JF_HIP(e, hipMemcpy(e->d_rv_count[e->cur] + src, &zero, sizeof(int), hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_rv_count[e->cur] + src, &zero, sizeof(int)));
     else
-        JF_HIP(e, hipMemcpy(&e->d_state[e->cur][src].count, &zero, sizeof(int), hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, &e->d_state[e->cur][src].count, &zero, sizeof(int)));
     return JF_OK;
     });
 }
@@ -1196,14 +1205,14 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
         for (int i = 0; i < 2; i++) {
             JF_HIP(e, hipMalloc(&e->d_rv_prev[i], sizeof(float) * S * B));
             JF_HIP(e, hipMalloc(&e->d_rv_count[i], sizeof(int) * S));
-            JF_HIP(e, hipMemset(e->d_rv_prev[i], 0, sizeof(float) * S * B));
-            JF_HIP(e, hipMemset(e->d_rv_count[i], 0, sizeof(int) * S));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_prev[i], 0, sizeof(float) * S * B, e->stream));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_count[i], 0, sizeof(int) * S, e->stream));
         }
         std::vector<SrcSignal> wet(S);
         for (size_t s = 0; s < S; s++) wet[s] = SrcSignal{e->d_rv_wet + s * Wr, Wr, 0};
-        JF_HIP(e, hipMemcpy(e->d_sigs_wet, wet.data(), sizeof(SrcSignal) * S, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_sigs_wet, wet.data(), sizeof(SrcSignal) * S));
         JF_HIP(e, hipMalloc(&d_ir, sizeof(float) * n_ir));
-        JF_HIP(e, hipMemcpy(d_ir, ir, sizeof(float) * n_ir, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, d_ir, ir, sizeof(float) * n_ir));
         // 1/B: normalisation of the B-point inverse used for the 2B-point real transform
         JF_HIP(e, launch_reverb_ir(d_ir, (int)n_ir, P, B, gain / (float)B, e->d_tw, e->d_rv_hspec, e->stream));
         if (P1 > 0) {
@@ -1214,10 +1223,10 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
                 tw1[j] = make_float2((float)cos(a), (float)sin(a));
             }
             JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * 2 * B1));
-            JF_HIP(e, hipMemcpy(e->d_rv_tw1, tw1.data(), sizeof(float2) * 2 * B1, hipMemcpyHostToDevice));
+            JF_HIP(e, h2d(e, e->d_rv_tw1, tw1.data(), sizeof(float2) * 2 * B1));
             const size_t NP = (size_t)P1 + 17;  // H'_0 .. H'_P1 and 16 partitions of zeros
             JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * (NP * B1 + NP)));
-            JF_HIP(e, hipMemset(e->d_rv_hspec1, 0, sizeof(float2) * (NP * B1 + NP)));
+            JF_HIP(e, hipMemsetAsync(e->d_rv_hspec1, 0, sizeof(float2) * (NP * B1 + NP), e->stream));
             JF_HIP(e, hipMalloc(&e->d_rv_fdl1, sizeof(float2) * (S * R1 * B1 + S * R1)));
             JF_HIP(e, hipMalloc(&e->d_rv_ybig, sizeof(float2) * S * steps_max * B1));
             JF_HIP(e, hipMalloc(&e->d_rv_dryring, sizeof(float) * S * Rn * B1));
@@ -1296,7 +1305,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
         JF_HIP(e, hipMalloc(&e->d_traj, bytes));
     }
     e->traj_blocks = total_blocks;
-    JF_HIP(e, hipMemcpy(e->d_traj, positions, bytes, hipMemcpyHostToDevice));
+    JF_HIP(e, h2d(e, e->d_traj, positions, bytes));
     // how many items of every block move (their (ele, azi) differ from the block before; block 0 counts as staying):
     // what decides whether a run reads pre-interpolated rows (jf_engine::interp_use)
     e->traj_moved.assign((size_t)total_blocks + 1, 0u);
@@ -1321,7 +1330,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
         }
         std::stable_sort(key.begin(), key.end());
         for (int s = 0; s < e->S; s++) e->order[s] = key[s].second;
-        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * e->S, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_order, e->order.data(), sizeof(int) * e->S));
         e->sorted_order = want_sorted;
     }
     return JF_OK;
@@ -1523,7 +1532,7 @@ int jf_debug_set_source_group(jf_engine *e, int group) {
     if (group > 0 && e->sorted_order) {  // a pinned group size means consecutive sources
         JF_HIP(e, hipStreamSynchronize(e->stream));
         for (int s = 0; s < e->S; s++) e->order[s] = s;
-        JF_HIP(e, hipMemcpy(e->d_order, e->order.data(), sizeof(int) * e->S, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, e->d_order, e->order.data(), sizeof(int) * e->S));
         e->sorted_order = false;
     }
     return JF_OK;
@@ -1658,8 +1667,8 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
         JF_HIP(e, hipMalloc(&d_w, sizeof(float) * 4 * n));
         JF_HIP(e, hipMalloc(&d_r, sizeof(int) * 4 * n));
         JF_HIP(e, hipMalloc(&d_n, sizeof(int) * n));
-        JF_HIP(e, hipMemcpy(d_e, ele, sizeof(float) * n, hipMemcpyHostToDevice));
-        JF_HIP(e, hipMemcpy(d_a, azi, sizeof(float) * n, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, d_e, ele, sizeof(float) * n));
+        JF_HIP(e, h2d(e, d_a, azi, sizeof(float) * n));
         JF_HIP(e, launch_interp_debug(e->rt, d_e, d_a, d_r, d_w, d_n, n,
                                       (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -1687,7 +1696,7 @@ int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spect
     auto body = [&]() -> int {
         JF_HIP(e, hipMalloc(&d_w, sizeof(float) * (size_t)n * kN));
         JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * kNc));
-        JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, d_w, windows, sizeof(float) * (size_t)n * kN));
         JF_HIP(e, launch_rfft_debug(d_w, n, e->d_twpack, d_s, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(spectra, d_s, sizeof(float2) * (size_t)n * kNc, hipMemcpyDeviceToHost));
@@ -1784,11 +1793,11 @@ int jf_debug_stage_taps(jf_engine *e, int n, const float *positions, const float
     auto body = [&]() -> int {
         JF_HIP(e, hipMalloc(&d_p, sizeof(float) * 5 * (size_t)n));
         JF_HIP(e, hipMalloc(&d_d, sizeof(float2) * (size_t)n * kNc));
-        JF_HIP(e, hipMemcpy(d_p, positions, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice));
+        JF_HIP(e, h2d(e, d_p, positions, sizeof(float) * 5 * (size_t)n));
         if (spectra) {
             JF_HIP(e, hipMalloc(&d_w, sizeof(float) * (size_t)n * kN));
             JF_HIP(e, hipMalloc(&d_s, sizeof(float2) * (size_t)n * 2 * kNc));
-            JF_HIP(e, hipMemcpy(d_w, windows, sizeof(float) * (size_t)n * kN, hipMemcpyHostToDevice));
+            JF_HIP(e, h2d(e, d_w, windows, sizeof(float) * (size_t)n * kN));
         }
         JF_HIP(e, launch_stage_debug(e->rt, kernel_mode(e), d_p, d_w, n, e->d_htab, e->d_twpack, d_d, d_s,
                                      e->stream));

@@ -195,7 +195,7 @@ def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S, re
             paused = not paused
             eng.set_pause(paused)
         got = eng.callback()
-        assert np.abs(got - prev).max() <= tol * max(1.0, float(np.abs(prev).max())), (seed, step, int(op))
+        assert np.abs(got - prev).max() <= tol * max(1.0, float(np.abs(prev).max())), (seed, step, int(op), float(np.abs(got - prev).max()), float(np.abs(prev).max()), float(np.abs(got).max()), paused)
         prev = np.zeros(2 * B, np.float32) if paused else ora.process_block()
         peak = max(peak, float(np.abs(prev).max()))
     rc, last = eng.collect_block()

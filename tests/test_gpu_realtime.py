@@ -261,3 +261,46 @@ def test_per_block_calls_continue_from_where_a_batch_call_left_the_sources(jf, h
     e.close()
     o.close()
     assert np.abs(a - b).max() <= TOL32 * S
+
+
+def test_a_reset_or_a_new_signal_right_before_a_block(jf, hrir, castanets):
+    """jf_source_reset / jf_source_set_signal and, at once, the next block -- 600 times, through the callback (a block in
+    flight while the state is rewritten) and through jf_process_block.  The engine's stream is a non-blocking stream: its
+    memsets and small copies must go through THAT stream, or the block's kernel may run before them (it did, one session in
+    twelve, when they went through the null stream: found by tests/test_gpu_random_sessions.py run over many seeds)."""
+    S, B = 5, 256
+    rng = np.random.default_rng(5)
+    for use_callback in (True, False):
+        e = jf.Engine(B, 512, S, hrir=hrir)
+        o = oracle_lib.Engine(B, 512, S, hrir)
+        for s in range(S):
+            sig = 0.4 * castanets[1500 * s:1500 * s + 5000]
+            e.set_signal(s, sig)
+            o.set_signal(s, sig)
+            e.set_spherical(s, 10 * s, 60 * s, 0.7)
+            o.set_spherical(s, 10 * s, 60 * s, 0.7)
+        prev = np.zeros(2 * B, np.float32)
+        worst = 0.0
+        for k in range(300):
+            s = int(rng.integers(0, S))
+            if k % 3 == 0:
+                e.reset(s)
+                o.reset(s)
+            elif k % 3 == 1:
+                a = int(rng.integers(0, 20000))
+                sig = 0.4 * castanets[a:a + int(rng.integers(50, 4000))]
+                e.set_signal(s, sig)
+                o.set_signal(s, sig)
+            if use_callback:
+                got = e.callback()
+                worst = max(worst, float(np.abs(got - prev).max()))
+                prev = o.process_block()
+            else:
+                worst = max(worst, float(np.abs(e.process_block() - o.process_block()).max()))
+        if use_callback:
+            rc, last = e.collect_block()
+            assert rc == 0
+            worst = max(worst, float(np.abs(last - prev).max()))
+        e.close()
+        o.close()
+        assert worst <= TOL32 * S, (use_callback, worst)
