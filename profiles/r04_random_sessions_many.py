@@ -17,7 +17,8 @@ for seed in range(n0, n1):
     reverb = 0 if B == 192 or rng.random() < 0.5 else int(rng.choice([700, 16 * B * 3 + 3, (16 if B <= 128 else 8) * B * 5 + 100]))
     for name, fn, args in (("block+batch", T.test_random_session_of_block_and_batch_calls, (seed, B, S, reverb)),
                            ("callback", T.test_random_session_through_the_callback, (seed, B, S, reverb)),
-                           ("trajectory", T.test_random_session_of_runs_over_an_uploaded_trajectory, (seed, B, 4 * max(1, S // 4), int(rng.choice([0, 1, 2, 4]))))):
+                           ("trajectory", T.test_random_session_of_runs_over_an_uploaded_trajectory, (seed, B, 4 * max(1, S // 4), int(rng.choice([0, 1, 2, 4])))),
+                           ("group", T.test_random_session_through_the_group_of_shards, (seed, B, max(S, 4), int(rng.choice([2, 3, 4])), reverb))):
         try:
             fn(jf, hrir, castanets, *args)
         except AssertionError as ex:
