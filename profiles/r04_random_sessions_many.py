@@ -13,7 +13,7 @@ fails = 0
 t0 = time.time()
 for seed in range(n0, n1):
     B = int(rng.choice([64, 128, 192, 256]))
-    S = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 33]))
+    S = int(rng.choice([64, 100, 257, 520] if os.environ.get("JF_SESS_BIG") else [1, 2, 3, 5, 8, 9, 16, 17, 33]))
     reverb = 0 if B == 192 or rng.random() < 0.5 else int(rng.choice([700, 16 * B * 3 + 3, (16 if B <= 128 else 8) * B * 5 + 100]))
     for name, fn, args in (("block+batch", T.test_random_session_of_block_and_batch_calls, (seed, B, S, reverb)),
                            ("callback", T.test_random_session_through_the_callback, (seed, B, S, reverb)),
