@@ -1057,6 +1057,9 @@ JF_DEV void ear_sums_to_z(const c2 (&sL)[4], const c2 (&sR)[4], bool special, c2
 #ifndef JF_PAIR_D_EARLY
 #define JF_PAIR_D_EARLY 0
 #endif
+#ifndef JF_PAIR_ACK_IN_VGPR
+#define JF_PAIR_ACK_IN_VGPR 1
+#endif
 #ifndef JF_PAIR_OVERLAP
 #define JF_PAIR_OVERLAP 0  // 1: a wave's window loads fly while it filters the partner's previous source -- 16 more live
                            // registers, which spill (72 B) and cost more than the overlap gains: 0.195 vs 0.182 ms
@@ -1122,6 +1125,8 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         int *f = reinterpret_cast<int *>(s_pair + tid * kPairLds + 2 * kPairWave);
         f[0] = f[1] = f[2] = f[3] = 0;
     }
+    // (the barrier moved behind the first unit's descriptor scan, so that the scan's scalar loads overlap with the staging above:
+    // 0.7 % SLOWER -- profiles/r04/pair_kernel_residue.md)
     __syncthreads();
 
     const int lane = tid & 63;
@@ -1147,7 +1152,16 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
     const float2 *pbuf = base + (half ^ 1) * kPairWave, *pmail = pbuf + kPairWork;  // the partner's
     const unsigned flags = (unsigned)(size_t)(base + 2 * kPairWave);  // LDS byte address of pub[2], ack[2]
     const unsigned my_pub = flags + 4 * half, his_pub = flags + 4 * (half ^ 1);
+#if JF_PAIR_ACK_IN_VGPR
+    // my_ack is needed once per source (consumed()), as the ADDRESS operand of a ds_write -- a vector register anyway: held in a
+    // scalar register it is one of the scalars the compiler keeps in lanes of a vector register (v_readlane + s_nop + v_mov
+    // per use: 20 of the kernel's 63 v_readlane; 808.0 -> 806.3 vector instructions per source-block, -0.1 % time)
+    unsigned my_ack = flags + 8 + 4 * half;
+    asm volatile("" : "+v"(my_ack));
+    const unsigned his_ack = flags + 8 + 4 * (half ^ 1);
+#else
     const unsigned my_ack = flags + 8 + 4 * half, his_ack = flags + 8 + 4 * (half ^ 1);
+#endif
     int npub = 0, nseen = 0;  // hand-offs I published / the partner's I consumed (wave-uniform)
     [[maybe_unused]] int steps_done = 0;  // sources I have run the front half of
     bool dead = false;        // a wait timed out (pair_wait)
