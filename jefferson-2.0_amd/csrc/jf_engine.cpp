@@ -42,6 +42,8 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
+int big_twiddle_pack_len(int B1);
+int big_twiddle_pack_index(int B1, int k);
 hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st);
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,
                                 float2 *d_hspec1, hipStream_t st);
@@ -1222,8 +1224,12 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
                 const double a = 3.14159265358979323846264338327950288 * j / (double)B1;
                 tw1[j] = make_float2((float)cos(a), (float)sin(a));
             }
-            JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * 2 * B1));
-            JF_HIP(e, h2d(e, e->d_rv_tw1, tw1.data(), sizeof(float2) * 2 * B1));
+            // ... followed by the transforms' own selection of them, laid out the way their lanes read them (jf_reverb.hip:
+            // BigTwiddles::load)
+            const int n_pack = big_twiddle_pack_len(B1);
+            for (int k = 0; k < n_pack; k++) tw1.push_back(tw1[(size_t)big_twiddle_pack_index(B1, k)]);
+            JF_HIP(e, hipMalloc(&e->d_rv_tw1, sizeof(float2) * tw1.size()));
+            JF_HIP(e, h2d(e, e->d_rv_tw1, tw1.data(), sizeof(float2) * tw1.size()));
             const size_t NP = (size_t)P1 + 17;  // H'_0 .. H'_P1 and 16 partitions of zeros
             JF_HIP(e, hipMalloc(&e->d_rv_hspec1, sizeof(float2) * (NP * B1 + NP)));
             JF_HIP(e, hipMemsetAsync(e->d_rv_hspec1, 0, sizeof(float2) * (NP * B1 + NP), e->stream));

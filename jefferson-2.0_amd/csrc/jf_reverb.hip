@@ -644,21 +644,24 @@ struct BigTwiddles {
     static_assert(NPT / 8 <= NT && NL >= 1, "one radix-8 butterfly per thread at most");
     float2 w8[2][7];        // passes with Ns = 8 and 64: exp(2 pi i r k / (8 Ns)), r = 1 .. 7
     float2 wl[NL][RL - 1];  // last pass (Ns = 512)
+    // The values are entries of the circle T2, but a wave that fetches them there gathers 64 cache lines per load (strides of
+    // 8 r .. 64 r entries between neighbouring lanes) -- 17 to 21 such loads per thread were a third of a transform kernel's
+    // time.  The engine lays the same values out per pass and r, neighbouring lanes side by side, BEHIND the circle
+    // (big_twiddle_pack_*, jf_engine.cpp): a load touches 1 to 8 lines.  Same bits, same results: forward 41.4 -> 35.2 us,
+    // inverse 43.5 -> 38.7 us per launch at config 5's batch shape (rocprofv3, 320 launches, twice).
     JF_DEV void load(const float2 *__restrict__ T2, int tid) {
+        const float2 *__restrict__ pk = T2 + 2 * NPT;
         const int j = tid < NPT / 8 ? tid : 0;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int Ns = p ? 64 : 8;
-            const int t1 = (j & (Ns - 1)) * (2 * NPT / (Ns * 8));
 #pragma unroll
-            for (int r = 1; r < 8; r++) w8[p][r - 1] = T2[r * t1];
+            for (int r = 1; r < 8; r++) w8[p][r - 1] = pk[(p ? 56 : 0) + (r - 1) * Ns + (j & (Ns - 1))];
         }
 #pragma unroll
-        for (int u = 0; u < NL; u++) {
-            const int t1 = ((tid + u * NT) & 511) * (2 * NPT / (512 * RL));
+        for (int u = 0; u < NL; u++)
 #pragma unroll
-            for (int r = 1; r < RL; r++) wl[u][r - 1] = T2[r * t1];
-        }
+            for (int r = 1; r < RL; r++) wl[u][r - 1] = pk[504 + (r - 1) * 512 + ((tid + u * NT) & 511)];
     }
 };
 
@@ -1203,6 +1206,15 @@ hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const Rever
     if (transforms && transforms->n_tr > 0) launch_big_transforms(*transforms, st);
     if (products && products->n_prod > 0) launch_big_products(*products, st);
     return hipGetLastError();
+}
+
+// The twiddle pack of BigTwiddles<B1, 256> behind the circle T2[0 .. 2 B1): pack[k] = T2[big_twiddle_pack_index(B1, k)].
+int big_twiddle_pack_len(int B1) { return 504 + (B1 / 512 - 1) * 512; }
+int big_twiddle_pack_index(int B1, int k) {
+    if (k < 56) return (k / 8 + 1) * (k % 8) * (2 * B1 / 64);             // second pass: exp(2 pi i r k / 64), r = 1 .. 7, k < 8
+    if (k < 504) return ((k - 56) / 64 + 1) * ((k - 56) % 64) * (2 * B1 / 512);  // third: exp(2 pi i r k / 512), k < 64
+    const int RL = B1 / 512;
+    return ((k - 504) / 512 + 1) * ((k - 504) % 512) * (2 * B1 / (512 * RL));   // last: exp(2 pi i r k / (512 RL)), k < 512
 }
 
 // form_used: 1, 2, 3 = form of stage B (after reverb_fft_kernel), 4 = form 1 with stage A fused in (no reverb_fft_kernel),
