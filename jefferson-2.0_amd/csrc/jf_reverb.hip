@@ -989,9 +989,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
             // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
             const int c0 = P.st_in[s].count;
             float *wet = P.wet + (size_t)s * P.Wr;
+            const int lgB = 31 - __builtin_clz((unsigned)P.B);  // B is 64, 128 or 256
             for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
                 const int n = 2 * m - B1;                   // sample inside the big block
-                const int kb = n / P.B;                      // (once per pair)
+                const int kb = n >> lgB;                     // n / B (once per pair)
                 const int k = P.wet_k0 + P.M * i + kb;       // block of the call
                 int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
                 w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
