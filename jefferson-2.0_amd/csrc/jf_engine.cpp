@@ -1183,6 +1183,8 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     const int B = e->B;
     if (B != 64 && B != 128 && B != 256)
         return fail(e, JF_ERR_ARG, "reverb needs frames_per_buffer of 64, 128 or 256 (FFT of 2 blocks)");
+    if ((long long)e->maxK * B >= (1LL << 30))  // the stage's play positions are 32-bit sums of a position and K B samples
+        return fail(e, JF_ERR_ARG, "max_batch_blocks too large for the reverb stage");
     const size_t S = (size_t)e->S;
     const int P_total = (int)((n_ir + B - 1) / B);
     // Non-uniform partitioning for a response of at least three big partitions (unless a uniform form is pinned, or

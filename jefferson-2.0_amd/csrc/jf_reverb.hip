@@ -226,8 +226,10 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
     const SrcSignal sg = P.dry[s];
     const int L = sg.length;  // >= 1024 (tiled / zero buffer)
     const int dc0 = P.dry_count_in[s];
-    const int cur0 = (int)(((long long)dc0 + (long long)k * B) % L);
-    const int prv0 = (int)(((long long)dc0 + (long long)(k > 0 ? k - 1 : 0) * B) % L);
+    // (dc0 < L < 2^31 and K B < 2^31: the sums fit 32 unsigned bits -- a 32-bit remainder is a fifth of the 64-bit one's
+    // instructions, and this is the head of the transformer's chain in one-block calls)
+    const int cur0 = (int)(((unsigned)dc0 + (unsigned)(k * B)) % (unsigned)L);
+    const int prv0 = (int)(((unsigned)dc0 + (unsigned)((k > 0 ? k - 1 : 0) * B)) % (unsigned)L);
     const float *prev_state = P.prev_in + (size_t)s * B;
     if (k >= P.copy_lo && k < P.copy_hi) {
         // a block whose output the big partitions form directly (ReverbBigParams: FULL) and whose spectrum nobody will read:
@@ -277,7 +279,7 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
             idx = idx >= L ? idx - L : idx;
             po[n] = sg.ptr[idx];
         }
-        if (lane == 0) P.dry_count_out[s] = (int)(((long long)dc0 + (long long)P.K * B) % L);
+        if (lane == 0) P.dry_count_out[s] = (int)(((unsigned)dc0 + (unsigned)(P.K * B)) % (unsigned)L);
     }
     JF_RV_SYNC();
     const float2 *Z = cfft_small<B, -1>(a, b, tw, lane);
@@ -374,7 +376,7 @@ JF_DEV void mac_finish(const float2 *red, int stride, float2 *fftbuf, const Reve
     // overlap-save: time samples B..2B-1 = z[m], m >= B/2 (even, odd interleaved)
     const int c0 = P.st_in[s].count;  // where the spatialiser will read the first new sample
     float *wet = P.wet + (size_t)s * P.Wr;
-    const int w0 = (int)(((long long)c0 + (long long)k * B) % P.Wr);
+    const int w0 = (int)(((unsigned)c0 + (unsigned)(k * B)) % (unsigned)P.Wr);
     // non-uniform partitioning: + what the partitions behind the head contribute to this block (reverb_big_*)
     const float *fut = P.fut != nullptr ? P.fut + (size_t)s * P.F + (size_t)((P.fut_pos0 + k * B) % P.F) : nullptr;
     for (int m = B / 2 + lane; m < B; m += 64) {
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
         // signal index of the first sample at or behind the call's start (one division per item, none per sample: the
         // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
         const int first_in = rel0 < 0 ? 0 : rel0;
-        const unsigned start = (unsigned)(((long long)dc0 + first_in) % L);
+        const unsigned start = ((unsigned)dc0 + (unsigned)first_in) % (unsigned)L;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
