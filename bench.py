@@ -137,7 +137,7 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
     # reverb stage every source's signal carries the float32 sum over P partitions on both sides as well: the tests'
     # per-source bound is (2e-7 + 1e-7 sqrt(P)) max(1, |y|); the S sources' errors add like noise
     if reverb is None:
-        bound = 3e-6 * max(1.0, peak) * max(1.0, S / 1024.0)
+        bound = 3e-6 * max(1.0, peak) * max(1.0, float(np.sqrt(S / 1024.0)))
         tol_src = TOL32
     else:
         # (measured on MI355X at 690 partitions: 8e-8 per source, 4e-7 per group of 16, 9e-7 on the mix of 256)
@@ -154,8 +154,10 @@ def cpu_baseline_and_check(jf, wl, hrir, src_ids, pos, n_pos, last_first_block, 
             worst = max(worst, float(np.abs(blk - want).max()))
         check["max_abs_err_group_blocks"] = worst
         check["groups_checked"] = sorted(gpu_groups)
-        check["bound_group_blocks"] = tol_src * G
-        ok = ok and worst <= tol_src * G
+        # each source is held to tol_src per sample (tests/test_gpu_pair_per_source.py holds the pair kernel itself to it, one
+        # live source per unit); the G sources' errors are independent and add like sqrt(G)
+        check["bound_group_blocks"] = tol_src * float(np.sqrt(G))
+        ok = ok and worst <= check["bound_group_blocks"]
     return base, bool(ok), check
 
 
@@ -656,7 +658,11 @@ def main():
                                       "while step i reduces; no collective on the data path of the kernels",
                            # the collective's own duration against a step: what it WOULD cost if it were not overlapped
                            "ms_per_collective": comm_ms,
-                           "fraction": (comm_ms / (dt / K * 1e3)) if comm_ms is not None else None,
+                           # only an RCCL collective has a share worth quoting: a rehearsal backend (gloo through the host)
+                           # exercises the measurement, its duration is in ms_per_collective, and it says nothing about xGMI
+                           "fraction": (comm_ms / (dt / K * 1e3)) if (comm_ms is not None and backend == "nccl") else None,
+                           "fraction_null_because": None if backend == "nccl" else
+                           f"the backend is {backend}, not RCCL: not a figure of the multi-GPU path",
                            "fraction_is": "duration of one collective / ms_per_step; the collective runs beside the next "
                                           "step's kernels, so this is an upper bound of its share of the step, not time added "
                                           "to it",

@@ -61,13 +61,15 @@ typedef struct jf_engine jf_engine;
 #define JF_FLAG_CORRECTED_INTERPOLATION 1u
 /*
  * The setters round elevation and azimuth to whole degrees (SoundSource.cu:33-34,42-43), so every position they latch is
- * one of 131 x 360.  By default an engine therefore also holds, behind the 710 measured rows, the weighted filter
- * sum_t w_t H[row_t] of each of those positions (386 MB of HBM, built once at creation by the same operations in the same
- * order as the per-block weighting: results are bit-identical) and batch calls read ONE row per filter set instead of up
- * to four rows and their weights (what GPUSoundSource.cu:118-292 recomputes for every block).  Positions that are not
- * whole degrees inside -40..90 x 0..359 keep the per-block weighting, and so do runs in which most sources move every
- * block (jf_debug_set_interp_table).  JF_FLAG_NO_INTERP_TABLE: do not build it (the environment variable
- * JF_INTERP_TABLE=0 does the same for every engine of a process).
+ * one of 131 x 360.  By default an engine may therefore also hold, behind the 710 measured rows, the weighted filter
+ * sum_t w_t H[row_t] of each of those positions (386 MB of HBM, built by the same operations in the same order as the
+ * per-block weighting: results are bit-identical) and batch calls read ONE row per filter set instead of up to four rows
+ * and their weights (what GPUSoundSource.cu:118-292 recomputes for every block).  The rows are built LAZILY -- by the first
+ * batch run whose policy takes them (jf_debug_set_interp_table), ~0.1 ms of kernel time and one allocation on that run --
+ * so an engine whose sources move every block, and each of several engines of a job on one device, never holds them.
+ * Positions that are not whole degrees inside -40..90 x 0..359 keep the per-block weighting, and so do runs in which most
+ * sources move every block.  JF_FLAG_NO_INTERP_TABLE: never build them (the environment variable JF_INTERP_TABLE=0 does
+ * the same for every engine of a process).
  */
 #define JF_FLAG_NO_INTERP_TABLE 2u
 
@@ -208,7 +210,7 @@ int jf_pa_callback(const void *input, void *output, unsigned long frames_per_buf
  *   convolution with the same nearest HRIR, CPUSoundSource.cpp:66-112) compute the same samples:
  *   B + taps - 1 <= PAD_LEN makes the circular product a linear convolution (tested).
  */
-enum { JF_MODE_FD_COMPLEX = 0, JF_MODE_FD_BASIC = 1 };
+enum { JF_MODE_FD_COMPLEX = 0, JF_MODE_FD_BASIC = 1, JF_MODE_TD = JF_MODE_FD_BASIC /* CPU_TD / GPU_TD: same samples */ };
 int jf_set_mode(jf_engine *e, int mode);
 
 /* Data::pauseStatus (DataTag.cuh:15, Audio.cu:101): while paused, blocks are silence and no input is consumed.
@@ -336,11 +338,14 @@ int jf_debug_read_stamps(jf_engine *e, unsigned long long *out, int n);
 /* Synchronous device-to-host copy of an engine-owned buffer (jf_batch_mix_device, ...). */
 int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, size_t bytes);
 
-/* Partitioning of the convolution reverb, in effect from the next jf_reverb_set_ir: 0 = by the response's length (default:
- * non-uniform from 48 partitions of frames_per_buffer on, unless jf_debug_set_reverb_form pins a uniform form), 1 = uniform
- * (one partition per block: P multiply-accumulates per bin and block), 2 = non-uniform (a head of 32 partitions of one
- * block + partitions of 16 blocks for the rest: P / 16 + 30; Gardner's zero-latency scheme with two sizes, the large size
- * starting two of its partitions into the response, so that its work for a big block can be done a whole big block early).  The reference's
+/* Partitioning of the convolution reverb, in effect from the next jf_reverb_set_ir.  With M = blocks per big partition (16 for
+ * frames_per_buffer 64 and 128, 8 for 256: big partitions of M * frames_per_buffer = 1024 or 2048 taps) and P = partitions
+ * of frames_per_buffer the response has: 0 = by the response's length (default: non-uniform from P >= 3 M on, unless
+ * jf_debug_set_reverb_form pins a uniform form), 1 = uniform (one partition per block: P multiply-accumulates per bin
+ * and block), 2 = non-uniform (a head of 2 M partitions of one block + partitions of M blocks for the rest: about
+ * P / M + 2 M - 2 per block; Gardner's zero-latency scheme with two sizes, the large size starting two of its partitions
+ * into the response, so that its work for a big block can be done a whole big block early; forced on a response shorter than
+ * 3 M blocks it degenerates gracefully -- no, one or two big partitions behind the zero-padded head: tested).  The reference's
  * own form is one product over the whole signal (cudaPart.cu:87-153).  Same results to float32 rounding. */
 int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
 /* One-block calls with the non-uniformly partitioned reverb (the real-time shape) run the big partitions' kernels on a second
@@ -366,9 +371,12 @@ int jf_debug_reverb_partitions(const jf_engine *e, int *head, int *big, int *big
  * move -- a source that stays reads its row out of the caches (12-18 % faster), one that moves streams 8 KB per block from
  * HBM, and a run in which every source moves every block is 2-5 % slower with the rows than with the weighting of the
  * cached measured rows; measured crossover: a third of the items moving --; calls without a trajectory take them.
- * on != 0 for an engine that did not build them: JF_ERR_STATE.  Results are bit-identical whatever the choice
- * (JF_INTERP_TABLE=0/1/2 in the environment sets it for every engine of a process). */
+ * on != 0 for an engine that may not build them (JF_FLAG_NO_INTERP_TABLE): JF_ERR_STATE.  on == 1 builds them now
+ * (JF_ERR_NOMEM without room for them), on == 2 leaves that to the first run that takes them.  Results are bit-identical
+ * whatever the choice (JF_INTERP_TABLE=0/1/2 in the environment sets it for every engine of a process). */
 int jf_debug_set_interp_table(jf_engine *e, int on);
+/* 1 once the engine holds the pre-interpolated rows (built on first use). */
+int jf_debug_interp_table_built(const jf_engine *e);
 /* 1 if the last batch run's descriptors could name pre-interpolated rows (the kernel instantiation that reads them ran). */
 int jf_debug_last_run_used_rows(const jf_engine *e);
 /* The setting above (0, 1 or 2); 0 for an engine without the rows. */

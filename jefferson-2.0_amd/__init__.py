@@ -96,6 +96,7 @@ _SIGS = {
     "jf_debug_read_table": (C.c_int, [C.c_void_p, _f]),
     "jf_debug_set_interp_table": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_interp_table": (C.c_int, [C.c_void_p]),
+    "jf_debug_interp_table_built": (C.c_int, [C.c_void_p]),
     "jf_debug_set_reverb_partitioning": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_async": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_sources_set_latched": (C.c_int, [C.c_void_p, _f]),
@@ -445,6 +446,10 @@ class Engine:
     def interp_table(self):
         """0 = off / not built, 1 = always, 2 = decided per run"""
         return lib().jf_debug_interp_table(self.h)
+
+    def interp_table_built(self):
+        """the engine holds the 47 160 pre-interpolated rows (built by the first run that takes them)"""
+        return bool(lib().jf_debug_interp_table_built(self.h))
 
     def count_desc_flags(self, n_items, mask):
         n = lib().jf_debug_count_desc_flags(self.h, int(n_items), int(mask))

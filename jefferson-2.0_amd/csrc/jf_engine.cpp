@@ -75,7 +75,11 @@ struct jf_engine {
     std::string err;
 
     float4 *d_htab = nullptr;
-    bool interp_built = false;  // d_htab also holds the kInterpRows pre-interpolated rows (jf_device.h)
+    // The kInterpRows pre-interpolated rows (jf_device.h; 386 MB behind the 710 measured rows) are built LAZILY: by the first
+    // run whose policy takes them (run_blocks), or when jf_debug_set_interp_table(e, 1) / a read of those rows asks -- never for
+    // an engine that only ever runs sources that move every block, and not for the eight shards of a job on one device.
+    bool interp_avail = false;  // the engine may have them (no JF_FLAG_NO_INTERP_TABLE, no JF_INTERP_TABLE=0, no failed allocation)
+    bool interp_built = false;  // d_htab holds them
     // ... and which batch calls use them (jf_debug_set_interp_table): 0 none, 1 all, 2 (default) decided per run.  A source
     // that stays where it is reads its one row out of the caches block after block (12-18 % faster than weighting four
     // measured rows); a source that moves streams a new 8 KB row from HBM, and when every source moves every block the
@@ -126,7 +130,7 @@ struct jf_engine {
     // block (Audio.cu:101,104)
     std::atomic<int> mode{0};  // 0 = FD_COMPLEX, 1 = FD_BASIC
     std::atomic<int> paused{0};
-    int resident_wgs[2] = {0, 0};  // persistent-grid size of the per-source / the pair kernel on this device
+    int resident_wgs[3] = {0, 0, 0};  // persistent-grid size of the per-source / the pair / the pair-with-rows kernel on this device
     int grid_limit = 0;            // > 0: tests shrink the grid so that waves loop over several units
     float last_peak = 0.0f;        // max |sample| of the last block handed out (Audio.cu:111-113 clip alert)
 
@@ -188,6 +192,8 @@ struct jf_engine {
     // what the last stage wants run on the side stream once the block's spatialiser has been launched (submit_side)
     bool side_tr = false;
     ReverbBigParams side_p[2];   // transforms, products
+    long long side_fut_m = 0;    // ... and what that work will have formed: committed to rv_fut_m / rv_side_urgent only once it
+    bool side_urgent = false;    //     has been launched (submit_side)
     int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
                                  // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md)
 };
@@ -261,8 +267,15 @@ EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
 }
 
 // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring, for the K blocks of this call (state parity p)
+static int submit_side(jf_engine *e);
 static int run_reverb_stage(jf_engine *e, int p, int K) {
     if (e->rv_P <= 0) return JF_OK;
+    if (e->side_tr) {
+        // the last stage's work for the side stream was never submitted (a launch between that stage and submit_side failed
+        // and the caller went on): it goes first -- the transform it holds is of samples the dry ring still has
+        const int rc = submit_side(e);
+        if (rc) return rc;
+    }
     EventPair *er = nullptr;
     if (e->profiling >= 2 && e->timed_now) {
         er = next_events(e, e->ev_reverb);
@@ -306,8 +319,9 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         e->rv_side_busy = e->rv_side_urgent = false;
     }
     ReverbBigParams &s_tr = e->side_p[0], &s_prod = e->side_p[1];
-    e->side_tr = false;
     e->last_side.clear();
+    const long long fut_m_before = e->rv_fut_m;
+    bool side_wanted = false;
     if (plan.big) {
         // Absolute block indices j0 .. j1 - 1; big block m = blocks 16 m .. 16 m + 15.
         const long long j0 = e->rv_blocks;
@@ -396,17 +410,24 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
             s_prod.n_prod = both ? 2 : 1;
             s_prod.ybig = e->d_rv_yacc;
             s_prod.mac_wgs = both ? 0 : e->rv_side_wgs;
-            e->rv_side_urgent = both;
-            if (e->rv_fut_m < mb + 2) e->rv_fut_m = mb + 2;
-            e->side_tr = true;
+            e->side_urgent = both;
+            e->side_fut_m = mb + 2;
+            side_wanted = true;
             e->last_side = "reverb_big_fft_kernel<" + b1 + ",1>@side;reverb_big_mac_kernel<" + b1 + ",1>@side;reverb_big_ifft_kernel<" +
                            b1 + ",1>@side;";
         }
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
-    JF_HIP(e, launch_reverb(R, &plan, e->stream, &e->last_rv_form));
+    {
+        const hipError_t q = launch_reverb(R, &plan, e->stream, &e->last_rv_form);
+        if (q != hipSuccess) {
+            e->rv_fut_m = fut_m_before;  // nothing of this call's schedule has been formed
+            JF_HIP(e, q);
+        }
+    }
     e->last_plan = plan;
+    e->side_tr = side_wanted;
 
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
@@ -418,14 +439,44 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
 // engine's stream: the side stream waits for them -- it then works beside what FOLLOWS the block (in real time: nothing; in a
 // run of calls back to back: the next blocks, which find room because its long kernel is launched narrow) -- and the block's
 // own kernels are not held up by it.
-static int submit_side(jf_engine *e) {
+int submit_side(jf_engine *e) {
     if (!e->side_tr) return JF_OK;
     JF_HIP(e, hipEventRecord(e->rv_ev_main, e->stream));
     JF_HIP(e, hipStreamWaitEvent(e->rv_side, e->rv_ev_main, 0));
     JF_HIP(e, launch_reverb_big_side(&e->side_p[0], &e->side_p[1], e->rv_side));
-    JF_HIP(e, hipEventRecord(e->rv_ev_side, e->rv_side));
-    e->rv_side_busy = true;
+    // launched: TAIL up to side_fut_m will be there (nothing before this line may claim so -- a stage whose launches failed
+    // must leave the schedule asking for them again)
     e->side_tr = false;
+    if (e->rv_fut_m < e->side_fut_m) e->rv_fut_m = e->side_fut_m;
+    e->rv_side_urgent = e->side_urgent;
+    e->rv_side_busy = true;
+    JF_HIP(e, hipEventRecord(e->rv_ev_side, e->rv_side));
+    return JF_OK;
+}
+
+// The pre-interpolated rows, built on first use (jf_engine::interp_avail): a table of 710 + kInterpRows rows takes the place of
+// the 710-row one -- the measured rows copied, the weighted sums formed behind them on the engine's stream.  Without room
+// for the 386 MB the engine goes on without rows (per-block weighting), for good.
+static int ensure_interp_rows(jf_engine *e) {
+    if (e->interp_built || !e->interp_avail) return JF_OK;
+    float4 *big = nullptr;
+    if (hipMalloc(&big, sizeof(float4) * ((size_t)kNumHrtf + kInterpRows) * 512) != hipSuccess) {
+        (void)hipGetLastError();
+        e->interp_avail = false;
+        e->interp_use = 0;
+        return JF_OK;
+    }
+    hipError_t q = hipMemcpyAsync(big, e->d_htab, sizeof(float4) * (size_t)kNumHrtf * 512, hipMemcpyDeviceToDevice, e->stream);
+    if (q == hipSuccess)
+        q = launch_table_interp_build(e->rt, (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, big, e->stream);
+    if (q == hipSuccess) q = hipStreamSynchronize(e->stream);  // (everything that reads the old table has finished as well)
+    if (q != hipSuccess) {
+        (void)hipFree(big);
+        JF_HIP(e, q);
+    }
+    (void)hipFree(e->d_htab);
+    e->d_htab = big;
+    e->interp_built = true;
     return JF_OK;
 }
 
@@ -463,10 +514,15 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     P.G = (e->S % G == 0) ? G : 1;
     const int canon = P.G > 1;  // descriptors in the pair-kernel layout
     // whole-degree positions as pre-interpolated rows: the pair kernel's descriptors only
-    bool rows = canon && e->interp_built && e->interp_use != 0;
+    bool rows = canon && e->interp_avail && e->interp_use != 0;
     if (rows && e->interp_use == 2 && first_block >= 0 && (size_t)(first_block + K) < e->traj_moved.size()) {
         const double moved = (double)(e->traj_moved[first_block + K] - e->traj_moved[first_block]) / (double)n_items;
         rows = moved <= kInterpMovedMax;
+    }
+    if (rows && !e->interp_built) {  // the first run that takes them builds them
+        const int rc = ensure_interp_rows(e);
+        if (rc) return rc;
+        rows = e->interp_built;
     }
     e->last_rows = rows;
     const int mode_now = kernel_mode(e) | (rows ? kModeInterpRows : 0);
@@ -511,7 +567,7 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
     P.prep_K = K;
     P.prep_canon = canon;
     P.rt = e->rt;
-    int max_wgs = e->resident_wgs[P.G > 1 ? 1 : 0];
+    int max_wgs = e->resident_wgs[P.G > 1 ? (rows ? 2 : 1) : 0];
     if (e->grid_limit > 0 && e->grid_limit < max_wgs) max_wgs = e->grid_limit;
     if (ef) JF_HIP(e, hipEventRecord(ef->a, e->stream));
     JF_HIP(e, launch_fused(P, max_wgs, e->stream));
@@ -562,6 +618,7 @@ void quiesce_side(jf_engine *e) {
 
 void free_reverb(jf_engine *e) {
     quiesce_side(e);
+    e->side_tr = false;
     e->last_side.clear();
     (void)hipFree(e->d_rv_yacc);
     e->d_rv_yacc = nullptr;
@@ -709,22 +766,15 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         }
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_main, hipEventDisableTiming));
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_side, hipEventDisableTiming));
-        for (int kind = 0; kind < 2; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
+        for (int kind = 0; kind < 3; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
         {
             const char *env = getenv("JF_INTERP_TABLE");
-            e->interp_built = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
-            e->interp_use = e->interp_built ? 2 : 0;
-            if (env && e->interp_built && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
+            e->interp_avail = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
+            e->interp_use = e->interp_avail ? 2 : 0;
+            if (env && e->interp_avail && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
         }
-        if (e->interp_built &&
-            hipMalloc(&e->d_htab, sizeof(float4) * ((size_t)kNumHrtf + kInterpRows) * 512) != hipSuccess) {
-            // no room for the 386 MB of pre-interpolated rows: the engine works without them (per-block weighting)
-            (void)hipGetLastError();
-            e->d_htab = nullptr;
-            e->interp_built = false;
-            e->interp_use = 0;
-        }
-        if (!e->d_htab) JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
+        // the 710 measured rows only; the pre-interpolated ones come with the first run that takes them (ensure_interp_rows)
+        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
         for (int i = 0; i < 2; i++) {
@@ -803,9 +853,6 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&d_hrir, hb));
         hipError_t s1 = h2d(e, d_hrir, hrir, hb);
         hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_twpack, e->d_htab, e->stream) : s1;
-        // ... and the weighted sums of every whole-degree position behind them (same stream: after the rows they read)
-        if (s2 == hipSuccess && e->interp_built)
-            s2 = launch_table_interp_build(e->rt, (cfg->flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->d_htab, e->stream);
         hipError_t s3 = s2 == hipSuccess ? hipStreamSynchronize(e->stream) : s2;
         (void)hipFree(d_hrir);
         JF_HIP(e, s3);
@@ -1317,7 +1364,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
     // how many items of every block move (their (ele, azi) differ from the block before; block 0 counts as staying):
     // what decides whether a run reads pre-interpolated rows (jf_engine::interp_use)
     e->traj_moved.assign((size_t)total_blocks + 1, 0u);
-    if (e->interp_built)
+    if (e->interp_avail)
         for (int b = 1; b < total_blocks; b++) {
             const float *p1 = positions + (size_t)b * e->S * 5, *p0 = p1 - (size_t)e->S * 5;
             unsigned n = 0;
@@ -1564,15 +1611,22 @@ int jf_debug_set_reverb_form(jf_engine *e, int form) {
 
 int jf_debug_set_interp_table(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     if (on < 0 || on > 2) return fail(e, JF_ERR_ARG, "0 = never, 1 = always, 2 = decided per run");
-    if (on && !e->interp_built) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
+    if (on && !e->interp_avail) return fail(e, JF_ERR_STATE, "this engine was created without the pre-interpolated rows");
     e->interp_use = on;  // the mode word of the next run changes with it: descriptors prepared ahead no longer match
+    if (on == 1) {       // "always" builds them now (a run under "per run" builds them when it first takes them)
+        const int rc = ensure_interp_rows(e);
+        if (rc) return rc;
+        if (!e->interp_built) return fail(e, JF_ERR_NOMEM, "no device memory for the pre-interpolated rows");
+    }
     return JF_OK;
     });
 }
 
-int jf_debug_interp_table(const jf_engine *e) { return e && e->interp_built ? e->interp_use : 0; }
+int jf_debug_interp_table(const jf_engine *e) { return e && e->interp_avail ? e->interp_use : 0; }
+int jf_debug_interp_table_built(const jf_engine *e) { return e && e->interp_built ? 1 : 0; }
 int jf_debug_last_run_used_rows(const jf_engine *e) { return e && e->last_rows ? 1 : 0; }
 
 int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask) {
@@ -1591,6 +1645,10 @@ int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask) {
 int jf_debug_read_table_rows(jf_engine *e, int first_row, int n, float *out) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
+    if (e && out && n > 0 && first_row >= 0 && first_row + (long long)n > kNumHrtf) {  // pre-interpolated rows: built on demand
+        const int rc = ensure_interp_rows(e);
+        if (rc) return rc;
+    }
     const int total = kNumHrtf + (e && e->interp_built ? kInterpRows : 0);
     if (!e || !out || n <= 0 || first_row < 0 || first_row > total - n) return fail(e, JF_ERR_ARG, "rows outside the table");
     JF_HIP(e, hipStreamSynchronize(e->stream));

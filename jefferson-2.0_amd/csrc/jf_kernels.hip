@@ -2222,14 +2222,22 @@ hipError_t launch_prep(const RingTable &rt, int mode, const float *d_pos, const 
 // Resident workgroups of the fused kernel that a call with these parameters launches (per-source kernel for
 // G = 1, pair kernel otherwise), on the CURRENT device: CUs x workgroups per CU for this build's LDS and register
 // footprint.  The engine asks once per (kernel, block size) at creation and keeps the answer with its device.
-hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source kernel, 1 pair kernel */, int *out) {
+hipError_t fused_resident_workgroups(int nb, int kind /* 0 per-source kernel, 1 pair kernel, 2 pair kernel with rows */, int *out) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     hipError_t q = hipGetDevice(&dev);
     if (q == hipSuccess) q = hipGetDeviceProperties(&prop, dev);
     if (q != hipSuccess) return q;
     const int threads = 64 * kWavesPerWg;
-    if (kind == 1) {
+    if (kind == 2) {
+        switch (nb) {
+        case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1, true>, threads, 0); break;
+        case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2, true>, threads, 0); break;
+        case 3: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<3, true>, threads, 0); break;
+        case 4: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<4, true>, threads, 0); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else if (kind == 1) {
         switch (nb) {
         case 1: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<1, false>, threads, 0); break;
         case 2: q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pair_kernel<2, false>, threads, 0); break;

@@ -23,10 +23,11 @@ for seed in range(n0, n1):
             fn(jf, hrir, castanets, *args)
         except AssertionError as ex:
             msg = str(ex).split("\n")[0][:200]
-            if "blocks >" in msg or "peak >" in msg or "prepared >" in msg or "(blocks, peak)" in msg or msg.startswith("("):
-                # the sanity counts at a test's end (enough blocks, loud enough, enough prepared runs) depend on the draw
-                if "assert" in msg and ("err" in msg or "step" in msg):
-                    pass
+            if ("blocks >" in msg or "peak >" in msg or "prepared >" in msg or "(blocks, peak)" in msg) and "step" not in msg:
+                # the sanity counts at a test's end (enough blocks, loud enough, enough prepared runs) depend on the draw:
+                # reported, not counted as a failure of the engine
+                print("SANITY", name, args, msg, flush=True)
+                continue
             print("FAIL", name, args, msg, flush=True)
             traceback.print_exc(limit=1)
             fails += 1

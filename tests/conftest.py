@@ -41,6 +41,27 @@ def jf():
     return mod
 
 
+def sum_tol(tol, n, k=1.0):
+    """Bound on the error of a sum of n per-source blocks each held to `tol` per sample (tol = a max over samples, i.e.
+    about five standard deviations of a source's error).  The sources' rounding errors are independent, so they add like
+    sqrt(n), not like n: a bound linear in n would let every source be many times less accurate unnoticed."""
+    return tol * max(1.0, k * float(np.sqrt(n)))
+
+
+def assert_within(got, want, tol, label="", scale=True):
+    """max |got - want| <= tol * max(1, |want|_inf) -- the reference's bound is stated for outputs below 1
+    (precision_test.cu:2158; above 1 it reports clipping, Audio.cu:111); scale=False: tol as it stands.  With JF_BOUNDS_LOG=<file> every comparison is
+    appended to that file as `error bound ratio label`: how much slack each bound has (profiles/r05/bounds.txt)."""
+    got, want = np.asarray(got), np.asarray(want)
+    err = float(np.abs(got - want).max())
+    bound = float(tol) * (max(1.0, float(np.abs(want).max())) if scale else 1.0)
+    log = os.environ.get("JF_BOUNDS_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{err:.3e} {bound:.3e} {err / bound:.3f} {label}\n")
+    assert err <= bound, (label, err, bound)
+
+
 def scenario_positions(azi0, ele0, n_dwell, n_rounds, r=0.5):
     """Position per block of a benchmarkTesting scenario (precision_test.cu:2093-2152)."""
     out = []

@@ -8,6 +8,7 @@ import pytest
 
 import model64
 import oracle_lib
+from conftest import assert_within, sum_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -135,8 +136,8 @@ def test_distance_sweep_gain_and_delay(jf, hrir):
     nearest radius (amplitude 0.5: |y| 0.9-1.3, the clipping regime) is held to its rms error instead: float32 transforms of 1024 points
     leave 4.2e-8 rms there and the worst of a few thousand samples is 5-6 sigma, 2.0-2.8e-7 over six seeds whichever way the
     complex products are written (profiles/r03/accuracy_seeds.txt; which stage owns that floor: profiles/r04/
-    error_floor.md) -- a known deviation recorded in DESIGN.md section 2, not a pass criterion; 5e-7 below only catches a
-    real regression."""
+    error_floor.md) -- a known deviation recorded in DESIGN.md section 2: bounded below by its rms (<= 6e-8) and the worst sample's
+    distance from it (<= 7 sigma)."""
     rng = np.random.default_rng(11)
     noise = rng.uniform(-.5, .5, 8192).astype(np.float32)
     for r, amp in ((0.05, 0.7), (0.05, 1.0), (0.5, 1.0), (1.0, 1.0), (2.0, 1.0), (3.5, 1.0), (4.9, 1.0)):
@@ -148,18 +149,23 @@ def test_distance_sweep_gain_and_delay(jf, hrir):
             x.set_spherical(0, 0, 45, r)
         loud = r < 0.1 and amp >= 1.0          # noise of amplitude 0.5 at gain ~2: |y| 0.9-1.3
         sq = n = 0
-        peak = 0.0
+        peak = worst_loud = 0.0
         for _ in range(8):
             y, y64 = e.process_block(), m.process_block()
             peak = max(peak, float(np.abs(y64).max()))
             if loud:
-                assert np.abs(y - y64).max() <= 5e-7          # regression guard only (see above)
+                worst_loud = max(worst_loud, float(np.abs(y - y64).max()))
             else:
                 assert np.abs(y64).max() < 1.0
                 assert np.abs(y - y64).max() <= TOL64         # the reference's bound, as it stands
             sq += float(np.sum((y - y64) ** 2))
             n += y.size
-        assert np.sqrt(sq / n) <= (6e-8 if loud else 4e-8 if r < 0.1 else 3e-8), (r, amp)     # (|y| to 0.9 at r = 0.05)
+        rms = float(np.sqrt(sq / n))
+        assert rms <= (6e-8 if loud else 4e-8 if r < 0.1 else 3e-8), (r, amp)     # (|y| to 0.9 at r = 0.05)
+        if loud:
+            # the deviation is BOUNDED, not waved through: the worst of the 4096 samples stays within 7 sigma of an error
+            # whose rms is bounded above (measured 4.8-6.7 sigma over six seeds) -- i.e. below 4.2e-7 here
+            assert worst_loud <= 7.0 * rms, (worst_loud, rms)
         assert peak > (0.9 if loud else 0.004), (r, amp, peak)
         e.close()
 
@@ -233,9 +239,9 @@ def test_group_kernel_mixed_units(jf, hrir, castanets, B, G):
     want.append(ora.process_batch(pos[K + 2:]))
     want = np.concatenate(want)
     assert np.abs(want).max() > 0.1
-    assert np.abs(outs[G] - outs[1]).max() <= TOL32 * S / 4
-    assert np.abs(outs[G] - want).max() <= TOL32 * S / 4
-    assert np.abs(outs[1] - want).max() <= TOL32 * S / 4
+    assert_within(outs[G], outs[1], sum_tol(TOL32, S), f'mixed units B={B} G={G}: pair vs per-source kernel', scale=False)
+    assert_within(outs[G], want, sum_tol(TOL32, S), f'mixed units B={B} G={G}: pair vs oracle32', scale=False)
+    assert_within(outs[1], want, sum_tol(TOL32, S), f'mixed units B={B}: per-source kernel vs oracle32', scale=False)
 
 
 def test_source_shards_sum_to_the_whole(jf, hrir, castanets):
@@ -263,7 +269,7 @@ def test_source_shards_sum_to_the_whole(jf, hrir, castanets):
         total += part.process_batch(np.ascontiguousarray(pos[:, lo:hi]))
         part.close()
     assert np.abs(want).max() > 0.2
-    assert np.abs(total - want).max() <= TOL32 * S / 4
+    assert_within(total, want, sum_tol(TOL32, S), 'two shards vs the whole', scale=False)
 
 
 def test_full_size_moving_workload_properties(jf, hrir):
@@ -327,7 +333,7 @@ def test_full_size_moving_workload_properties(jf, hrir):
         gpart = e3.read_device(e3.partial_device_ptr(), (K, S // G, 2 * B))
         e3.close()
         want = part.astype(np.float64).reshape(K, S // G, G, 2 * B).sum(axis=2)
-        assert np.abs(gpart - want).max() <= TOL64 * G, G      # |block| ~ 1 per source
+        assert_within(gpart, want, sum_tol(TOL64, G), f'full width: groups of {G} vs sums of per-source blocks', scale=False)
         assert np.abs(grouped - mix).max() < 2e-5, G           # |mix| ~ 10
 
 

@@ -198,3 +198,45 @@ def test_the_rows_are_taken_per_run_by_how_many_items_move(jf, hrir):
             e.close()
         assert np.abs(outs[2]).max() > 0.01
         assert np.array_equal(outs[2], outs[1]) and np.array_equal(outs[2], outs[0])
+
+
+def test_the_rows_are_built_by_the_first_run_that_takes_them(jf, hrir):
+    """386 MB of rows nobody reads are not built: an engine holds the 710 measured rows until a run's policy takes the
+    pre-interpolated ones (or a caller asks for them), whatever runs before -- per-block calls, runs in which every source
+    moves -- and the run that builds them gives the same blocks, bit for bit, as an engine that never has them.  An engine
+    that may not have them (JF_FLAG_NO_INTERP_TABLE) never builds them."""
+    S, K, B = 16, 16, 128
+    ids = np.arange(S)
+    ele = (-40 + (ids * 9) % 131).astype(np.float32)
+    b = np.arange(3 * K, dtype=np.int64)[:, None]
+    moving = ((ids * 23)[None, :] + b) % 360
+    azi = np.where(b < K, moving, ((ids * 23)[None, :] + K - 1) % 360)      # window 0 moves every block, windows 1 and 2 stay
+    pos = jf.positions_from_spherical(np.broadcast_to(ele, azi.shape), azi.astype(np.float32),
+                                      np.broadcast_to(np.float32(0.9), azi.shape))
+    e, _ = _engine(jf, hrir, S, K, B=B, group=4)
+    never, _ = _engine(jf, hrir, S, K, B=B, group=4, flags=jf.JF_FLAG_NO_INTERP_TABLE)
+    assert e.interp_table() == 2 and not e.interp_table_built()
+    assert never.interp_table() == 0 and not never.interp_table_built()
+    for x in (e, never):
+        x.process_block()                    # the one-launch kernel: no rows
+        x.upload_positions(pos)
+    assert not e.interp_table_built()
+    for w in range(3):
+        for x in (e, never):
+            x.batch_run(w * K, K)
+            x.synchronize()
+        assert e.last_run_used_rows() == (w > 0) and not never.last_run_used_rows()
+        assert e.interp_table_built() == (w > 0), w      # built by window 1, the first one whose policy takes them
+        assert not never.interp_table_built()
+        got = e.read_device(e.mix_device_ptr(), (K, 2 * B))
+        want = never.read_device(never.mix_device_ptr(), (K, 2 * B))
+        assert np.abs(want).max() > 0.01 and np.array_equal(got, want), w
+    # asking for them builds them at once
+    e2, _ = _engine(jf, hrir, S, K, B=B, group=4)
+    assert not e2.interp_table_built()
+    e2.set_interp_table(1)
+    assert e2.interp_table_built()
+    rows = e2.read_table_rows(jf.NUM_HRTF, 4)
+    assert np.array_equal(rows, e.read_table_rows(jf.NUM_HRTF, 4)) and np.abs(rows).max() > 0
+    for x in (e, e2, never):
+        x.close()

@@ -5,6 +5,7 @@ import pytest
 
 import model64
 import oracle_lib
+from conftest import assert_within, sum_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +42,8 @@ def test_fd_basic_vs_oracles_and_time_domain(jf, hrir, castanets, S, rt_max):
     eng.close()
     got, w32, w64 = np.array(got), np.array(w32), np.array(w64)
     assert np.abs(w64).max() > 0.02
-    assert np.abs(got - w64).max() <= TOL64 * max(1, S // 4)
-    assert np.abs(got - w32).max() <= TOL32 * max(1, S // 4)
+    assert_within(got, w64, sum_tol(TOL64, S), f'FD_BASIC S={S} vs model64')
+    assert_within(got, w32, sum_tol(TOL32, S), f'FD_BASIC S={S} vs oracle32')
     if S == 1:
         # time-domain definition (CPU_TD): y[n] = sum_k x[n-k] h[k] with the nearest HRIR of each block
         stream = sigs[0].astype(np.float64)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+from conftest import sum_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +75,7 @@ def test_random_session_of_block_and_batch_calls(jf, hrir, castanets, seed, B, S
         eng.set_reverb(ir, 0.5)
         ora.set_reverb(ir, 0.5)
         P = -(-reverb // B)
-    tol_rel = (TOL32 + (2e-7 + 1e-7 * np.sqrt(P) if P else 0.0)) * S
+    tol_rel = sum_tol(TOL32 + (2e-7 + 1e-7 * np.sqrt(P) if P else 0.0), S)   # S sources: their errors add like sqrt(S)
     worst = peak = 0.0
     blocks = 0
     paused = False
@@ -163,13 +164,13 @@ def test_random_session_through_the_callback(jf, hrir, castanets, seed, B, S, re
         sig = (0.4 * castanets[1000 * s:1000 * s + 6000]).astype(np.float32)
         eng.set_signal(s, sig)
         ora.set_signal(s, sig)
-    tol = TOL32 * S
+    tol = sum_tol(TOL32, S)
     if reverb:      # the big partitions' work goes to the side stream a whole big block ahead (16 blocks: 220 calls cross 13 of them)
         ir = (rng.standard_normal(reverb) * np.exp(-4.0 * np.arange(reverb) / reverb)).astype(np.float32)
         ir /= np.sqrt((ir ** 2).sum())
         eng.set_reverb(ir, 0.5)
         ora.set_reverb(ir, 0.5)
-        tol += (2e-7 + 1e-7 * np.sqrt(-(-reverb // B))) * S
+        tol = sum_tol(TOL32 + 2e-7 + 1e-7 * np.sqrt(-(-reverb // B)), S)
     prev = np.zeros(2 * B, np.float32)        # intermediate[] before the first block
     paused = False
     peak = 0.0
@@ -220,13 +221,13 @@ def test_random_session_through_the_group_of_shards(jf, hrir, castanets, seed, B
         sig = (0.4 * castanets[900 * s:900 * s + 5000 + 31 * s]).astype(np.float32)
         g.set_signal(s, sig)
         ora.set_signal(s, sig)
-    tol = TOL32 * S
+    tol = sum_tol(TOL32, S)
     if reverb:
         ir = (rng.standard_normal(reverb) * np.exp(-4.0 * np.arange(reverb) / reverb)).astype(np.float32)
         ir /= np.sqrt((ir ** 2).sum())
         g.set_reverb(ir, 0.5)
         ora.set_reverb(ir, 0.5)
-        tol += (2e-7 + 1e-7 * np.sqrt(-(-reverb // B))) * S
+        tol = sum_tol(TOL32 + 2e-7 + 1e-7 * np.sqrt(-(-reverb // B)), S)
     paused = False
     peak = 0.0
     blocks = 0
@@ -325,7 +326,7 @@ def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets,
             eng.set_prep_ahead(bool(rng.integers(0, 2)))
         elif op < 45:                            # a per-block call in between (positions: where the last run left the sources)
             a, b = eng.process_block(), ora.process_block()
-            assert np.abs(a - b).max() <= TOL32 * S * max(1.0, float(np.abs(b).max())), (seed, step, "block")
+            assert np.abs(a - b).max() <= sum_tol(TOL32, S) * max(1.0, float(np.abs(b).max())), (seed, step, "block")
         # a run: mostly the window that follows, sometimes any other
         n = int(rng.integers(1, K + 1))
         if rng.random() < 0.25 or nxt + n > len(pos):
@@ -340,7 +341,7 @@ def test_random_session_of_runs_over_an_uploaded_trajectory(jf, hrir, castanets,
         eng.set_latched(pos[first + n - 1])      # jf_batch_run leaves the sources alone: say where they stand
         nxt = first + n
         peak = max(peak, float(np.abs(want).max()))
-        assert np.abs(got - want).max() <= TOL32 * S * max(1.0, float(np.abs(want).max())), (seed, step, int(op), first, n, eng.last_kernels())
+        assert np.abs(got - want).max() <= sum_tol(TOL32, S) * max(1.0, float(np.abs(want).max())), (seed, step, int(op), first, n, eng.last_kernels())
     eng.close()
     ora.close()
     assert peak > 0.02 and prepared >= 1, (peak, prepared)

@@ -232,6 +232,54 @@ def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, 
     assert np.abs(cut - want).max() > 100 * tol
 
 
+@pytest.mark.parametrize("B", [128, 256])
+@pytest.mark.parametrize("short", ["half", "one", "one_and_a_bit", "two_and_a_bit", "almost_three"])
+def test_forced_nonuniform_partitioning_of_short_responses(jf, hrir, castanets, B, short):
+    """jf_debug_set_reverb_partitioning(e, 2) with a response the default would never partition non-uniformly (below three
+    big partitions): no big partition behind the head at all (the head alone, zero-padded to 2 M partitions), ONE (TAIL
+    sums over no spectrum: zeros) and TWO (TAIL is a single product).  Against the float64 convolution, the uniform form,
+    and per-block calls (the side stream) against batch calls without a whole big block bit for bit."""
+    S, K = 2, 52
+    M = 16 if B <= 128 else 8
+    B1 = M * B
+    n_ir = {"half": B1 // 2 + 3, "one": B1, "one_and_a_bit": B1 + 5, "two_and_a_bit": 2 * B1 + 9, "almost_three": 3 * B1 - 1}[short]
+    p1 = {"half": 0, "one": 0, "one_and_a_bit": 1, "two_and_a_bit": 2, "almost_three": 2}[short]
+    ir = _ir(n_ir, decay=2.0)
+    gain = 0.6
+    sigs = [castanets[5000 * s: 5000 * s + 12000 + 91 * s] for s in range(S)]
+    pos = _positions(jf, S, K)
+    want = _model(hrir, B, S, K, ir, gain, sigs, pos)
+    P = -(-n_ir // B)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * S
+    outs = {}
+    for part, sizes in ((2, (1, 5, 16, 17, 13)), (2, (6, 46)), (2, (7,) * 7 + (3,)), (1, (6, 46))):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max(sizes))
+        e.set_reverb_partitioning(part)
+        if sizes[0] == 7:
+            e.set_reverb_form(1)       # (pinned like the per-block run below: same sums in the head)
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+        e.set_reverb(ir, gain)
+        n, head, big, taps = e.reverb_partitions()
+        assert n == P
+        if part == 2:
+            assert (head, big, taps) == (2 * M, max(p1 - 1, 0), B1 if p1 else 0), (head, big, taps)
+        got, b0 = [], 0
+        for k in sizes:
+            got.append(e.process_batch(pos[b0:b0 + k]))
+            b0 += k
+        assert b0 == K
+        outs[part, sizes] = np.concatenate(got)
+        e.close()
+    assert np.abs(want).max() > 0.02
+    for key, got in outs.items():
+        assert np.abs(got - want).max() <= tol, key
+    blockwise = _run(jf, hrir, B, S, K, 1, ir, gain, sigs, pos, blockwise=True, form=1, part=2)
+    assert np.array_equal(blockwise, outs[2, (7,) * 7 + (3,)])
+    free = _run(jf, hrir, B, S, K, 1, ir, gain, sigs, pos, blockwise=True, part=2)       # the fused head kernel + the side stream
+    assert np.abs(free - want).max() <= tol
+
+
 def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, castanets):
     """Per-block calls against batch calls that contain no whole big block (ragged sizes up to 15, boundaries inside and at
     their ends) with the head's form pinned for both: bit-identical -- every block is then head + TAIL(m), and TAIL's products
