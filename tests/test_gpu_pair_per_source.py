@@ -38,7 +38,7 @@ def _live_slot(u, G):
 def _trajectory(jf, kind, u, K):
     """[K][5] latched records of the live source of unit u."""
     out = np.zeros((K, 5), np.float32)
-    r = 0.35 + 0.11 * u
+    r = 0.2 + 0.03 * u          # near: the path's gain 1 / (1 + fsvs r'^2) stays above 0.3, every unit is well above the bound
     for k in range(K):
         ele, azi = 0.0, 0.0
         frac = None
@@ -88,12 +88,14 @@ def test_one_live_source_per_unit_meets_the_per_source_tolerance(jf, hrir, casta
     live = [G * u + _live_slot(u, G) for u in range(N_UNITS)]
     assert {s % 2 for s in live} == {0, 1} and len(set(s % G for s in live)) >= min(G, 2)
     sigs = []
+    loud0 = max(0, int(np.argmax(np.abs(castanets))) - 2500)      # the excerpts begin shortly before the input's loudest click
     for u, s in enumerate(live):
         pos[:, s] = _trajectory(jf, u % 8, u, CALLS * K)
         if u % 2:
-            sig = rng.uniform(-0.35, 0.35, 3000 + 411 * u).astype(np.float32)      # white noise, a short loop
+            sig = rng.uniform(-0.25, 0.25, 3000 + 411 * u).astype(np.float32)      # white noise, a short loop
         else:
-            sig = (0.6 * np.roll(castanets, 5003 * u)[: 20000 + 1111 * u]).astype(np.float32)
+            sig = 0.42 * np.roll(castanets, -(loud0 + 777 * u))[: 20000 + 1111 * u]     # clicks with silence in between ...
+            sig = (sig + rng.uniform(-0.08, 0.08, len(sig))).astype(np.float32)          # ... over a noise floor
         sigs.append(sig)
 
     eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=K)
