@@ -103,6 +103,39 @@ int jf_engine_create(const jf_config *cfg, const float *hrir, int taps, jf_engin
  */
 int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_engine **out);
 
+/*
+ * Any HRTF set measured on a grid of elevation rings -- the author's TODO "Add compatibility for any HRTF database"
+ * (FuturePlans.md:21); the reference hard-codes KEMAR's 14 rings in hrtf_signals.cu:7-12 and its loader loop :107-153.
+ * Ring r lies at ring_elevation[r] degrees (ascending, within [-90, 90]) and holds ring_count[r] measurements, measurement
+ * i at azimuth i * ring_step[r] degrees (ring_step == NULL: 360 / count; a ring of one measurement is the pole).  Table
+ * rows run ring by ring, azimuth ascending: jf_grid_rows() of them, hrir [rows][2][taps].
+ *   - The reference's own grid -- jf_kemar_grid(): 14 rings at -40 .. 90, 56 + 60 + 72 + ... + 1 = 710 rows, the ROUNDED
+ *     steps of hrtf_signals.cu:8 (6.43 for 360 / 56 ...) -- is recognised: jf_engine_create_grid with it IS jf_engine_create
+ *     (the reference's index/weight rule by default, bit-identical output; tested).
+ *   - Any other grid is worked by the corrected rule of JF_FLAG_CORRECTED_INTERPOLATION in its general form: the two rings
+ *     whose elevations enclose the position (positions outside the grid clamped to its first / last ring), linear
+ *     weights in elevation, on each ring the two measurements that enclose the azimuth with the wrap at 360 and weights
+ *     that sum to 1; JF_MODE_FD_BASIC takes the nearest ring's nearest measurement.  The setters accept elevations in
+ *     [-90, 90].  jf_grid_interpolation / jf_grid_pick are the host twins of the kernels' rule (same float32 steps).
+ * A SOFA (HDF5) container is not read here: the image has no HDF5 library and the reference no such file; a caller
+ * that has one fills this struct from its SourcePosition array and passes Data.IR as hrir.
+ */
+#define JF_MAX_RINGS 40
+typedef struct jf_hrtf_grid {
+    int n_rings;                 /* 1 .. JF_MAX_RINGS */
+    const float *ring_elevation; /* [n_rings] */
+    const int *ring_count;       /* [n_rings] */
+    const float *ring_step;      /* [n_rings] or NULL */
+} jf_hrtf_grid;
+int jf_kemar_grid(jf_hrtf_grid *out);            /* pointers into static storage of the library */
+int jf_grid_rows(const jf_hrtf_grid *grid);      /* table rows of the grid, or a JF_ERR_* code */
+int jf_engine_create_grid(const jf_config *cfg, const jf_hrtf_grid *grid, const float *hrir, int taps, jf_engine **out);
+/* idx = {ring0 low, ring0 high, ring1 low, ring1 high} rows, omegas = {A, B, C, D, E, F} as in jf_interpolation */
+int jf_grid_interpolation(const jf_hrtf_grid *grid, float ele, float azi, int idx[4], float omegas[6]);
+int jf_grid_pick(const jf_hrtf_grid *grid, float ele, float azi);   /* nearest measurement's row */
+/* rows of this engine's HRTF table (710 for KEMAR) */
+int jf_table_rows(const jf_engine *e);
+
 /* closeEverything() / cleanup_hrtf_buffers() / ~GPUSoundSource (hrtf_signals.cu:100-105, GPUSoundSource.cu:532-548). */
 void jf_engine_destroy(jf_engine *e);
 

@@ -33,6 +33,11 @@ class JfConfig(C.Structure):
                 ("device", C.c_int), ("max_batch_blocks", C.c_int), ("flags", C.c_uint)]
 
 
+class JfHrtfGrid(C.Structure):
+    _fields_ = [("n_rings", C.c_int), ("ring_elevation", C.POINTER(C.c_float)), ("ring_count", C.POINTER(C.c_int)),
+                ("ring_step", C.POINTER(C.c_float))]
+
+
 class JfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"jefferson error {code}: {msg}")
@@ -44,6 +49,12 @@ _lib = None
 _SIGS = {
     "jf_engine_create": (C.c_int, [C.POINTER(JfConfig), _f, C.c_int, C.POINTER(C.c_void_p)]),
     "jf_engine_create_from_dir": (C.c_int, [C.POINTER(JfConfig), C.c_char_p, C.POINTER(C.c_void_p)]),
+    "jf_engine_create_grid": (C.c_int, [C.POINTER(JfConfig), C.POINTER(JfHrtfGrid), _f, C.c_int, C.POINTER(C.c_void_p)]),
+    "jf_kemar_grid": (C.c_int, [C.POINTER(JfHrtfGrid)]),
+    "jf_grid_rows": (C.c_int, [C.POINTER(JfHrtfGrid)]),
+    "jf_grid_interpolation": (C.c_int, [C.POINTER(JfHrtfGrid), C.c_float, C.c_float, _i, _f]),
+    "jf_grid_pick": (C.c_int, [C.POINTER(JfHrtfGrid), C.c_float, C.c_float]),
+    "jf_table_rows": (C.c_int, [C.c_void_p]),
     "jf_engine_destroy": (None, [C.c_void_p]),
     "jf_last_error": (C.c_char_p, [C.c_void_p]),
     "jf_frames_per_buffer": (C.c_int, [C.c_void_p]),
@@ -232,14 +243,53 @@ def wav_write_stereo24(path, interleaved, fs=44100):
         raise JfError(rc, lib().jf_last_error(None).decode())
 
 
+class Grid:
+    """include/jefferson.h: jf_hrtf_grid (keeps its arrays alive)."""
+
+    def __init__(self, ring_elevation, ring_count, ring_step=None):
+        self.ele = np.ascontiguousarray(ring_elevation, np.float32)
+        self.count = np.ascontiguousarray(ring_count, np.int32)
+        self.step = None if ring_step is None else np.ascontiguousarray(ring_step, np.float32)
+        assert len(self.ele) == len(self.count) and (self.step is None or len(self.step) == len(self.ele))
+        self.c = JfHrtfGrid(len(self.ele), _fp(self.ele), _ip(self.count), _fp(self.step) if self.step is not None else None)
+
+    @staticmethod
+    def kemar():
+        g = JfHrtfGrid()
+        assert lib().jf_kemar_grid(C.byref(g)) == 0
+        n = g.n_rings
+        return Grid([g.ring_elevation[i] for i in range(n)], [g.ring_count[i] for i in range(n)],
+                    [g.ring_step[i] for i in range(n)])
+
+    def rows(self):
+        n = lib().jf_grid_rows(C.byref(self.c))
+        if n < 0:
+            raise JfError(n, lib().jf_last_error(None).decode())
+        return n
+
+    def interpolation(self, ele, azi):
+        idx = np.zeros(4, np.int32)
+        om = np.zeros(6, np.float32)
+        rc = lib().jf_grid_interpolation(C.byref(self.c), ele, azi, _ip(idx), _fp(om))
+        return None if rc else (idx, om)
+
+    def pick(self, ele, azi):
+        return lib().jf_grid_pick(C.byref(self.c), ele, azi)
+
+
 class Engine:
     """Thin object wrapper; method names follow the C ABI."""
 
-    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1, flags=0):
+    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1, flags=0, grid=None):
         L = lib()
         cfg = JfConfig(B, hrtf_len, n_sources, device, max_batch_blocks, flags)
         h = C.c_void_p()
-        if hrir_dir is not None:
+        if grid is not None:
+            hrir = np.ascontiguousarray(hrir, np.float32)
+            assert hrir.shape[1] == 2
+            self._grid = grid
+            rc = L.jf_engine_create_grid(C.byref(cfg), C.byref(grid.c), _fp(hrir), hrir.shape[2], C.byref(h))
+        elif hrir_dir is not None:
             rc = L.jf_engine_create_from_dir(C.byref(cfg), hrir_dir.encode(), C.byref(h))
         else:
             hrir = np.ascontiguousarray(hrir, np.float32)
@@ -431,8 +481,11 @@ class Engine:
     def set_rt_max_sources(self, n):
         self._chk(lib().jf_debug_set_rt_max_sources(self.h, int(n)))
 
+    def table_rows(self):
+        return lib().jf_table_rows(self.h)
+
     def read_table(self):
-        t = np.zeros((NUM_HRTF, 2, NC, 2), np.float32)
+        t = np.zeros((self.table_rows(), 2, NC, 2), np.float32)
         self._chk(lib().jf_debug_read_table(self.h, _fp(t)))
         return t.view(np.complex64)[..., 0]
 

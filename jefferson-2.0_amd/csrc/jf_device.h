@@ -1,16 +1,16 @@
 // jf_device.h -- shared host/device declarations of the HIP engine (gfx950).
 //
 // Data layout in HBM (all engine-owned):
-//   htab   float4[710][512]   HRTF spectra, both ears interleaved per bin:
+//   htab   float4[n_rows][512] HRTF spectra (n_rows = 710 for KEMAR), both ears interleaved per bin:
 //                             k >= 1: {L.re, L.im, R.re, R.im};
 //                             k == 0: {L[0].re, L[512].re, R[0].re, R[512].re}
 //                             (bins 0 and 512 of a real HRIR are real), so one
 //                             16-byte load per lane fetches both ears and a row
 //                             is exactly 8 KiB.  Same numbers as the reference's
 //                             fft_hrtf[(j*2+ear)*513+k] (hrtf_signals.cu:90-98).
-//                             Rows 710 .. 710 + 47159 (optional, 386 MB): the PRE-INTERPOLATED filters of every whole-degree
+//                             Rows n_rows .. n_rows + 47159 (built on first use, 386 MB): the PRE-INTERPOLATED filters of every whole-degree
 //                             position the setters can latch (SoundSource.cu:33-34,42-43 round to whole degrees):
-//                             row 710 + (ele + 40) * 360 + azi = sum_t w_t H[row_t] for (ele, azi), ele -40..90,
+//                             row n_rows + (ele + 40) * 360 + azi = sum_t w_t H[row_t] for (ele, azi), ele -40..90,
 //                             azi 0..359, by the same operations in the same order as the filters' own weighting
 //                             (table_interp_build_kernel).  A filter set is then ONE row with weight 1.
 //   tw     float2[1024]       exp(+2*pi*i*j/1024), from double (reverb kernels).
@@ -31,8 +31,9 @@ namespace jf {
 
 constexpr int kN = 1024;       // PAD_LEN (Universal.cuh:12)
 constexpr int kNc = 513;       // PAD_LEN / 2 + 1
-constexpr int kNumHrtf = 710;  // NUM_HRTF (Universal.cuh:4)
-constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25)
+constexpr int kNumHrtf = 710;  // NUM_HRTF (Universal.cuh:4): rows of the reference's KEMAR table
+constexpr int kNumElev = 14;   // NUM_ELEV (hrtf_signals.cuh:25): its elevation rings
+constexpr int kMaxRings = 40;  // JF_MAX_RINGS (include/jefferson.h): elevation rings of any HRTF grid (5-degree rings pole to pole: 37)
 // pre-interpolated rows behind the 710 measured ones (see htab above)
 constexpr int kInterpEleMin = -40, kInterpEleMax = 90, kInterpAzi = 360;
 constexpr int kInterpRows = (kInterpEleMax - kInterpEleMin + 1) * kInterpAzi;  // 47 160
@@ -111,13 +112,22 @@ struct SrcSignal {
     int pad;
 };
 
-// hrtf_signals.cu:7-12 tables, filled on the host by the reference's own loop.
+// The measurement grid of the HRTF set: elevation rings, each sampled at a uniform azimuth step from azimuth 0; table rows
+// ring by ring, azimuth ascending.  For the reference's KEMAR grid (kemar = 1) these are the tables of hrtf_signals.cu:7-12,
+// filled on the host by the reference's own loop (the steps are the reference's ROUNDED ones: 6.43 for 360 / 56 ...), and the
+// reference's index/weight rule applies unless the corrected one is asked for; any other grid (jf_engine_create_grid)
+// is worked by the corrected rule in its general form (dev_interp_corrected) and a plain nearest-measurement search.
 constexpr int kPickAzi = 401;  // integer azimuths 0 .. 400 of the nearest-azimuth table
 struct RingTable {
-    int offset[kNumElev + 1];
-    float inc[kNumElev];
-    // [kNumElev][kPickAzi] device table (null: search): the table row nearest to integer azimuth a on ring e -- what
-    // pick_hrtf's search over a ring (hrtf_signals.cu:20-51) returns for (elevation of e, a); built by that search
+    int n_rings;  // 14 for KEMAR
+    int n_rows;   // 710 for KEMAR: offset[n_rings]; the pre-interpolated rows follow row n_rows - 1
+    int kemar;    // 1: the reference's grid (ring r at -40 + 10 r degrees; `pick` valid)
+    int pad;
+    int offset[kMaxRings + 1];
+    float inc[kMaxRings];
+    float ele[kMaxRings];  // elevation of ring r, ascending
+    // KEMAR only: [kNumElev][kPickAzi] device table (null: search): the table row nearest to integer azimuth a on ring e --
+    // what pick_hrtf's search over a ring (hrtf_signals.cu:20-51) returns for (elevation of e, a); built by that search
     const short *pick;
 };
 

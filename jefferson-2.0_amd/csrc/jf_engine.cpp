@@ -21,7 +21,7 @@
 #include "jf_host.h"
 
 namespace jf {
-hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
+hipError_t launch_table_build(const float *d_hrir, int n_rows, int taps, const float2 *d_tw, float4 *d_htab, hipStream_t st);
 hipError_t launch_table_interp_build(const RingTable &rt, int corrected, float4 *d_htab, hipStream_t st);
 hipError_t launch_rfft_debug(const float *d_win, int n, const float2 *d_tw, float2 *d_spec, hipStream_t st);
 hipError_t launch_interp_debug(const RingTable &rt, const float *d_ele, const float *d_azi, int *d_rows,
@@ -226,6 +226,11 @@ int fail(jf_engine *e, int code, const std::string &msg) {
 
 bool valid_src(const jf_engine *e, int s) { return e && s >= 0 && s < e->S; }
 
+// Elevations the setters take: where the reference's rule names two measured rings, (-50, 90] (SoundSource.cu:67-68 with
+// the table of hrtf_signals.cu:7); with a grid of its own the engine clamps to the grid's first and last ring: [-90, 90].
+bool elevation_ok(const jf_engine *e, float ele) { return e->rt.kemar ? (ele > -50.0f && ele <= 90.0f) : (ele >= -90.0f && ele <= 90.0f); }
+const char *elevation_msg(const jf_engine *e) { return e->rt.kemar ? "elevation outside (-50, 90]" : "elevation outside [-90, 90]"; }
+
 // The error word of the fused kernels (host-mapped): set when a wait between the two wavefronts of a pair timed out
 // (fused_pair_kernel; impossible by its protocol, and bounded so that a fault cannot hang the GPU).  The blocks of that
 // launch are wrong and the sources' state is undefined from then on, so the condition is FATAL for the engine: every
@@ -253,8 +258,11 @@ struct DeviceGuard {
 };
 
 // what the kernels get as `mode`: bit 0 = FD_BASIC, bit 1 = the corrected index/weight rule
+static bool corrected_rule(const jf_engine *e) {  // (a grid that is not the reference's has no other rule)
+    return (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) != 0 || !e->rt.kemar;
+}
 static int kernel_mode(const jf_engine *e) {
-    return e->mode.load(std::memory_order_relaxed) | ((e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 2 : 0);
+    return e->mode.load(std::memory_order_relaxed) | (corrected_rule(e) ? 2 : 0);
 }
 
 EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
@@ -460,15 +468,15 @@ int submit_side(jf_engine *e) {
 static int ensure_interp_rows(jf_engine *e) {
     if (e->interp_built || !e->interp_avail) return JF_OK;
     float4 *big = nullptr;
-    if (hipMalloc(&big, sizeof(float4) * ((size_t)kNumHrtf + kInterpRows) * 512) != hipSuccess) {
+    const size_t n_rows = (size_t)e->rt.n_rows;
+    if (hipMalloc(&big, sizeof(float4) * (n_rows + kInterpRows) * 512) != hipSuccess) {
         (void)hipGetLastError();
         e->interp_avail = false;
         e->interp_use = 0;
         return JF_OK;
     }
-    hipError_t q = hipMemcpyAsync(big, e->d_htab, sizeof(float4) * (size_t)kNumHrtf * 512, hipMemcpyDeviceToDevice, e->stream);
-    if (q == hipSuccess)
-        q = launch_table_interp_build(e->rt, (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, big, e->stream);
+    hipError_t q = hipMemcpyAsync(big, e->d_htab, sizeof(float4) * n_rows * 512, hipMemcpyDeviceToDevice, e->stream);
+    if (q == hipSuccess) q = launch_table_interp_build(e->rt, corrected_rule(e) ? 1 : 0, big, e->stream);
     if (q == hipSuccess) q = hipStreamSynchronize(e->stream);  // (everything that reads the old table has finished as well)
     if (q != hipSuccess) {
         (void)hipFree(big);
@@ -717,7 +725,8 @@ void destroy_engine(jf_engine *e) {
     delete e;
 }
 
-int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine **out) {
+// grid: the table of the HRTF set's measurement grid (null: the reference's KEMAR grid, 710 rows)
+int create_engine(const jf_config *cfg, const RingTable *grid, const float *hrir, int taps, jf_engine **out) {
     if (!cfg || !hrir || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
     *out = nullptr;
     const int B = cfg->frames_per_buffer;
@@ -774,7 +783,8 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
             if (env && e->interp_avail && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
         }
         // the 710 measured rows only; the pre-interpolated ones come with the first run that takes them (ensure_interp_rows)
-        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * kNumHrtf * 512));
+        e->rt = grid ? *grid : ring_table();
+        JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * (size_t)e->rt.n_rows * 512));
         JF_HIP(e, hipMalloc(&e->d_tw, sizeof(float2) * 1024));
         JF_HIP(e, hipMalloc(&e->d_sigs, sizeof(SrcSignal) * S));
         for (int i = 0; i < 2; i++) {
@@ -788,7 +798,8 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
         JF_HIP(e, hipMalloc(&e->d_partial, sizeof(float) * S * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_mix, sizeof(float) * K * 2 * B));
         JF_HIP(e, hipMalloc(&e->d_pos_rt, sizeof(float) * S * 5));
-        {
+        e->rt.pick = nullptr;
+        if (e->rt.kemar) {
             // nearest table row per (ring, integer azimuth), by the search itself (host_pick_hrtf = hrtf_signals.cu:20-51)
             static const int elev[kNumElev] = {-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90};
             std::vector<short> pick((size_t)kNumElev * kPickAzi);
@@ -796,7 +807,6 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
                 for (int a = 0; a < kPickAzi; a++) pick[(size_t)r * kPickAzi + a] = (short)host_pick_hrtf((float)elev[r], (float)a);
             JF_HIP(e, hipMalloc(&e->d_pick, sizeof(short) * pick.size()));
             JF_HIP(e, h2d(e, e->d_pick, pick.data(), sizeof(short) * pick.size()));
-            e->rt = ring_table();
             e->rt.pick = e->d_pick;
         }
         JF_HIP(e, hipMalloc(&e->d_order, sizeof(int) * S));
@@ -849,10 +859,10 @@ int create_engine(const jf_config *cfg, const float *hrir, int taps, jf_engine *
 
         // HRTF spectra on the GPU (read_hrtf_signals + transform_hrtfs)
         float *d_hrir = nullptr;
-        const size_t hb = sizeof(float) * kNumHrtf * 2 * (size_t)taps;
+        const size_t hb = sizeof(float) * (size_t)e->rt.n_rows * 2 * (size_t)taps;
         JF_HIP(e, hipMalloc(&d_hrir, hb));
         hipError_t s1 = h2d(e, d_hrir, hrir, hb);
-        hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, taps, e->d_twpack, e->d_htab, e->stream) : s1;
+        hipError_t s2 = s1 == hipSuccess ? launch_table_build(d_hrir, e->rt.n_rows, taps, e->d_twpack, e->d_htab, e->stream) : s1;
         hipError_t s3 = s2 == hipSuccess ? hipStreamSynchronize(e->stream) : s2;
         (void)hipFree(d_hrir);
         JF_HIP(e, s3);
@@ -892,7 +902,66 @@ extern "C" {
 
 int jf_engine_create(const jf_config *cfg, const float *hrir, int taps, jf_engine **out) {
     return jf_guard([&]() -> int {
-    return create_engine(cfg, hrir, taps, out);
+    return create_engine(cfg, nullptr, hrir, taps, out);
+    });
+}
+
+// ---- any grid of elevation rings ("SOFA / other HRTF sets", FuturePlans.md:21) ----
+static const float kKemarEle[kNumElev] = {-40, -30, -20, -10, 0, 10, 20, 30, 40, 50, 60, 70, 80, 90};
+static int g_kemar_count[kNumElev];
+
+int jf_kemar_grid(jf_hrtf_grid *out) {
+    if (!out) return JF_ERR_ARG;
+    const RingTable &k = ring_table();
+    for (int r = 0; r < kNumElev; r++) g_kemar_count[r] = k.offset[r + 1] - k.offset[r];  // (the same values whoever writes them)
+    out->n_rings = kNumElev;
+    out->ring_elevation = kKemarEle;
+    out->ring_count = g_kemar_count;
+    out->ring_step = kemar_ring_steps();
+    return JF_OK;
+}
+
+static int grid_table(const jf_hrtf_grid *grid, RingTable *rt) {
+    if (!grid) return fail(nullptr, JF_ERR_ARG, "null grid");
+    std::string err;
+    const int rc = host_grid_table(grid->n_rings, grid->ring_elevation, grid->ring_count, grid->ring_step, rt, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+}
+
+int jf_grid_rows(const jf_hrtf_grid *grid) {
+    return jf_guard([&]() -> int {
+    RingTable rt;
+    const int rc = grid_table(grid, &rt);
+    return rc ? rc : rt.n_rows;
+    });
+}
+
+int jf_grid_interpolation(const jf_hrtf_grid *grid, float ele, float azi, int idx[4], float omegas[6]) {
+    return jf_guard([&]() -> int {
+    if (!idx || !omegas) return JF_ERR_ARG;
+    RingTable rt;
+    const int rc = grid_table(grid, &rt);
+    return rc ? rc : host_grid_interpolation(rt, ele, azi, idx, omegas);
+    });
+}
+
+int jf_grid_pick(const jf_hrtf_grid *grid, float ele, float azi) {
+    return jf_guard([&]() -> int {
+    RingTable rt;
+    const int rc = grid_table(grid, &rt);
+    if (rc) return rc;
+    if (!(ele >= -1.0e6f && ele <= 1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
+    return host_grid_pick(rt, ele, azi);
+    });
+}
+
+int jf_engine_create_grid(const jf_config *cfg, const jf_hrtf_grid *grid, const float *hrir, int taps, jf_engine **out) {
+    return jf_guard([&]() -> int {
+    if (out) *out = nullptr;
+    RingTable rt;
+    const int rc = grid_table(grid, &rt);
+    if (rc) return rc;
+    return create_engine(cfg, &rt, hrir, taps, out);
     });
 }
 
@@ -904,7 +973,7 @@ int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_eng
     std::string err;
     int rc = load_hrir_dir(hrir_dir, &hrir, &taps, &err);
     if (rc) return fail(nullptr, rc, err);
-    return create_engine(cfg, hrir.data(), taps, out);
+    return create_engine(cfg, nullptr, hrir.data(), taps, out);
     });
 }
 
@@ -915,6 +984,7 @@ const char *jf_last_error(const jf_engine *e) { return e ? e->err.c_str() : g_cr
 int jf_frames_per_buffer(const jf_engine *e) { return e ? e->B : JF_ERR_ARG; }
 int jf_pad_len(const jf_engine *e) { return e ? kN : JF_ERR_ARG; }
 int jf_num_sources(const jf_engine *e) { return e ? e->S : JF_ERR_ARG; }
+int jf_table_rows(const jf_engine *e) { return e ? e->rt.n_rows : JF_ERR_ARG; }
 
 int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     return jf_guard([&]() -> int {
@@ -963,7 +1033,7 @@ int jf_source_set_cartesian(jf_engine *e, int src, float x, float y, float z) {
     float rec[5], r;
     int rc = host_from_cartesian(x, y, z, rec, &r);
     if (rc) return fail(e, rc, "zero or non-finite coordinates");
-    if (!(rec[0] > -50.0f && rec[0] <= 90.0f)) return fail(e, JF_ERR_RANGE, "elevation outside (-50, 90]");
+    if (!elevation_ok(e, rec[0])) return fail(e, JF_ERR_RANGE, elevation_msg(e));
     std::lock_guard<std::mutex> lk(e->pos_mu);
     e->pos[src] = HostPos{rec[0], rec[1], r, x, y, z};
     return JF_OK;
@@ -975,7 +1045,7 @@ int jf_source_set_spherical(jf_engine *e, int src, float ele, float azi, float r
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
     float rec[5];
     host_from_spherical(ele, azi, r, rec);
-    if (!(rec[0] > -50.0f && rec[0] <= 90.0f)) return fail(e, JF_ERR_RANGE, "elevation outside (-50, 90]");
+    if (!elevation_ok(e, rec[0])) return fail(e, JF_ERR_RANGE, elevation_msg(e));
     if (!(fabsf(rec[1]) < 1.0e6f) || !(fabsf(r) < 3.0e38f)) return fail(e, JF_ERR_RANGE, "non-finite azimuth or radius");
     std::lock_guard<std::mutex> lk(e->pos_mu);
     e->pos[src] = HostPos{rec[0], rec[1], r, rec[2], rec[3], rec[4]};
@@ -1381,7 +1451,7 @@ int jf_batch_upload_positions(jf_engine *e, int total_blocks, const float *posit
         for (int s = 0; s < e->S; s++) {
             const float *p = positions + 5 * (size_t)s;
             const bool ok = p[0] > -1.0e6f && p[0] < 1.0e6f && p[1] > -1.0e6f && p[1] < 1.0e6f;
-            key[s] = {want_sorted && ok ? host_pick_hrtf(p[0], p[1]) : 0, s};
+            key[s] = {want_sorted && ok ? host_grid_pick(e->rt, p[0], p[1]) : 0, s};
         }
         std::stable_sort(key.begin(), key.end());
         for (int s = 0; s < e->S; s++) e->order[s] = key[s].second;
@@ -1645,11 +1715,11 @@ int jf_debug_count_desc_flags(jf_engine *e, int n_items, int mask) {
 int jf_debug_read_table_rows(jf_engine *e, int first_row, int n, float *out) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
-    if (e && out && n > 0 && first_row >= 0 && first_row + (long long)n > kNumHrtf) {  // pre-interpolated rows: built on demand
+    if (e && out && n > 0 && first_row >= 0 && first_row + (long long)n > e->rt.n_rows) {  // pre-interpolated rows: built on demand
         const int rc = ensure_interp_rows(e);
         if (rc) return rc;
     }
-    const int total = kNumHrtf + (e && e->interp_built ? kInterpRows : 0);
+    const int total = e ? e->rt.n_rows + (e->interp_built ? kInterpRows : 0) : 0;
     if (!e || !out || n <= 0 || first_row < 0 || first_row > total - n) return fail(e, JF_ERR_ARG, "rows outside the table");
     JF_HIP(e, hipStreamSynchronize(e->stream));
     JF_HIP(e, hipMemcpy(out, e->d_htab + (size_t)first_row * 512, sizeof(float4) * 512 * (size_t)n, hipMemcpyDeviceToHost));
@@ -1694,10 +1764,10 @@ int jf_debug_read_table(jf_engine *e, float *out) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
     if (!e || !out) return JF_ERR_ARG;
-    std::vector<float4> h((size_t)kNumHrtf * 512);
+    std::vector<float4> h((size_t)e->rt.n_rows * 512);
     JF_HIP(e, hipStreamSynchronize(e->stream));
     JF_HIP(e, hipMemcpy(h.data(), e->d_htab, sizeof(float4) * h.size(), hipMemcpyDeviceToHost));
-    for (int j = 0; j < kNumHrtf; j++) {
+    for (int j = 0; j < e->rt.n_rows; j++) {
         float *L = out + ((size_t)j * 2 + 0) * kNc * 2;
         float *R = out + ((size_t)j * 2 + 1) * kNc * 2;
         const float4 *row = h.data() + (size_t)j * 512;
@@ -1735,8 +1805,7 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
         JF_HIP(e, hipMalloc(&d_n, sizeof(int) * n));
         JF_HIP(e, h2d(e, d_e, ele, sizeof(float) * n));
         JF_HIP(e, h2d(e, d_a, azi, sizeof(float) * n));
-        JF_HIP(e, launch_interp_debug(e->rt, d_e, d_a, d_r, d_w, d_n, n,
-                                      (e->cfg.flags & JF_FLAG_CORRECTED_INTERPOLATION) ? 1 : 0, e->stream));
+        JF_HIP(e, launch_interp_debug(e->rt, d_e, d_a, d_r, d_w, d_n, n, corrected_rule(e) ? 1 : 0, e->stream));
         JF_HIP(e, hipStreamSynchronize(e->stream));
         JF_HIP(e, hipMemcpy(rows, d_r, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
         JF_HIP(e, hipMemcpy(weights, d_w, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));

@@ -28,9 +28,13 @@ struct Rings {
     int pos_azi[kNumHrtf];
     Rings() {
         int j = 0;
+        rt = RingTable{};
+        rt.n_rings = kNumElev;
+        rt.kemar = 1;
         rt.offset[0] = 0;
         for (int e = 0; e < kNumElev; e++) {
             rt.inc[e] = kAziInc[e];
+            rt.ele[e] = (float)kElevPos[e];
             // the reference steps a float azimuth; ring sizes follow from that
             for (float azi = 0; azi < 360; azi += kAziInc[e]) {
                 if (j < kNumHrtf) {
@@ -41,6 +45,8 @@ struct Rings {
             }
             rt.offset[e + 1] = j;
         }
+        for (int e = kNumElev; e < kMaxRings; e++) rt.offset[e + 1] = j;
+        rt.n_rows = j;
         rt.pick = nullptr;
     }
 };
@@ -51,6 +57,69 @@ const Rings &rings() {
 }  // namespace
 
 const RingTable &ring_table() { return rings().rt; }
+const float *kemar_ring_steps() { return kAziInc; }
+
+// include/jefferson.h: jf_hrtf_grid -> the table the kernels and the host rules work from.  The reference's own grid
+// (14 rings at -40 .. 90, its counts, its rounded steps) is recognised and becomes ring_table() itself (kemar = 1: the
+// reference's rule applies by default); anything else is a general grid.
+int host_grid_table(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step, RingTable *out,
+                    std::string *err) {
+    auto bad = [&](const char *m) {
+        if (err) *err = m;
+        return JF_ERR_ARG;
+    };
+    if (!ring_ele || !ring_count || !out) return bad("null grid description");
+    if (n_rings < 1 || n_rings > kMaxRings) return bad("a grid has 1 .. JF_MAX_RINGS elevation rings");
+    RingTable rt{};
+    rt.n_rings = n_rings;
+    long long rows = 0;
+    for (int r = 0; r < n_rings; r++) {
+        const float el = ring_ele[r];
+        if (!(el >= -90.0f && el <= 90.0f)) return bad("ring elevations lie in [-90, 90] degrees");
+        if (r > 0 && !(el > ring_ele[r - 1])) return bad("ring elevations must ascend");
+        const int n = ring_count[r];
+        if (n < 1 || n > 3600) return bad("a ring has 1 .. 3600 measurements");
+        float step = ring_step ? ring_step[r] : 360.0f / (float)n;
+        if (n == 1 && !(step >= 360.0f)) step = 361.0f;  // one measurement: it is the ring (hrtf_signals.cu:8 writes 361 too)
+        // n steps must cover the circle and n - 1 must not: the ring's last measurement lies below 360 degrees
+        if (!(step > 0.0f) || (n > 1 && (!((float)(n - 1) * step < 360.0f) || !((float)n * step >= 359.0f))))
+            return bad("a ring's azimuth step does not fit its count (measurement i sits at i * step, i < count, below 360)");
+        rt.ele[r] = el;
+        rt.inc[r] = step;
+        rt.offset[r] = (int)rows;
+        rows += n;
+    }
+    if (rows > 32000) return bad("more than 32000 table rows");
+    for (int r = n_rings; r <= kMaxRings; r++) rt.offset[r] = (int)rows;
+    rt.n_rows = (int)rows;
+    const RingTable &k = ring_table();
+    bool same = n_rings == k.n_rings;
+    for (int r = 0; same && r < n_rings; r++)
+        same = rt.ele[r] == k.ele[r] && rt.inc[r] == k.inc[r] && rt.offset[r + 1] == k.offset[r + 1];
+    *out = same ? k : rt;
+    return JF_OK;
+}
+
+// The nearest measurement of a general grid (twin of dev_grid_pick).
+int host_grid_pick(const RingTable &rt, float ele, float azi) {
+    if (rt.kemar) return host_pick_hrtf(ele, azi);
+    float dmin = 1e37f;
+    int ring = 0;
+    for (int r = 0; r < rt.n_rings; r++) {
+        float d = ele - rt.ele[r];
+        if (d < 0) d = -d;
+        if (d < dmin) {
+            dmin = d;
+            ring = r;
+        }
+    }
+    const int n = rt.offset[ring + 1] - rt.offset[ring];
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    int i = (int)floorf(a / rt.inc[ring] + 0.5f);
+    if (i >= n) i = 0;
+    return rt.offset[ring] + i;
+}
 
 void table_position(int j, int *ele, int *azi) {
     *ele = rings().pos_ele[j];
@@ -117,17 +186,35 @@ int host_interpolation(float ele, float azi, int idx[4], float omegas[6]) {
 
 // The corrected rule (include/jefferson.h JF_FLAG_CORRECTED_INTERPOLATION); twin of dev_interp_corrected.
 int host_interpolation_corrected(float ele, float azi, int idx[4], float omegas[6]) {
+    return host_grid_interpolation(ring_table(), ele, azi, idx, omegas);
+}
+
+// ... in its general form, for any grid of rings (twin of dev_interp_corrected, which says why the reference's grid keeps
+// its closed form: the same bits either way)
+int host_grid_interpolation(const RingTable &rt, float ele, float azi, int idx[4], float omegas[6]) {
     if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return JF_ERR_RANGE;
-    const RingTable &rt = ring_table();
-    if (ele < -40.0f) ele = -40.0f;
     float a = azi - 360.0f * floorf(azi / 360.0f);
     if (!(a < 360.0f)) a = 0.0f;
-    const float q = floorf(ele / 10.0f);
-    const float phi0 = 10.0f * q;
+    int r0;
+    float phi0, span;
+    if (rt.kemar) {
+        if (ele < -40.0f) ele = -40.0f;
+        const float q = floorf(ele / 10.0f);
+        phi0 = 10.0f * q;
+        r0 = (int)q + 4;
+        span = 10.0f;
+    } else {
+        const int last = rt.n_rings - 1;
+        if (ele < rt.ele[0]) ele = rt.ele[0];
+        if (ele > rt.ele[last]) ele = rt.ele[last];
+        r0 = 0;
+        for (int r = 1; r <= last; r++) r0 = rt.ele[r] <= ele ? r : r0;
+        phi0 = rt.ele[r0];
+        span = rt.ele[r0 < last ? r0 + 1 : r0] - phi0;
+    }
     const bool on_ring = ele == phi0;
-    const int r0 = (int)q + 4;
     const int ring[2] = {r0, on_ring ? r0 : r0 + 1};
-    const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+    const float omE = on_ring ? 0.0f : (ele - phi0) / span;
     for (int j = 0; j < 2; j++) {
         const int r = ring[j];
         const float d = rt.inc[r];

@@ -19,6 +19,13 @@ void table_position(int j, int *ele, int *azi);
 int host_pick_hrtf(float obj_ele, float obj_azi);                             // hrtf_signals.cu:20-51
 int host_interpolation(float ele, float azi, int idx[4], float omegas[6]);    // SoundSource.cu:65-105
 int host_interpolation_corrected(float ele, float azi, int idx[4], float omegas[6]);  // JF_FLAG_CORRECTED_INTERPOLATION
+// any grid of elevation rings (include/jefferson.h: jf_hrtf_grid): its table, the corrected rule in its general form, the
+// nearest measurement
+const float *kemar_ring_steps();  // hrtf_signals.cu:8
+int host_grid_table(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step, RingTable *out,
+                    std::string *err);
+int host_grid_interpolation(const RingTable &rt, float ele, float azi, int idx[4], float omegas[6]);
+int host_grid_pick(const RingTable &rt, float ele, float azi);
 void host_from_spherical(float ele, float azi, float r, float out[5]);        // SoundSource.cu:41-54
 int host_from_cartesian(float x, float y, float z, float out[5], float *r);   // SoundSource.cu:20-36
 

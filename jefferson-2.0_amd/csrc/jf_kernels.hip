@@ -1097,14 +1097,10 @@ __global__ JF_FUSED_BOUNDS void fused_pair_kernel(const FusedParams Pin) {
         P.hist_in = q->hist_in, P.hist_out = q->hist_out, P.pos = q->pos, P.partial = q->partial;
         P.S = q->S, P.K = q->K, P.B = q->B, P.G = q->G, P.mode = q->mode, P.order = q->order, P.err = q->err;
         P.n_pair_wgs = q->n_pair_wgs, P.prep_pos = q->prep_pos, P.prep_desc = q->prep_desc, P.prep_K = q->prep_K;
-        P.prep_canon = q->prep_canon, P.rt.pick = q->rt.pick;
-#pragma unroll
-        for (int i = 0; i < kNumElev + 1; i++) P.rt.offset[i] = q->rt.offset[i];
-#pragma unroll
-        for (int i = 0; i < kNumElev; i++) P.rt.inc[i] = q->rt.inc[i];
-        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable) &&
-                          sizeof(RingTable) == (2 * kNumElev + 1) * 4 + 4 + 8,
-                      "a field was added to FusedParams / RingTable: reload it here too");
+        P.prep_canon = q->prep_canon;
+        // (P.rt is not reloaded: nothing behind a reload reads it -- the workgroups that build descriptors take Pin.rt)
+        static_assert(sizeof(FusedParams) == 10 * 8 + 5 * 4 + 4 + 2 * 8 + 4 + 4 + 2 * 8 + 2 * 4 + sizeof(RingTable),
+                      "a field was added to FusedParams: reload it here too");
     };
 #else
     const FusedParams &P = Pin;
@@ -1537,8 +1533,30 @@ JF_DEV int dev_pick_int(const RingTable &rt, int ring, int th) {
     return dev_pick_azi(rt, ring, (float)th);
 }
 
+// The nearest measurement of a grid that is not the reference's (jf_engine_create_grid; twin of host_grid_pick): the ring
+// whose elevation is nearest (the lower one on a tie), on it the azimuth nearest on the circle.
+JF_DEV int dev_grid_pick(const RingTable &rt, float ele, float azi) {
+    float dmin = 1e37f;
+    int ring = 0;
+    for (int r = 0; r < rt.n_rings; r++) {
+        float d = ele - rt.ele[r];
+        d = d > 0 ? d : -d;
+        if (d < dmin) {
+            dmin = d;
+            ring = r;
+        }
+    }
+    const int n = rt.offset[ring + 1] - rt.offset[ring];
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    int i = (int)floorf(a / rt.inc[ring] + 0.5f);
+    if (i >= n) i = 0;  // nearer to 360 = the ring's first entry
+    return rt.offset[ring] + i;
+}
+
 // hrtf_signals.cu:20-51 in full: nearest elevation ring, then nearest azimuth on it
 JF_DEV int dev_pick_hrtf(const RingTable &rt, float obj_ele, float obj_azi) {
+    if (!rt.kemar) return dev_grid_pick(rt, obj_ele, obj_azi);
     obj_ele = roundf(obj_ele / 10) * 10;
     float dmin = 1e37f;
     int ring = 0;
@@ -1558,17 +1576,34 @@ JF_DEV int dev_pick_hrtf(const RingTable &rt, float obj_ele, float obj_azi) {
 // true floor of the elevation, azimuth folded into [0, 360) with a ring's last interval wrapping to its first
 // entry, float azimuths (a ring's two weights sum to 1), elevations below the lowest ring clamped to it.
 // Same index order and weight meaning as the reference's rule.  Float32 step by step as in the oracles.
+// In its general form (any grid of rings, include/jefferson.h: jf_hrtf_grid): the ring pair is the one whose elevations
+// enclose the position (elevations outside the grid clamped to its first / last ring), the elevation weight is linear between
+// them.  For the reference's grid the closed form below gives the same ring, the same phi0 and the same divisor 10 -- bit for
+// bit the same indices and weights (tests/test_abi.py compares the two on the host, tests/test_gpu_grid.py on the GPU).
 JF_DEV bool dev_interp_corrected(const RingTable &rt, float ele, float azi, int h[4], float om[6]) {
     if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return false;
-    if (ele < -40.0f) ele = -40.0f;
     float a = azi - 360.0f * floorf(azi / 360.0f);
     if (!(a < 360.0f)) a = 0.0f;
-    const float q = floorf(ele / 10.0f);
-    const float phi0 = 10.0f * q;
+    int r0;
+    float phi0, span;
+    if (rt.kemar) {
+        if (ele < -40.0f) ele = -40.0f;
+        const float q = floorf(ele / 10.0f);
+        phi0 = 10.0f * q;
+        r0 = (int)q + 4;
+        span = 10.0f;
+    } else {
+        const int last = rt.n_rings - 1;
+        if (ele < rt.ele[0]) ele = rt.ele[0];
+        if (ele > rt.ele[last]) ele = rt.ele[last];
+        r0 = 0;
+        for (int r = 1; r <= last; r++) r0 = rt.ele[r] <= ele ? r : r0;
+        phi0 = rt.ele[r0];
+        span = rt.ele[r0 < last ? r0 + 1 : r0] - phi0;
+    }
     const bool on_ring = ele == phi0;
-    const int r0 = (int)q + 4;
     const int ring[2] = {r0, on_ring ? r0 : r0 + 1};
-    const float omE = on_ring ? 0.0f : (ele - phi0) / 10.0f;
+    const float omE = on_ring ? 0.0f : (ele - phi0) / span;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int r = ring[j];
@@ -1596,7 +1631,7 @@ JF_DEV int dev_flatten_terms(int h0, int h1, int h2, int h3, float omegaA, float
                              float omegaE, float omegaF, int rows[4], float w[4]);
 
 JF_DEV int dev_interp_terms(const RingTable &rt, float ele, float azi, int rows[4], float w[4], bool corrected = false) {
-    if (corrected) {
+    if (corrected || !rt.kemar) {  // (the reference's rule is a rule of the reference's grid)
         int h[4];
         float om[6];
         if (!dev_interp_corrected(rt, ele, azi, h, om)) return 0;
@@ -1759,7 +1794,7 @@ JF_DEV void prep_body(const RingTable &rt, int mode, const float *__restrict__ p
               floorf(a_in) == a_in;
         int n_in;
         if (pre) {
-            rows[0] = rows[1] = rows[2] = rows[3] = kNumHrtf + ((int)e_in - kInterpEleMin) * kInterpAzi + (int)a_in;
+            rows[0] = rows[1] = rows[2] = rows[3] = rt.n_rows + ((int)e_in - kInterpEleMin) * kInterpAzi + (int)a_in;
             w[0] = 1.0f;
             n_in = 1;
         } else {
@@ -2047,7 +2082,7 @@ __global__ __launch_bounds__(64) void table_build_kernel(const float *__restrict
             make_float4(0.5f * Xe[0][q].x, 0.5f * Xe[0][q].y, 0.5f * Xe[1][q].x, 0.5f * Xe[1][q].y);
 }
 
-// The pre-interpolated rows (jf_device.h: htab): row 710 + (ele + 40) 360 + azi = sum_t w_t H[row_t] for the whole-degree
+// The pre-interpolated rows (jf_device.h: htab): row n_rows + (ele + 40) 360 + azi = sum_t w_t H[row_t] for the whole-degree
 // position (ele, azi) -- the index/weight rule itself (dev_interp_terms, SoundSource.cu:65-105) and the half-filters' own
 // weighting (weighted_ears), one wave per row.  What GPUSoundSource.cu:118-292 recomputes for every block and source
 // (four scaled products summed by atomicAdd) is computed here once per position the setters can latch.
@@ -2067,7 +2102,7 @@ __global__ __launch_bounds__(64) void table_interp_build_kernel(const RingTable 
         const float f = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[t])));
         wv[t] = c2{f, f};
     }
-    float4 *out = htab + (size_t)(kNumHrtf + r) * 512 + lane;
+    float4 *out = htab + (size_t)(rt.n_rows + r) * 512 + lane;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         c2 heL = c2{0.f, 0.f}, heR = c2{0.f, 0.f};  // n == 0 (no such position inside the table's range: tested): zeros
@@ -2187,9 +2222,9 @@ hipError_t launch_stage_debug(const RingTable &rt, int mode, const float *d_pos,
     return hipGetLastError();
 }
 
-hipError_t launch_table_build(const float *d_hrir, int taps, const float2 *d_tw, float4 *d_htab,
+hipError_t launch_table_build(const float *d_hrir, int n_rows, int taps, const float2 *d_tw, float4 *d_htab,
                               hipStream_t st) {
-    hipLaunchKernelGGL(table_build_kernel, dim3(kNumHrtf), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
+    hipLaunchKernelGGL(table_build_kernel, dim3(n_rows), dim3(64), 0, st, d_hrir, taps, d_tw, d_htab);
     return hipGetLastError();
 }
 

@@ -175,6 +175,112 @@ int jfo_interp_corrected(float ele, float azi, int hrtf_indices[4], float omegas
     return 0;
 }
 
+/* ---- any grid of elevation rings (jf_oracle.h) ---- */
+typedef struct {
+    int n_rings, n_rows;
+    int offset[JFO_MAX_RINGS + 1];
+    float step[JFO_MAX_RINGS], ele[JFO_MAX_RINGS];
+} jfo_grid;
+
+static int grid_fill(jfo_grid *g, int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step) {
+    if (n_rings < 1 || n_rings > JFO_MAX_RINGS || !ring_ele || !ring_count) return -1;
+    g->n_rings = n_rings;
+    g->offset[0] = 0;
+    for (int r = 0; r < n_rings; r++) {
+        if (ring_count[r] < 1 || (r > 0 && !(ring_ele[r] > ring_ele[r - 1]))) return -1;
+        g->ele[r] = ring_ele[r];
+        g->step[r] = ring_step ? ring_step[r] : 360.0f / (float)ring_count[r];
+        if (ring_count[r] == 1 && !(g->step[r] >= 360.0f)) g->step[r] = 361.0f; /* the pole: one measurement is the ring */
+        g->offset[r + 1] = g->offset[r] + ring_count[r];
+    }
+    g->n_rows = g->offset[n_rings];
+    return 0;
+}
+
+int jfo_grid_rows(int n_rings, const int *ring_count) {
+    int n = 0;
+    for (int r = 0; r < n_rings; r++) n += ring_count[r];
+    return n;
+}
+
+void jfo_kemar_grid(float ring_ele[JFO_NUM_ELEV], int ring_count[JFO_NUM_ELEV], float ring_step[JFO_NUM_ELEV]) {
+    build_offsets();
+    for (int r = 0; r < JFO_NUM_ELEV; r++) {
+        ring_ele[r] = (float)elevation_pos[r];
+        ring_count[r] = azimuth_offset[r + 1] - azimuth_offset[r];
+        ring_step[r] = azimuth_inc[r];
+    }
+}
+
+/* Same index order and weight meaning as jfo_interp_corrected; float32 step by step. */
+static int grid_interp(const jfo_grid *g, float ele, float azi, int hrtf_indices[4], float omegas[6]) {
+    if (!(ele <= 90.0f) || !(ele > -1.0e6f) || !(azi > -1.0e6f && azi < 1.0e6f)) return -1;
+    const int last = g->n_rings - 1;
+    if (ele < g->ele[0]) ele = g->ele[0];
+    if (ele > g->ele[last]) ele = g->ele[last];
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    int r0 = 0;
+    while (r0 < last && g->ele[r0 + 1] <= ele) r0++; /* the highest ring at or below the position */
+    const float phi0 = g->ele[r0];
+    const int on_ring = (ele == phi0);
+    const int r1 = on_ring ? r0 : r0 + 1;
+    const float omE = on_ring ? 0.0f : (ele - phi0) / (g->ele[r0 + 1] - phi0);
+    const int ring[2] = {r0, r1};
+    for (int j = 0; j < 2; j++) {
+        const int r = ring[j];
+        const float d = g->step[r];
+        const int n = g->offset[r + 1] - g->offset[r];
+        int i0 = (int)floorf(a / d);
+        if (i0 > n - 1) i0 = n - 1;
+        float wa = (a - (float)i0 * d) / d;
+        if (wa < 0.0f) wa = 0.0f;
+        if (wa > 1.0f) wa = 1.0f;
+        if (n == 1) wa = 0.0f;
+        int i1 = i0 + 1 == n ? 0 : i0 + 1;
+        if (wa == 0.0f) i1 = i0;
+        hrtf_indices[2 * j] = g->offset[r] + i0;
+        hrtf_indices[2 * j + 1] = g->offset[r] + i1;
+        omegas[2 * j] = wa;
+        omegas[2 * j + 1] = 1.0f - wa;
+    }
+    omegas[4] = omE;
+    omegas[5] = 1.0f - omE;
+    return 0;
+}
+
+static int grid_pick(const jfo_grid *g, float ele, float azi) {
+    int ring = 0;
+    float dmin = 1e37f;
+    for (int r = 0; r < g->n_rings; r++) {
+        float d = ele - g->ele[r];
+        d = d > 0 ? d : -d;
+        if (d < dmin) {
+            dmin = d;
+            ring = r;
+        }
+    }
+    const int n = g->offset[ring + 1] - g->offset[ring];
+    float a = azi - 360.0f * floorf(azi / 360.0f);
+    if (!(a < 360.0f)) a = 0.0f;
+    int i = (int)floorf(a / g->step[ring] + 0.5f);
+    if (i >= n) i = 0;
+    return g->offset[ring] + i;
+}
+
+int jfo_grid_interp(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step,
+                    float ele, float azi, int idx[4], float omegas[6]) {
+    jfo_grid g;
+    if (grid_fill(&g, n_rings, ring_ele, ring_count, ring_step)) return -2;
+    return grid_interp(&g, ele, azi, idx, omegas);
+}
+
+int jfo_grid_pick(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step, float ele, float azi) {
+    jfo_grid g;
+    if (grid_fill(&g, n_rings, ring_ele, ring_count, ring_step)) return -2;
+    return grid_pick(&g, ele, azi);
+}
+
 /* GPUSoundSource.cu:301-316 (the CUDA path's predicate; CPUSoundSource.cpp:262
  * tests only idx0==idx2 for case 2 -- SURVEY.md App. C#6). */
 int jfo_case(const int h[4]) {
@@ -417,7 +523,9 @@ typedef struct {
 struct jfo_engine {
     int B, L, N, Nc, n_sources;
     int mode; /* bit 0: 0 = FD_COMPLEX (interpolated), 1 = FD_BASIC (nearest HRTF); bit 1: corrected index/weight rule */
-    float *table; /* [710][2][Nc][2] */
+    float *table; /* [710][2][Nc][2] ([grid.n_rows] with a grid of its own) */
+    int has_grid; /* jfo_create_grid: the grid's rule and pick in every mode */
+    jfo_grid grid;
     jfo_source *src;
     jfo_plan ph, pf;
     /* reverb stage: P partitions of B taps, spectra of [h_p, 0] (2B-point r2c, B + 1 bins, planar), pre-scaled by
@@ -427,7 +535,25 @@ struct jfo_engine {
     jfo_plan rv_ph, rv_pf; /* n = B and n = 2B */
 };
 
+static jfo_engine *create_rows(int B, int hrtf_len, int n_sources, int n_rows, const float *hrir, int taps);
+
 jfo_engine *jfo_create(int B, int hrtf_len, int n_sources, const float *hrir, int taps) {
+    return create_rows(B, hrtf_len, n_sources, JFO_NUM_HRTF, hrir, taps);
+}
+
+jfo_engine *jfo_create_grid(int B, int hrtf_len, int n_sources, int n_rings, const float *ring_ele,
+                            const int *ring_count, const float *ring_step, const float *hrir, int taps) {
+    jfo_grid g;
+    if (grid_fill(&g, n_rings, ring_ele, ring_count, ring_step)) return NULL;
+    jfo_engine *e = create_rows(B, hrtf_len, n_sources, g.n_rows, hrir, taps);
+    if (e) {
+        e->has_grid = 1;
+        e->grid = g;
+    }
+    return e;
+}
+
+static jfo_engine *create_rows(int B, int hrtf_len, int n_sources, int n_rows, const float *hrir, int taps) {
     if (B <= 0 || hrtf_len <= 0 || n_sources <= 0 || taps > hrtf_len) return NULL;
     jfo_engine *e = (jfo_engine *)calloc(1, sizeof(*e));
     e->B = B;
@@ -438,8 +564,8 @@ jfo_engine *jfo_create(int B, int hrtf_len, int n_sources, const float *hrir, in
     e->n_sources = n_sources;
     plan_init(&e->ph, e->N / 2);
     plan_init(&e->pf, e->N);
-    e->table = (float *)malloc(sizeof(float) * (size_t)JFO_NUM_HRTF * 2 * e->Nc * 2);
-    jfo_build_table(hrir, JFO_NUM_HRTF, taps, e->N, e->table);
+    e->table = (float *)malloc(sizeof(float) * (size_t)n_rows * 2 * e->Nc * 2);
+    jfo_build_table(hrir, n_rows, taps, e->N, e->table);
     e->src = (jfo_source *)calloc((size_t)n_sources, sizeof(jfo_source));
     for (int s = 0; s < n_sources; s++) {
         jfo_source *q = &e->src[s];
@@ -781,7 +907,7 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
     if (e->mode & 1) {
         /* CPU_FD_BASIC (CPUSoundSource.cpp:50-52,113-142): nearest table row, no interpolation,
          * no distance factor, no crossfade */
-        rows[0] = jfo_pick_hrtf(ele, azi);
+        rows[0] = e->has_grid ? grid_pick(&e->grid, ele, azi) : jfo_pick_hrtf(ele, azi);
         w[0] = 1.0f;
         for (int k = 0; k < Nc; k++) {
             D[2 * k] = 1.0f;
@@ -795,9 +921,14 @@ static int source_block(const jfo_engine *e, jfo_source *q, float ele, float azi
         return 0;
     }
     int (*rule)(float, float, int *, float *) = (e->mode & 2) ? jfo_interp_corrected : jfo_interp;
-    if (rule(ele, azi, idx, om)) rc = -1;
     int xfade = (q->old_azi != azi || q->old_ele != ele);
-    if (xfade && rule(q->old_ele, q->old_azi, oidx, oom)) rc = -1;
+    if (e->has_grid) {
+        if (grid_interp(&e->grid, ele, azi, idx, om)) rc = -1;
+        if (xfade && grid_interp(&e->grid, q->old_ele, q->old_azi, oidx, oom)) rc = -1;
+    } else {
+        if (rule(ele, azi, idx, om)) rc = -1;
+        if (xfade && rule(q->old_ele, q->old_azi, oidx, oom)) rc = -1;
+    }
     if (rc == 0) {
         nt = jfo_terms(idx, om, rows, w);
         if (xfade) ont = jfo_terms(oidx, oom, orows, ow);

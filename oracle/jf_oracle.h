@@ -53,6 +53,18 @@ int jfo_pick_hrtf(float obj_ele, float obj_azi);
 int jfo_interp(float ele, float azi, int idx[4], float omegas[6]);
 /* the corrected rule behind the drop-in's JF_FLAG_CORRECTED_INTERPOLATION (not in the reference) */
 int jfo_interp_corrected(float ele, float azi, int idx[4], float omegas[6]);
+/* The corrected rule for ANY grid of elevation rings (the drop-in's jf_engine_create_grid; the reference hard-codes KEMAR's
+ * rings, hrtf_signals.cu:7-12, and lists other HRTF sets as a TODO, FuturePlans.md:21): ring r at ring_ele[r] degrees
+ * (ascending) with ring_count[r] measurements at azimuths i * ring_step[r] (ring_step NULL: 360 / count); rows ring by ring.
+ * Elevations outside the grid are clamped to its first / last ring; with KEMAR's grid and steps this IS jfo_interp_corrected
+ * (tested bit for bit).  jfo_grid_pick: the nearest ring's nearest measurement (what FD_BASIC plays on such a grid). */
+#define JFO_MAX_RINGS 40
+int jfo_grid_rows(int n_rings, const int *ring_count);
+int jfo_grid_interp(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step,
+                    float ele, float azi, int idx[4], float omegas[6]);
+int jfo_grid_pick(int n_rings, const float *ring_ele, const int *ring_count, const float *ring_step, float ele, float azi);
+/* KEMAR as such a grid: elevations, counts and the reference's rounded steps (hrtf_signals.cu:7-10) */
+void jfo_kemar_grid(float ring_ele[JFO_NUM_ELEV], int ring_count[JFO_NUM_ELEV], float ring_step[JFO_NUM_ELEV]);
 /* GPUSoundSource.cu:301-316 predicate -> 1..4 */
 int jfo_case(const int idx[4]);
 /* Flatten (idx, omegas) into <=4 (row, weight) terms in accumulation order
@@ -76,6 +88,10 @@ void jfo_irfft(const float *X, int N, float *y /* N */);
 /* Engine = Data + sources (DataTag.cuh:9-17, SoundSource.cuh, CPUSoundSource.h). */
 jfo_engine *jfo_create(int frames_per_buffer, int hrtf_len, int n_sources,
                        const float *hrir /* [710][2][taps] */, int taps);
+/* the same engine on a grid of its own: hrir [jfo_grid_rows][2][taps]; the grid's rule and pick replace KEMAR's in every
+ * mode (mode bit 1 is then implied) */
+jfo_engine *jfo_create_grid(int frames_per_buffer, int hrtf_len, int n_sources, int n_rings, const float *ring_ele,
+                            const int *ring_count, const float *ring_step, const float *hrir, int taps);
 void jfo_destroy(jfo_engine *e);
 int jfo_pad_len(const jfo_engine *e);
 /* Data::type (DataTag.cuh:16): 0 = *_FD_COMPLEX, 1 = *_FD_BASIC (CPUSoundSource.cpp:113-142) */

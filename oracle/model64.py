@@ -162,6 +162,76 @@ def interp_corrected(ele, azi):
     return idx, om
 
 
+class Grid:
+    """Any grid of elevation rings (jf_oracle.h: jfo_grid_interp; the drop-in's jf_engine_create_grid): ring r at ele[r] degrees
+    (ascending) with count[r] measurements at azimuths i * step[r] (step None: 360 / count); rows ring by ring."""
+
+    def __init__(self, ring_ele, ring_count, ring_step=None):
+        self.ele = [f32(v) for v in ring_ele]
+        self.count = [int(v) for v in ring_count]
+        self.step = [f32(f32(360) / f32(n)) if ring_step is None else f32(ring_step[r]) for r, n in enumerate(self.count)]
+        for r, n in enumerate(self.count):
+            if n == 1 and not self.step[r] >= 360:
+                self.step[r] = f32(361)
+        self.offset = [0]
+        for n in self.count:
+            self.offset.append(self.offset[-1] + n)
+        self.n_rows = self.offset[-1]
+
+    @staticmethod
+    def kemar():
+        return Grid(ELEVATION_POS, [AZIMUTH_OFFSET[i + 1] - AZIMUTH_OFFSET[i] for i in range(NUM_ELEV)], AZIMUTH_INC)
+
+    def interp(self, ele, azi):
+        """The corrected rule in its general form; float32 step by step like jfo_grid_interp."""
+        ele, azi = f32(ele), f32(azi)
+        if not (ele <= 90) or not (ele > -1e6) or not (-1e6 < azi < 1e6):
+            return None
+        last = len(self.ele) - 1
+        ele = max(ele, self.ele[0])
+        ele = min(ele, self.ele[last])
+        a = f32(azi - f32(f32(360) * f32(np.floor(f32(azi / f32(360))))))
+        if not a < 360:
+            a = f32(0)
+        r0 = 0
+        while r0 < last and self.ele[r0 + 1] <= ele:
+            r0 += 1
+        phi0 = self.ele[r0]
+        on_ring = bool(ele == phi0)
+        omE = f32(0) if on_ring else f32(f32(ele - phi0) / f32(self.ele[r0 + 1] - phi0))
+        idx, om = [], []
+        for r in (r0, r0 if on_ring else r0 + 1):
+            d = self.step[r]
+            n = self.count[r]
+            i0 = min(int(np.floor(f32(a / d))), n - 1)
+            wa = f32(f32(a - f32(f32(i0) * d)) / d)
+            wa = min(max(wa, f32(0)), f32(1))
+            if n == 1:
+                wa = f32(0)
+            i1 = 0 if i0 + 1 == n else i0 + 1
+            if wa == 0:
+                i1 = i0
+            idx += [self.offset[r] + i0, self.offset[r] + i1]
+            om += [wa, f32(f32(1) - wa)]
+        return idx, om + [omE, f32(f32(1) - omE)]
+
+    def pick(self, ele, azi):
+        ele, azi = f32(ele), f32(azi)
+        ring, dmin = 0, f32(1e37)
+        for r, e in enumerate(self.ele):
+            d = f32(ele - e)
+            d = d if d > 0 else -d
+            if d < dmin:
+                dmin, ring = d, r
+        a = f32(azi - f32(f32(360) * f32(np.floor(f32(azi / f32(360))))))
+        if not a < 360:
+            a = f32(0)
+        i = int(np.floor(f32(f32(a / self.step[ring]) + f32(0.5))))
+        if i >= self.count[ring]:
+            i = 0
+        return self.offset[ring] + i
+
+
 def case_of(h):
     """GPUSoundSource.cu:301-316."""
     if h[0] == h[1] == h[2] == h[3]:
@@ -248,11 +318,13 @@ class Source:
 class Model:
     """Data + sources + callback_func (Audio.cu:94-163, CPU timing: zero latency)."""
 
-    def __init__(self, frames_per_buffer, hrtf_len, n_sources, hrir):
+    def __init__(self, frames_per_buffer, hrtf_len, n_sources, hrir, grid=None):
+        """grid: a Grid of the set's own (its rule and pick then replace KEMAR's in every mode); None: the reference's."""
         self.B = int(frames_per_buffer)
         self.N = int(2 ** math.ceil(math.log2(self.B + hrtf_len - 1)))  # Universal.cuh:12
         self.Nc = self.N // 2 + 1
-        assert hrir.shape[0] == NUM_HRTF and hrir.shape[1] == 2
+        self.grid = grid
+        assert hrir.shape[0] == (NUM_HRTF if grid is None else grid.n_rows) and hrir.shape[1] == 2
         self.table = build_table(np.asarray(hrir, np.float32), self.N)
         self.src = [Source(self.N) for _ in range(n_sources)]
         i = np.arange(self.B, dtype=np.float32)
@@ -301,7 +373,7 @@ class Model:
         q.x[N - B:] = new
         X = np.fft.rfft(q.x) / N
         if self.mode & 1:
-            Y = X[None, :] * self.table[pick_hrtf(ele, azi)]
+            Y = X[None, :] * self.table[pick_hrtf(ele, azi) if self.grid is None else self.grid.pick(ele, azi)]
             Y[:, 0] = Y[:, 0].real
             Y[:, -1] = Y[:, -1].real
             y = (np.fft.irfft(Y, n=N, axis=-1) * N)[:, N - B:]
@@ -309,7 +381,7 @@ class Model:
             q.x[:N - B] = q.x[B:].copy()
             q.last = y.T.copy().reshape(-1)
             return q.last
-        rule = interp_corrected if self.mode & 2 else interp
+        rule = self.grid.interp if self.grid is not None else interp_corrected if self.mode & 2 else interp
         cur = rule(ele, azi)
         xfade = (q.old_azi != azi) or (q.old_ele != ele)
         old = rule(q.old_ele, q.old_azi) if xfade else None

@@ -74,6 +74,15 @@ def lib():
         L.jfo_reverb_padded_size.restype = C.c_int
         L.jfo_reverb_offline.argtypes = [_f, C.c_int, _f, C.c_int, _f]
         L.jfo_reverb_offline.restype = C.c_float
+        L.jfo_grid_rows.argtypes = [C.c_int, _i]
+        L.jfo_grid_rows.restype = C.c_int
+        L.jfo_grid_interp.argtypes = [C.c_int, _f, _i, _f, C.c_float, C.c_float, _i, _f]
+        L.jfo_grid_interp.restype = C.c_int
+        L.jfo_grid_pick.argtypes = [C.c_int, _f, _i, _f, C.c_float, C.c_float]
+        L.jfo_grid_pick.restype = C.c_int
+        L.jfo_kemar_grid.argtypes = [_f, _i, _f]
+        L.jfo_create_grid.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _f, _i, _f, _f, C.c_int]
+        L.jfo_create_grid.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -172,13 +181,47 @@ def reverb_offline(x, ir):
     return out, float(g)
 
 
+class Grid:
+    """(ring elevations, counts, steps or None) as the C oracle takes them"""
+
+    def __init__(self, ring_ele, ring_count, ring_step=None):
+        self.ele = np.ascontiguousarray(ring_ele, np.float32)
+        self.count = np.ascontiguousarray(ring_count, np.int32)
+        self.step = None if ring_step is None else np.ascontiguousarray(ring_step, np.float32)
+        self.n = len(self.ele)
+        self.n_rows = int(self.count.sum())
+
+    def args(self):
+        return self.n, fptr(self.ele), iptr(self.count), fptr(self.step) if self.step is not None else None
+
+    @staticmethod
+    def kemar():
+        e, c, s = np.zeros(14, np.float32), np.zeros(14, np.int32), np.zeros(14, np.float32)
+        lib().jfo_kemar_grid(fptr(e), iptr(c), fptr(s))
+        return Grid(e, c, s)
+
+    def interp(self, ele, azi):
+        idx = np.zeros(4, np.int32)
+        om = np.zeros(6, np.float32)
+        rc = lib().jfo_grid_interp(*self.args(), ele, azi, iptr(idx), fptr(om))
+        assert rc != -2, "bad grid"
+        return None if rc else (idx, om)
+
+    def pick(self, ele, azi):
+        return lib().jfo_grid_pick(*self.args(), ele, azi)
+
+
 class Engine:
     """Same method names as the HIP engine binding so tests read alike."""
 
-    def __init__(self, B, hrtf_len, n_sources, hrir):
+    def __init__(self, B, hrtf_len, n_sources, hrir, grid=None):
         self.hrir = np.ascontiguousarray(hrir, np.float32)
         self.B, self.S = B, n_sources
-        self.h = lib().jfo_create(B, hrtf_len, n_sources, fptr(self.hrir), self.hrir.shape[2])
+        if grid is None:
+            self.h = lib().jfo_create(B, hrtf_len, n_sources, fptr(self.hrir), self.hrir.shape[2])
+        else:
+            assert self.hrir.shape[0] == grid.n_rows
+            self.h = lib().jfo_create_grid(B, hrtf_len, n_sources, *grid.args(), fptr(self.hrir), self.hrir.shape[2])
         if not self.h:
             raise ValueError("jfo_create failed")
         self.N = lib().jfo_pad_len(self.h)
