@@ -607,6 +607,12 @@ def main():
                 iss["valu_issue_share_at_4_cycles_per_inst"] = per_simd * 4 / cycles
                 iss["valu_rate_note"] = ("2 cycles: what the SIMD needs with >= 2 waves ready (plain f32; packed f32 twice "
                                          "that); 4 cycles: what one wave alone can issue")
+            if fpmc.get("SQ_ACTIVE_INST_VALU") and fpmc.get("GRBM_GUI_ACTIVE"):
+                # The bound the kernel actually sits on: the share of the launch in which a SIMD's vector pipe is executing a
+                # vector instruction (SQ_ACTIVE_INST_VALU counts quad-cycles, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE
+                # cycles, summed over the 8 XCDs).  The flop fraction (`frac`) prices the same work at 2 cycles per
+                # instruction; executed, an instruction of this kernel's mix occupies the pipe for ~4.
+                iss["valu_active_share"] = (fpmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (fpmc["GRBM_GUI_ACTIVE"] / 8.0)
             if fpmc.get("SQ_INSTS_VMEM_RD"):
                 iss["vmem_loads_per_source_block"] = fpmc["SQ_INSTS_VMEM_RD"] / (S * KB)
             if fpmc.get("SQ_WAVE_CYCLES") and fpmc.get("SQ_WAIT_ANY"):
