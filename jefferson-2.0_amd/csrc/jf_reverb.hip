@@ -23,6 +23,8 @@
 #include "jf_device.h"
 #include "jf_packed.h"
 
+#include <algorithm>
+
 namespace jf {
 
 #define JF_DEV __device__ __forceinline__
@@ -81,6 +83,9 @@ typedef c2 rv_v2;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(x), "v"(h), "v"(acc));
     return r;
 }
+
+// pointers loaded from a table are generic to the compiler (flat loads): the signals and rings are global memory
+#define JF_RV_GLOBAL __attribute__((address_space(1)))
 
 // Wave-private LDS hand-off (see jf_kernels.hip)
 #define JF_RV_SYNC()                                            \
@@ -639,13 +644,37 @@ __global__ __launch_bounds__(64 * kTileWaves) JF_TILE_ATTR void reverb_mac_tiled
 // radix 2 or 4.  T2[j] = exp(+2 pi i j / (2 NPT)), j < 2 NPT.  The twiddles a thread needs do not depend on the data: they
 // are loaded into registers FIRST (BigTwiddles::load, before the caller fetches its input), so that a transform waits for
 // global memory once, not once per pass.
+#ifndef JF_RV_BIG_TW_LDS
+#define JF_RV_BIG_TW_LDS 1
+#endif
 template <int NPT, int NT>
 struct BigTwiddles {
     static constexpr int RL = NPT / 512;               // radix of the last pass
     static constexpr int NL = NPT / RL / NT;           // its butterflies per thread
     static_assert(NPT / 8 <= NT && NL >= 1, "one radix-8 butterfly per thread at most");
-    float2 w8[2][7];        // passes with Ns = 8 and 64: exp(2 pi i r k / (8 Ns)), r = 1 .. 7
+    // passes with Ns = 8 and 64: exp(2 pi i r k / (8 Ns)), r = 1 .. 7 -- JF_RV_BIG_TW_LDS = 0: in registers (28 of them, held
+    // through the whole kernel); 1: in LDS (504 entries, 4 KB per workgroup, staged once by stage_w8: pass Ns = 8 reads
+    // eight distinct entries per wave -- broadcasts --, pass Ns = 64 one entry per lane).  The persistent transform kernels keep
+    // the next item's input in registers instead.
+#if !JF_RV_BIG_TW_LDS
+    float2 w8[2][7];
+#endif
     float2 wl[NL][RL - 1];  // last pass (Ns = 512)
+    static constexpr int kW8Len = 504;
+    JF_DEV static void stage_w8(const float2 *__restrict__ T2, float2 *s_w8, int tid) {
+#if JF_RV_BIG_TW_LDS
+        const float2 *__restrict__ pk = T2 + 2 * NPT;
+        for (int k = tid; k < kW8Len; k += NT) s_w8[k] = pk[k];
+#endif
+    }
+    JF_DEV float2 w8_at(const float2 *s_w8, int p, int r, int tid) const {  // r = 1 .. 7
+#if JF_RV_BIG_TW_LDS
+        const int Ns = p ? 64 : 8;
+        return s_w8[(p ? 56 : 0) + (r - 1) * Ns + (tid & (Ns - 1))];
+#else
+        return w8[p][r - 1];
+#endif
+    }
     // The values are entries of the circle T2, but a wave that fetches them there gathers 64 cache lines per load (strides of
     // 8 r .. 64 r entries between neighbouring lanes) -- 17 to 21 such loads per thread were a third of a transform kernel's
     // time.  The engine lays the same values out per pass and r, neighbouring lanes side by side, BEHIND the circle
@@ -653,6 +682,7 @@ struct BigTwiddles {
     // inverse 43.5 -> 38.7 us per launch at config 5's batch shape (rocprofv3, 320 launches, twice).
     JF_DEV void load(const float2 *__restrict__ T2, int tid) {
         const float2 *__restrict__ pk = T2 + 2 * NPT;
+#if !JF_RV_BIG_TW_LDS
         const int j = tid < NPT / 8 ? tid : 0;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -660,6 +690,7 @@ struct BigTwiddles {
 #pragma unroll
             for (int r = 1; r < 8; r++) w8[p][r - 1] = pk[(p ? 56 : 0) + (r - 1) * Ns + (j & (Ns - 1))];
         }
+#endif
 #pragma unroll
         for (int u = 0; u < NL; u++)
 #pragma unroll
@@ -667,20 +698,123 @@ struct BigTwiddles {
     }
 };
 
-// NTR transforms of NPT points at once by one workgroup, IN PLACE in NTR buffers of LDS (padded layout rv_at<true>): the
+// Where element i of a workgroup transform lies in its LDS buffer.  The passes read with unit stride and write with strides of
+// 8 (first pass: 8 j + r) and of 8 inside runs of 64 (second pass: 64 (j >> 3) + (j & 7) + 8 r); the later passes write with
+// unit stride.  JF_RV_BIG_XOR = 0: one float2 of padding per 8 (rv_at<true>) -- the strided stores are conflict-free, but a
+// half-wave's unit-stride 8-byte reads then span 36 bank pairs of 32: one extra LDS cycle per read, 40 % of the transform
+// kernels' LDS cycles (round 4's counters).  1: no padding, the low five index bits XORed with index bits 5-7 (low three) and
+// 6-7 (bits 3-4): aligned unit-stride runs stay permutations of the 32 bank pairs, the first pass's 32 lanes (bits 3-4 =
+// j & 3, low bits r) get (j >> 2) & 7 in the low bits and ((j >> 3) ^ j) & 3 above -- injective in j -- and the second
+// pass's (low bits j & 7, bits 3-4 of r) get j >> 3 into bits 3-4: every access of every pass conflict-free, and a
+// transform takes 16 KB instead of 18.
+#ifndef JF_RV_BIG_XOR
+#define JF_RV_BIG_XOR 0
+#endif
+JF_DEV int rv_big_at(int i) {
+#if JF_RV_BIG_XOR
+    return i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3);
+#else
+    return rv_at<true>(i);
+#endif
+}
+constexpr int rv_big_len(int n) { return JF_RV_BIG_XOR ? n : rv_buf_len<true>(n); }
+
+// NTR transforms of NPT points at once by one workgroup, IN PLACE in NTR buffers of LDS (layout rv_big_at): the
 // twiddles depend on the thread and the pass only, so the transforms share them (registers, loads) and the barriers -- and
 // since every thread has read its butterflies' inputs before any thread writes (a barrier between), one buffer per transform
 // is enough.  The input comes in REGISTERS: v[t][r] = x_t[tid + r NPT / 8] of threads tid < NPT / 8 (the first pass needs no
 // twiddles and reads nothing from LDS: the caller loads straight from global memory).  The results lie in buf[t] in natural order.
 template <int NPT, int DIR, int NT, int NTR, int LEN>
-JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwiddles<NPT, NT> &tw, int tid) {
-    const bool on = tid < NPT / 8;
+JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwiddles<NPT, NT> &tw, const float2 *s_w8, int tid) {
+    constexpr int N8 = NPT / 8;  // radix-8 butterflies per pass, one per thread
+    const bool on = tid < N8;
+#if !JF_RV_BIG_XOR
+    // Padded layout, every address spelled out as ONE per-thread base + a compile-time offset (the compiler does not see that
+    // (tid + 256 r) >> 3 = (tid >> 3) + 32 r and recomputed every one of the ~70 addresses of a transform: a third of the
+    // kernel's vector instructions, round 5's counters): at(i) = i + (i >> 3), so
+    //   reads of the radix-8 passes   at(tid + r N8)              = rd0 + r (9 N8 / 8)
+    //   first pass's stores            at(8 tid + r)               = 9 tid + r
+    //   second pass's (Ns = 8)         at(64 g + k + 8 r), k < 8   = 72 g + k + 9 r
+    //   third pass's (Ns = 64)         at(512 g + k + 64 r), k < 64 = 576 g + k + (k >> 3) + 72 r
+    //   last pass, in place            at(tid + 256 u + r NPT / RL) = rd0 + 288 u + r (9 NPT / (8 RL))
+    const int rd0 = tid + (tid >> 3);
+    const int wa0 = 9 * tid;
+    const int wb0 = 72 * (tid >> 3) + (tid & 7);
+    const int wc0 = 576 * (tid >> 6) + (tid & 63) + ((tid & 63) >> 3);
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < NTR; t++) {
+            rv_fft8<DIR>(v[t]);
+            float2 *w = buf[t] + wa0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) w[r] = v[t][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < NTR; t++) {
+                const float2 *rd = buf[t] + rd0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[t][r] = rd[r * (9 * N8 / 8)];
+#pragma unroll
+                for (int r = 1; r < 8; r++) {
+                    const float2 w = tw.w8_at(s_w8, p, r, tid);
+                    v[t][r] = DIR > 0 ? rv_mul(v[t][r], w) : rv_mulc(v[t][r], w);
+                }
+                rv_fft8<DIR>(v[t]);
+            }
+        }
+        __syncthreads();  // every input of the pass has been read
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < NTR; t++) {
+                float2 *w = buf[t] + (p ? wc0 : wb0);
+#pragma unroll
+                for (int r = 0; r < 8; r++) w[r * (p ? 72 : 9)] = v[t][r];
+            }
+        }
+        __syncthreads();
+    }
+    constexpr int RL = BigTwiddles<NPT, NT>::RL, NL = BigTwiddles<NPT, NT>::NL;
+    static_assert(RL * NL <= 8 && NT == 256 && NL * NT <= 512, "the registers of v[t] hold the last pass's values; j < 512");
+#pragma unroll
+    for (int t = 0; t < NTR; t++) {
+        float2 *io = buf[t] + rd0;
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            float2 x[RL];
+#pragma unroll
+            for (int r = 0; r < RL; r++) x[r] = io[288 * u + r * (9 * NPT / (8 * RL))];
+#pragma unroll
+            for (int r = 1; r < RL; r++) x[r] = DIR > 0 ? rv_mul(x[r], tw.wl[u][r - 1]) : rv_mulc(x[r], tw.wl[u][r - 1]);
+            rv_fftR<RL, DIR>(x);
+            // in place: butterfly j = tid + 256 u (< 512) reads and writes elements j + r NPT / RL ... no: it WRITES j + 512 r,
+            // which other butterflies read when RL = 4 (NPT / RL = 512 too) -- the same elements: in place indeed
+            static_assert(NPT / RL == 512, "the last pass is in place");
+#pragma unroll
+            for (int r = 0; r < RL; r++) v[t][u * RL + r] = x[r];
+        }
+    }
+    // (in place and each element touched by ONE butterfly: no barrier between the reads and the writes)
+#pragma unroll
+    for (int t = 0; t < NTR; t++) {
+        float2 *io = buf[t] + rd0;
+#pragma unroll
+        for (int u = 0; u < NL; u++)
+#pragma unroll
+            for (int r = 0; r < RL; r++) io[288 * u + r * 576] = v[t][u * RL + r];
+    }
+    __syncthreads();
+#else
     auto store = [&](int j, int Ns) {  // Stockham: butterfly j's outputs go to j0 + r Ns
         const int k = j & (Ns - 1), j0 = (j - k) * 8 + k;
 #pragma unroll
         for (int t = 0; t < NTR; t++)
 #pragma unroll
-            for (int r = 0; r < 8; r++) buf[t][rv_at<true>(j0 + r * Ns)] = v[t][r];
+            for (int r = 0; r < 8; r++) buf[t][rv_big_at(j0 + r * Ns)] = v[t][r];
     };
     if (on) {
 #pragma unroll
@@ -695,9 +829,12 @@ JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwidd
 #pragma unroll
             for (int t = 0; t < NTR; t++) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) v[t][r] = buf[t][rv_at<true>(tid + r * (NPT / 8))];
+                for (int r = 0; r < 8; r++) v[t][r] = buf[t][rv_big_at(tid + r * (NPT / 8))];
 #pragma unroll
-                for (int r = 1; r < 8; r++) v[t][r] = DIR > 0 ? rv_mul(v[t][r], tw.w8[p][r - 1]) : rv_mulc(v[t][r], tw.w8[p][r - 1]);
+                for (int r = 1; r < 8; r++) {
+                    const float2 w = tw.w8_at(s_w8, p, r, tid);
+                    v[t][r] = DIR > 0 ? rv_mul(v[t][r], w) : rv_mulc(v[t][r], w);
+                }
                 rv_fft8<DIR>(v[t]);
             }
         }
@@ -715,7 +852,7 @@ JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwidd
             const int j = tid + u * NT;
             float2 x[RL];
 #pragma unroll
-            for (int r = 0; r < RL; r++) x[r] = buf[t][rv_at<true>(j + r * (NPT / RL))];
+            for (int r = 0; r < RL; r++) x[r] = buf[t][rv_big_at(j + r * (NPT / RL))];
 #pragma unroll
             for (int r = 1; r < RL; r++) x[r] = DIR > 0 ? rv_mul(x[r], tw.wl[u][r - 1]) : rv_mulc(x[r], tw.wl[u][r - 1]);
             rv_fftR<RL, DIR>(x);
@@ -729,9 +866,10 @@ JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwidd
         for (int u = 0; u < NL; u++) {
             const int j = tid + u * NT, k = j & 511, j0 = (j - k) * RL + k;
 #pragma unroll
-            for (int r = 0; r < RL; r++) buf[t][rv_at<true>(j0 + r * 512)] = v[t][u * RL + r];
+            for (int r = 0; r < RL; r++) buf[t][rv_big_at(j0 + r * 512)] = v[t][u * RL + r];
         }
     __syncthreads();
+#endif
 }
 
 constexpr int kBigThreads = 256;
@@ -740,15 +878,32 @@ constexpr int kBigThreads = 256;
 // into fdl1 (packed: bin 0 = (X[0], X[B1])).  NTR transforms per workgroup (items g = NTR blockIdx + t of the n_tr S).
 template <int B1, int NTR>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_buf[NTR][rv_buf_len<true>(B1)];
-    const int tid = threadIdx.x;
+    __shared__ float2 s_buf[NTR][rv_big_len(B1)];
+    const int tid0 = threadIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
-    tw.load(P.tw1, tid);
+    __shared__ float2 s_w8[BigTwiddles<B1, kBigThreads>::kW8Len];
+    BigTwiddles<B1, kBigThreads>::stage_w8(P.tw1, s_w8, tid0);  // (the first pass ends with a barrier: staged before anybody reads)
+    tw.load(P.tw1, tid0);
     const int n_items = P.n_tr * P.S;
+    const int n_turns = (n_items + NTR - 1) / NTR;
+#if JF_RV_BIG_SPLIT_TW_EARLY
+    // the split's twiddles (they depend on the thread only): once per workgroup, no global load behind the last pass
+    float2 wsplit[B1 / kBigThreads];
+#pragma unroll
+    for (int u = 0; u < B1 / kBigThreads; u++) wsplit[u] = P.tw1[tid0 + u * kBigThreads];
+#endif
+    // PERSISTENT (round 5): a workgroup takes the turns w = blockIdx.x, blockIdx.x + gridDim.x, ... -- the twiddles are loaded
+    // once per workgroup instead of once per transform (they were as many bytes through the vector L1 as the samples), and the
+    // workgroups of a compute unit, each in another phase of load / passes / store, keep memory and vector unit busy together
+#pragma unroll 1
+    for (int turn = blockIdx.x; turn < n_turns; turn += gridDim.x) {
+    // (opaque per turn: the compiler otherwise hoists every LDS address of the four passes out of the loop: ~60 registers)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
     float2 v[NTR][8];  // z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8: the first pass's input
 #pragma unroll
     for (int t = 0; t < NTR; t++) {
-        const int g = min((int)blockIdx.x * NTR + t, n_items - 1);  // (an odd last item is done twice)
+        const int g = min(turn * NTR + t, n_items - 1);  // (an odd last item is done twice)
         const int i = g / P.S, s = g - i * P.S;
         // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
         // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
@@ -761,6 +916,27 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
         // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
         const int first_in = rel0 < 0 ? 0 : rel0;
         const unsigned start = ((unsigned)dc0 + (unsigned)first_in) % (unsigned)L;
+        // Where the 2 B1 samples lie is the same for the whole workgroup.  The two usual cases -- all of them one stretch of the
+        // looped signal (transforms inside a batch call), all of them one stretch of the dry ring (the side stream's, and a
+        // call's first transform) -- are eight 8-byte loads at base + 2 m: no per-sample index arithmetic (it was a fifth of
+        // the kernel's vector instructions, and its 4-byte flat loads twice the load instructions).
+        const float *stretch = nullptr;
+        if (rel0 >= 0 && start + 2u * (unsigned)B1 <= (unsigned)L) {
+            stretch = (const float *)__builtin_assume_aligned(sg.ptr, 4) + start;
+        } else if (rel0 + 2 * B1 <= 0) {
+            int pos = P.dry_pos0 + rel0;
+            pos = pos < 0 ? pos + Rd : pos;
+            if (pos >= 0 && pos + 2 * B1 <= Rd) stretch = ring + pos;
+        }
+        if (stretch != nullptr) {
+            const float JF_RV_GLOBAL *gs = (const float JF_RV_GLOBAL *)stretch;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+                const c2 pr = *reinterpret_cast<const c2 JF_RV_GLOBAL *>(gs + 2 * m);
+                v[t][r] = make_float2(pr.x, pr.y);
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
@@ -778,16 +954,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
             }
         }
     }
-#if JF_RV_BIG_SPLIT_TW_EARLY
-    // the split's twiddles too before the transform (they do not depend on the data): no global load behind the last pass
-    float2 wsplit[B1 / kBigThreads];
-#pragma unroll
-    for (int u = 0; u < B1 / kBigThreads; u++) wsplit[u] = P.tw1[tid + u * kBigThreads];
-#endif
-    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, tid);
+    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, s_w8, tid);
 #pragma unroll
     for (int t = 0; t < NTR; t++) {
-        const int g = (int)blockIdx.x * NTR + t;
+        const int g = turn * NTR + t;
         if (g >= n_items) break;
         const int i = g / P.S, s = g - i * P.S;
         const float2 *Z = s_buf[t];
@@ -796,8 +966,8 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
 #pragma unroll
         for (int u = 0; u < B1 / kBigThreads; u++) {
             const int q = tid + u * kBigThreads;
-            const float2 zk = Z[rv_at<true>(q)];
-            const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
+            const float2 zk = Z[rv_big_at(q)];
+            const float2 zm = Z[rv_big_at((B1 - q) & (B1 - 1))];
             const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
             const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
 #if JF_RV_BIG_SPLIT_TW_EARLY
@@ -812,6 +982,8 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
             }
             out[q] = x;
         }
+    }
+    __syncthreads();  // the buffers are read out before the next turn's first pass writes them
     }
 }
 
@@ -925,82 +1097,114 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const
     }
 }
 
+#ifndef JF_RV_BIG_IFFT_WQ_REGS
+#define JF_RV_BIG_IFFT_WQ_REGS 0
+#endif
+#ifndef JF_RV_BIG_IFFT_WAVES
+#define JF_RV_BIG_IFFT_WAVES 0
+#endif
 // Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.  NTR products
-// per workgroup (items g = NTR blockIdx + t of the n_prod S).
+// per workgroup and turn (items g = NTR w + t of the n_prod S, w = blockIdx.x, blockIdx.x + gridDim.x, ...).
+// PERSISTENT with the next turn's input in flight (round 5): a workgroup that loads, transforms and stores one after the other
+// leaves the memory system idle while it computes and the vector unit idle while it loads, and three or four such workgroups
+// per compute unit that start together stay in step (round 4: 39 us per launch for 100 MB, 2.6 TB/s, vector pipe a third
+// busy, LDS conflicts or not).  Here the spectra of turn w + gridDim.x are requested BEFORE turn w's passes and untangled
+// into the first pass's registers when that turn begins: raw[t][r] = (Y[q], Y[B1 - q]), q = tid + r B1 / 8.
 template <int B1, int NTR>
-__global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_buf[NTR][rv_buf_len<true>(B1)];
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(kBigThreads, JF_RV_BIG_IFFT_WAVES) void reverb_big_ifft_kernel(const ReverbBigParams P) {
+    __shared__ float2 s_buf[NTR][rv_big_len(B1)];
+    const int tid0 = threadIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
-    tw.load(P.tw1, tid);
+    __shared__ float2 s_w8[BigTwiddles<B1, kBigThreads>::kW8Len];
+    BigTwiddles<B1, kBigThreads>::stage_w8(P.tw1, s_w8, tid0);  // (the first pass ends with a barrier: staged before anybody reads)
+    tw.load(P.tw1, tid0);
     const int n_items = P.n_prod * P.S;
-    float2 v[NTR][8];
+    const int n_turns = (n_items + NTR - 1) / NTR;
+#if JF_RV_BIG_IFFT_WQ_REGS
+    // the untangling twiddles W^q of this thread's bins: the same for every item
+    float2 wq[8];
 #pragma unroll
-    for (int t = 0; t < NTR; t++) {
-        const int g = min((int)blockIdx.x * NTR + t, n_items - 1);
-        const int i = g / P.S, s = g - i * P.S;
-        const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
-        // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
-        // over the partitions (thread 0, which owns bin 0 below, is one of them)
-        float2 y0 = make_float2(0.f, 0.f);
-        if (tid < 64) {
-            const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
-            const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
-            for (int q = tid; q < P.n_part; q += 64) {
-                int slot = (P.anchor_slot_first + i - q) % P.R1;
-                if (slot < 0) slot += P.R1;
-                const float2 x = x0[slot], h = h0[q];
-                y0.x += x.x * h.x;
-                y0.y += x.y * h.y;
+    for (int r = 0; r < 8; r++) wq[r] = P.tw1[(tid0 < B1 / 8 ? tid0 : 0) + r * (B1 / 8)];
+#endif
+#pragma unroll 1
+    for (int turn = blockIdx.x; turn < n_turns; turn += gridDim.x) {
+        // (opaque per turn: the compiler otherwise hoists every LDS and global address of the four passes out of the loop and
+        // keeps them in ~60 registers)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        float2 v[NTR][8];
+#pragma unroll
+        for (int t = 0; t < NTR; t++) {
+            const int g = min(turn * NTR + t, n_items - 1);  // (an odd last item is done twice)
+            const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
+            const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
+            // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
+            // over the partitions (thread 0, which owns bin 0 below, is one of them)
+            float2 y0 = make_float2(0.f, 0.f);
+            if (tid < 64) {
+                const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
+                const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
+                for (int q = tid; q < P.n_part; q += 64) {
+                    int slot = (P.anchor_slot_first + i - q) % P.R1;
+                    if (slot < 0) slot += P.R1;
+                    const float2 x = x0[slot], h = h0[q];
+                    y0.x += x.x * h.x;
+                    y0.y += x.y * h.y;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    y0.x += __shfl_xor(y0.x, m);
+                    y0.y += __shfl_xor(y0.y, m);
+                }
             }
+            // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
+            // memory into the first pass's registers: q = tid + r B1 / 8
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                y0.x += __shfl_xor(y0.x, m);
-                y0.y += __shfl_xor(y0.y, m);
+            for (int r = 0; r < 8; r++) {
+                const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+                const float2 yk = y[q];
+                const float2 ym = y[(B1 - q) & (B1 - 1)];
+                if (q == 0) {
+                    v[t][r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
+                } else {
+                    const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+                    const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+#if JF_RV_BIG_IFFT_WQ_REGS
+                    const float2 o = rv_mul(d, wq[r]);
+#else
+                    const float2 o = rv_mul(d, P.tw1[q]);
+#endif
+                    v[t][r] = make_float2(e.x - o.y, e.y + o.x);
+                }
             }
         }
-        // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
-        // memory into the first pass's registers: q = tid + r B1 / 8
+        cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, s_w8, tid);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-            const float2 yk = y[q];
-            const float2 ym = y[(B1 - q) & (B1 - 1)];
-            if (q == 0) {
-                v[t][r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
+        for (int t = 0; t < NTR; t++) {
+            const int g = turn * NTR + t;
+            if (g >= n_items) break;
+            const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
+            const float2 *zt = s_buf[t];
+            // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
+            if (!P.to_wet) {
+                float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
+                for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_big_at(m)];
             } else {
-                const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-                const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-                const float2 o = rv_mul(d, P.tw1[q]);
-                v[t][r] = make_float2(e.x - o.y, e.y + o.x);
+                // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
+                const int c0 = P.st_in[s].count;
+                float *wet = P.wet + (size_t)s * P.Wr;
+                const int lgB = 31 - __builtin_clz((unsigned)P.B);  // B is 64, 128 or 256
+                for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
+                    const int n = 2 * m - B1;                   // sample inside the big block
+                    const int kb = n >> lgB;                     // n / B (once per pair)
+                    const int k = P.wet_k0 + P.M * i + kb;       // block of the call
+                    int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
+                    w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
+                    *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_big_at(m)];
+                }
             }
         }
-    }
-    cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, tid);
-#pragma unroll
-    for (int t = 0; t < NTR; t++) {
-        const int g = (int)blockIdx.x * NTR + t;
-        if (g >= n_items) break;
-        const int i = g / P.S, s = g - i * P.S;
-        const float2 *zt = s_buf[t];
-        // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
-        if (!P.to_wet) {
-            float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
-            for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_at<true>(m)];
-        } else {
-            // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
-            const int c0 = P.st_in[s].count;
-            float *wet = P.wet + (size_t)s * P.Wr;
-            const int lgB = 31 - __builtin_clz((unsigned)P.B);  // B is 64, 128 or 256
-            for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
-                const int n = 2 * m - B1;                   // sample inside the big block
-                const int kb = n >> lgB;                     // n / B (once per pair)
-                const int k = P.wet_k0 + P.M * i + kb;       // block of the call
-                int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
-                w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
-                *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_at<true>(m)];
-            }
-        }
+        __syncthreads();  // the buffers are read out before the next turn's first pass writes them
     }
 }
 
@@ -1009,10 +1213,12 @@ template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float *__restrict__ ir, int n_ir, int t0, float scale,
                                                                    const float2 *__restrict__ tw1, float2 *__restrict__ hspec1,
                                                                    float2 *__restrict__ h0 /* [P1] compact bin-0 pairs */) {
-    __shared__ float2 s_buf[1][rv_buf_len<true>(B1)];
+    __shared__ float2 s_buf[1][rv_big_len(B1)];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
+    __shared__ float2 s_w8[BigTwiddles<B1, kBigThreads>::kW8Len];
+    BigTwiddles<B1, kBigThreads>::stage_w8(tw1, s_w8, tid);
     tw.load(tw1, tid);
     float2 v[1][8];
 #pragma unroll
@@ -1024,11 +1230,11 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ir_kernel(const float 
         const float a1 = (n + 1 < B1 && i1 < n_ir) ? ir[i1] : 0.0f;
         v[0][r] = make_float2(a0, a1);
     }
-    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, tid);
+    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, s_w8, tid);
     const float2 *Z = s_buf[0];
     for (int q = tid; q < B1; q += kBigThreads) {
-        const float2 zk = Z[rv_at<true>(q)];
-        const float2 zm = Z[rv_at<true>((B1 - q) & (B1 - 1))];
+        const float2 zk = Z[rv_big_at(q)];
+        const float2 zm = Z[rv_big_at((B1 - q) & (B1 - 1))];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
         const float2 wo = rv_mulc(o, tw1[q]);
@@ -1165,12 +1371,36 @@ hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int
     return hipGetLastError();
 }
 
+// workgroups of kBigThreads of `kernel` the current device holds at once (1024 if it will not say)
+template <class K>
+static int big_resident_wgs(K kernel) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBigThreads, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return 1024;
+    }
+    return prop.multiProcessorCount * per_cu;
+}
+
 // two transforms per workgroup (shared twiddles and barriers) once there are enough of them to fill the GPU
+#ifndef JF_RV_BIG_NTR_FFT
+#define JF_RV_BIG_NTR_FFT 1
+#endif
+#ifndef JF_RV_BIG_NTR_IFFT
+#define JF_RV_BIG_NTR_IFFT 1
+#endif
 template <int B1>
 static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
     const int n = P.n_tr * P.S;
-    if (n >= 1024) hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 2>), dim3((n + 1) / 2), dim3(kBigThreads), 0, st, P);
-    else hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 1>), dim3(n), dim3(kBigThreads), 0, st, P);
+    if (n >= 1024 && JF_RV_BIG_NTR_FFT == 2) {
+        static const int resident = big_resident_wgs(reverb_big_fft_kernel<B1, 2>);
+        hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 2>), dim3(std::min((n + 1) / 2, resident)), dim3(kBigThreads), 0, st, P);
+    } else {
+        static const int resident = big_resident_wgs(reverb_big_fft_kernel<B1, 1>);
+        hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
+    }
 }
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
@@ -1185,8 +1415,14 @@ static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
         hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(wgs), dim3(64 * kBigMacWaves), 0, st, P);
     }
     const int n = P.n_prod * P.S;
-    if (n >= 1024) hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 2>), dim3((n + 1) / 2), dim3(kBigThreads), 0, st, P);
-    else hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 1>), dim3(n), dim3(kBigThreads), 0, st, P);
+    // persistent grids: what the device holds at once (the surplus of a larger grid would only queue)
+    if (n >= 1024 && JF_RV_BIG_NTR_IFFT == 2) {
+        static const int resident = big_resident_wgs(reverb_big_ifft_kernel<B1, 2>);
+        hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 2>), dim3(std::min((n + 1) / 2, resident)), dim3(kBigThreads), 0, st, P);
+    } else {
+        static const int resident = big_resident_wgs(reverb_big_ifft_kernel<B1, 1>);
+        hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
+    }
 }
 static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {
