@@ -248,11 +248,6 @@ struct ReverbPlan {
     int n_ranges = 1;             // block ranges the uniform stage's multiply-accumulate works on
     int kb[2] = {0, 0}, kn[2] = {0, 0};
     int forms[2] = {0, 0};        // out: form each range took
-    // A call made of whole big blocks only: FULL forms every block's wet signal, and the small transforms of its last 2 M - 1
-    // blocks (with the dry ring's copy of them and the play position) are state for the NEXT call -- nothing of this call
-    // reads them.  The engine then has them launched on its second stream, beside the big partitions' kernels (12 us of a
-    // 300 us step at config 5's batch shape that hide behind the product kernel, which leaves a wave slot per SIMD free).
-    bool fft_aside = false;
 };
 
 }  // namespace jf

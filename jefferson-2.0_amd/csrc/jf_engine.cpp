@@ -41,7 +41,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
                            int n_wgs, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
-hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used, hipStream_t fft_stream);
+hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
 int big_twiddle_pack_len(int B1);
 int big_twiddle_pack_index(int B1, int k);
 hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st);
@@ -427,25 +427,12 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
-    // (a call of whole big blocks: the small transforms of its last blocks, state for the next call only, run on the second
-    // stream beside the big partitions' kernels -- behind everything the engine's stream has been given so far, and the next
-    // call's stage waits for them: rv_side_urgent)
-    plan.fft_aside = plan.big && K > 1 && e->rv_async && e->rv_form == 0 && e->profiling < 2 && e->rv_side != nullptr &&
-                     plan.n_ranges == 2 && plan.kn[0] == 0 && plan.kn[1] == 0;
-    if (plan.fft_aside) {
-        JF_HIP(e, hipEventRecord(e->rv_ev_main, e->stream));
-        JF_HIP(e, hipStreamWaitEvent(e->rv_side, e->rv_ev_main, 0));
-    }
     {
-        const hipError_t q = launch_reverb(R, &plan, e->stream, &e->last_rv_form, e->rv_side);
+        const hipError_t q = launch_reverb(R, &plan, e->stream, &e->last_rv_form);
         if (q != hipSuccess) {
             e->rv_fut_m = fut_m_before;  // nothing of this call's schedule has been formed
             JF_HIP(e, q);
         }
-    }
-    if (plan.fft_aside) {
-        JF_HIP(e, hipEventRecord(e->rv_ev_side, e->rv_side));
-        e->rv_side_busy = e->rv_side_urgent = true;
     }
     e->last_plan = plan;
     e->side_tr = side_wanted;

@@ -1315,7 +1315,7 @@ static int launch_mac_range(const ReverbParams &P0, int kb, int kn, hipStream_t 
 
 // The whole stage for one call.  plan == null: uniform partitioning, every block through stage B.
 template <int B, int T, int KB>
-static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, hipStream_t fft_stream) {
+static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st) {
     const bool big = plan && plan->big;
     if (big && plan->tail_early.n_prod > 0) launch_big_products(plan->tail_early, st);  // needs nothing of this call
     const bool few = !(P.S % T == 0 && (long long)P.S / T >= 512);  // (many sources: the source-grouped form, two kernels)
@@ -1329,9 +1329,7 @@ static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st,
         if (plan) plan->forms[0] = 4;
         return 4;
     }
-    // transforms of the blocks (where needed) and the dry ring -- beside the stage, on the caller's second stream, when nothing of
-    // this call reads what they leave (ReverbPlan::fft_aside: a call of whole big blocks; the caller orders the streams)
-    launch_fft<B>(P, big && plan->fft_aside && fft_stream != nullptr ? fft_stream : st);
+    launch_fft<B>(P, st);  // transforms of the blocks (where needed) and the dry ring
     int form = 0;
     if (big) {
         // The blocks in front of the call's first whole big block first: they read the fut ring at their big block's place,
@@ -1460,12 +1458,12 @@ int big_twiddle_pack_index(int B1, int k) {
 
 // form_used: 1, 2, 3 = form of stage B (after reverb_fft_kernel), 4 = form 1 with stage A fused in (no reverb_fft_kernel),
 // 0 = no block went through stage B (a batch call whose blocks the big partitions formed alone)
-hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used, hipStream_t fft_stream) {
+hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used) {
     int form = 0;
     switch (P.B) {
-    case 64: form = launch_stage<64, 4, 16>(P, plan, st, fft_stream); break;
-    case 128: form = launch_stage<128, 4, 16>(P, plan, st, fft_stream); break;
-    case 256: form = launch_stage<256, 2, 8>(P, plan, st, fft_stream); break;
+    case 64: form = launch_stage<64, 4, 16>(P, plan, st); break;
+    case 128: form = launch_stage<128, 4, 16>(P, plan, st); break;
+    case 256: form = launch_stage<256, 2, 8>(P, plan, st); break;
     default: return hipErrorInvalidValue;
     }
     if (form_used) *form_used = form;
