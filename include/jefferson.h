@@ -389,6 +389,13 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
  * (the last block of a big block then costs ~9 us more than the others at configs[4], the first ~40 us).  Default 1.  Same
  * kernels, same order of every sum: bit-identical results. */
 int jf_debug_set_reverb_async(jf_engine *e, int on);
+/* One-block calls with a short head (the 2 M partitions of a non-uniformly partitioned response, or a response of at most 64
+ * blocks) and at most 512 sources CAN run the reverb's head INSIDE the one-launch real-time kernel (on = 1): the wave that
+ * spatialises a source first takes its block through the head's partitions (in order) and leaves it in the wet ring -- one
+ * launch per audio block instead of two.  Off by default (the head as a kernel of its own in front): the one launch measured
+ * 5 us slower per block at 256 sources, a head being one wave's chain there (profiles/r05/reverb_realtime.md).  Same sums of
+ * the same products in another order: equal to float32 rounding, not bit for bit. */
+int jf_debug_set_reverb_head_fused(jf_engine *e, int on);
 /* The schedule of the non-uniformly partitioned reverb for a call of K blocks that starts at absolute block j0, with big blocks
  * of M blocks and TAIL formed up to big block fut_m (host logic only: no engine, no GPU; tests/test_reverb_plan.py replays
  * runs of calls against a model of the rings).  out = {m_lo, n_tr, ma, n_mid, n_ranges, kb0, kn0, kb1, kn1, copy_lo, copy_hi,

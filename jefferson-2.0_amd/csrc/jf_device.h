@@ -248,6 +248,10 @@ struct ReverbPlan {
     int n_ranges = 1;             // block ranges the uniform stage's multiply-accumulate works on
     int kb[2] = {0, 0}, kn[2] = {0, 0};
     int forms[2] = {0, 0};        // out: form each range took
+    // A one-block call whose head the spatialiser's one-launch kernel runs itself (rt_block_kernel<.., true>: rv_head_wave):
+    // launch_reverb then launches what must come BEFORE the head only (tail_early) and reports form 5; the caller launches the
+    // real-time kernel and, behind it, `transforms` if any are left in line (launch_reverb_big_side(&transforms, nullptr, stream)).
+    bool head_fused = false;
 };
 
 }  // namespace jf

@@ -38,7 +38,7 @@ hipError_t launch_mix_prep(const float *d_partial, float *d_mix, int S_groups, i
                            const float *d_pos_next, ItemDesc *d_desc_next, int S, int K_next, int canon, hipStream_t st);
 int rt_waves_per_wg(int n_sources);
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
-                           int n_wgs, hipStream_t st);
+                           int n_wgs, const ReverbParams *head, hipStream_t st);
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
@@ -66,6 +66,7 @@ struct EventPair {
 
 constexpr double kInterpMovedMax = 0.30;  // jf_engine::interp_use == 2: largest share of moving items a run may have to take the rows
 constexpr long kRtPollNs = 2000000;  // jf_collect_block polls the real-time kernel's completion words for at most this long
+constexpr int kRvFusedHeadMax = 64;  // partitions of B a wave takes a block through by itself (rv_head_wave)
 constexpr int kRtMaxWgs = 128;  // workgroups (8 or 16 waves, a source per wave and turn) of the one-launch real-time kernel: 64 and 256 measure slower
 
 struct jf_engine {
@@ -194,6 +195,15 @@ struct jf_engine {
     ReverbBigParams side_p[2];   // transforms, products
     long long side_fut_m = 0;    // ... and what that work will have formed: committed to rv_fut_m / rv_side_urgent only once it
     bool side_urgent = false;    //     has been launched (submit_side)
+    // One-block calls through the one-launch real-time kernel CAN run the stage's HEAD inside that launch (rt_block_kernel<..,
+    // true>, jf_rv_small.h: rv_head_wave) when the head is short (<= kRvFusedHeadMax partitions: the 2 M of a non-uniformly
+    // partitioned response, or a short response) and eight waves share a workgroup: one launch per audio block instead of two.
+    // OFF by default: measured 5 us SLOWER per block at config 5's 256 sources (35.1 against 30.1 us mean: the head's two small
+    // transforms and its 64 KB of spectra per source are then ONE wave's chain on one of 32 compute units, where the head
+    // kernel spreads a source over 16 waves and the sources over every compute unit: profiles/r05/reverb_realtime.md)
+    int rv_head_fused = 0;       // jf_debug_set_reverb_head_fused
+    bool post_tr = false;        // transforms left in line behind the fused head (run_reverb_stage -> jf_submit_block)
+    ReverbBigParams post_tr_p;
     int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
                                  // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md)
 };
@@ -276,7 +286,11 @@ EventPair *next_events(jf_engine *e, std::vector<EventPair> &pool) {
 
 // reverb ahead of the spatialiser: dry signal -> FDL -> wet ring, for the K blocks of this call (state parity p)
 static int submit_side(jf_engine *e);
-static int run_reverb_stage(jf_engine *e, int p, int K) {
+// head_out (one-block calls through the real-time kernel; may be null): if the stage's head can run inside that kernel, it is
+// NOT launched here -- *head_out receives its parameters, *head_fused says so, and e->post_tr holds what must follow the kernel
+static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out = nullptr, bool *head_fused = nullptr) {
+    if (head_fused) *head_fused = false;
+    e->post_tr = false;
     if (e->rv_P <= 0) return JF_OK;
     if (e->side_tr) {
         // the last stage's work for the side stream was never submitted (a launch between that stage and submit_side failed
@@ -427,11 +441,23 @@ static int run_reverb_stage(jf_engine *e, int p, int K) {
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
+    plan.head_fused = head_out != nullptr && K == 1 && e->rv_head_fused && e->rv_form == 0 && e->profiling < 2 &&
+                      e->rv_P <= kRvFusedHeadMax && rt_waves_per_wg(e->S) == 8 && (e->B == 64 || e->B == 128 || e->B == 256);
     {
         const hipError_t q = launch_reverb(R, &plan, e->stream, &e->last_rv_form);
         if (q != hipSuccess) {
             e->rv_fut_m = fut_m_before;  // nothing of this call's schedule has been formed
             JF_HIP(e, q);
+        }
+    }
+    if (plan.head_fused) {
+        R.kb = 0;
+        R.kn = 1;
+        *head_out = R;
+        *head_fused = true;
+        if (plan.transforms.n_tr > 0) {  // (in line: the block completed a big block and the side stream is not used)
+            e->post_tr = true;
+            e->post_tr_p = plan.transforms;
         }
     }
     e->last_plan = plan;
@@ -1134,8 +1160,12 @@ int jf_submit_block(jf_engine *e) {
             // from and writing the stereo block to pinned host memory -- no copies, one sync
             const int p = e->cur;
             e->ahead.valid = false;  // this block moves every source's old position
+            ReverbParams head;
+            bool head_fused = false;
             {
-                const int rc = run_reverb_stage(e, p, 1);  // the wet ring is then this block's signal
+                // the wet ring is then this block's signal (written by the stage's own kernel, or by the real-time kernel's
+                // waves themselves: head_fused)
+                const int rc = run_reverb_stage(e, p, 1, &head, &head_fused);
                 if (rc) return rc;
             }
             FusedParams P;
@@ -1162,7 +1192,12 @@ int jf_submit_block(jf_engine *e) {
             int wgs = (e->S + rtw - 1) / rtw;
             if (wgs > kRtMaxWgs) wgs = kRtMaxWgs;
             e->rt_seq = e->rt_seq == 0x7fffffff ? 1 : e->rt_seq + 1;
-            JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, e->hd_done, e->rt_seq, wgs, e->stream));
+            JF_HIP(e, launch_rt_block(P, e->rt, e->hd_pos, e->hd_out, e->hd_done, e->rt_seq, wgs, head_fused ? &head : nullptr,
+                                      e->stream));
+            if (e->post_tr) {  // X_m of the big block this block completed, behind the kernel that wrote the block's samples
+                JF_HIP(e, launch_reverb_big_side(&e->post_tr_p, nullptr, e->stream));
+                e->post_tr = false;
+            }
             {
                 const int rc = submit_side(e);
                 if (rc) return rc;
@@ -1735,6 +1770,14 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
     });
 }
 
+int jf_debug_set_reverb_head_fused(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    e->rv_head_fused = on != 0;
+    return JF_OK;
+    });
+}
+
 int jf_debug_set_reverb_async(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
@@ -1855,7 +1898,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         if (e->rv_P > 0) {
             const ReverbPlan &pl = e->last_plan;
             const std::string b1 = std::to_string(e->rv_B1);
-            auto per_wg = [&](int n) { return std::string(n * e->S >= 1024 ? ",2>;" : ",1>;"); };  // transforms per workgroup
+            auto per_wg = [&](int) { return std::string(",1>;"); };  // transforms per workgroup and turn (persistent since round 5)
             auto products = [&](const ReverbBigParams &g) {
                 return g.n_prod > 0 ? "reverb_big_mac_kernel<" + b1 + "," + (g.n_prod >= 4 ? "16" : "1") + ">;reverb_big_ifft_kernel<" +
                                           b1 + per_wg(g.n_prod) : std::string();
@@ -1871,7 +1914,9 @@ const char *jf_debug_last_kernels(jf_engine *e) {
                 return "reverb_mac_kernel<" + bs + "," + std::to_string(form == 2 ? grp : 1) + ">;";
             };
             if (pl.big) k += products(pl.tail_early);
-            if (e->last_rv_form == 4) {
+            if (e->last_rv_form == 5) {
+                // (the head ran inside the real-time kernel, named below; transforms left in line follow it)
+            } else if (e->last_rv_form == 4) {
                 k += stage_b(4);
                 if (pl.big) k += transforms(pl.transforms);
             } else {
@@ -1891,7 +1936,14 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         const int n_part = e->last_group > 0 ? e->S / e->last_group : e->S;
         const std::string mix_name = (n_part == 16 || n_part == 32 || n_part == 64)
                                          ? ";mix_few_kernel<" + std::to_string(n_part / 16) + ">" : std::string(";mix_kernel");
-        if (e->last_rt) k += "rt_block_kernel<" + nb + "," + std::to_string(rt_waves_per_wg(e->S)) + ">";
+        if (e->last_rt) {
+            const bool fused = e->rv_P > 0 && e->last_rv_form == 5;
+            k += "rt_block_kernel<" + nb + "," + std::to_string(rt_waves_per_wg(e->S)) + (fused ? ",reverb>" : ">");
+            if (fused && e->last_plan.big && e->last_plan.transforms.n_tr > 0) {
+                const std::string b1 = std::to_string(e->rv_B1);
+                k += ";reverb_big_fft_kernel<" + b1 + ",1>";
+            }
+        }
         else k += std::string(e->last_group > 1 ? "fused_pair_kernel<" : "fused_block_kernel<") + nb +
                   (e->last_fused_prep ? ">+prep" : ">") + (e->last_mix_prep ? ";mix_prep_kernel" : mix_name);
         e->kernels = k;

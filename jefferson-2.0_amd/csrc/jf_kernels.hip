@@ -1992,22 +1992,32 @@ __global__ void interp_debug_kernel(const RingTable rt, const float *ele, const 
 // workgroup's partial block crosses PCIe, and from ~1000 sources on the fewer, larger workgroups win
 // (profiles/r04/rt_waves.md: 16 .. 128 sources 22.5-24.4 -> 18.4-21.1 us, 512 equal, 1024 30.9 against 33.6).
 constexpr int kRtWavesFew = 8, kRtWavesMany = 16, kRtFewMaxSources = 512;
-template <int NOUT, int RTW>
+#include "jf_rv_small.h"
+
+// RV: the reverb stage's head runs inside this kernel (jf_rv_small.h: rv_head_wave): the wave of source s first takes the
+// block through the P partitions of R -- the head of a non-uniformly partitioned response -- and leaves it in the wet ring,
+// then spatialises it: ONE launch per audio block with the reverb on (round 4: the head kernel, 8 us, a launch gap, this kernel).
+template <int NOUT, int RTW, bool RV>
 // done (may be null): host-mapped words, one per workgroup; workgroup g stores `seq` into done[g] once its block lies in
 // `out` -- the host then polls these words instead of synchronising the stream (the runtime's completion path costs more
 // than the kernel's arithmetic at one source).
 __global__ __launch_bounds__(64 * RTW) void rt_block_kernel(const FusedParams P, const RingTable rt,
                                                             const float *__restrict__ pos,
-                                                            float2 *__restrict__ out, int *__restrict__ done, int seq) {
+                                                            float2 *__restrict__ out, int *__restrict__ done, int seq,
+                                                            const ReverbParams R) {
     constexpr int kRtWaves = RTW;
     __shared__ float2 s_tw[kTwPack];
     __shared__ float2 s_buf[kRtWaves * kWaveLds];
     __shared__ ItemDesc s_desc[kRtWaves];
+    __shared__ float2 s_tw1024[RV ? 1024 : 1];  // exp(2 pi i j / 1024): the head's small transforms read it in every pass
     constexpr int B = 64 * NOUT;
+    static_assert(!RV || (4 * B <= kWaveLds && (B == 64 || B == 128 || B == 256)), "rv_head_wave's LDS; the reverb's block sizes");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int j = tid; j < kTwPack; j += 64 * kRtWaves) s_tw[j] = P.tw[j];
+    if (RV)
+        for (int j = tid; j < 1024; j += 64 * kRtWaves) s_tw1024[j] = R.tw[j];
     // the first source's descriptor before the barrier: its position comes over PCIe (host-mapped memory) and the index/
     // weight rule is a long chain in one lane -- both overlap with the twiddle loads of the other lanes
     const int s_first = blockIdx.x * kRtWaves + wave;
@@ -2024,6 +2034,13 @@ __global__ __launch_bounds__(64 * RTW) void rt_block_kernel(const FusedParams P,
         const float *p = pos + 5 * s;
         if (lane == 0 && s != s_first) make_desc(rt, P.mode, p, P.st_in[s].old_ele, P.st_in[s].old_azi, s_desc[wave]);
         JF_WAVE_LDS_SYNC();
+        if constexpr (RV) {
+            if constexpr (B == 64 || B == 128 || B == 256) rv_head_wave<B>(R, s, buf, s_tw1024, lane);
+            // the block lies in the wet ring (this wave's own stores, acknowledged) before the window below is gathered from it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            JF_WAVE_LDS_SYNC();
+        }
         spatialise_item<NOUT>(P, &s_desc[wave], p, 0, s, buf, s_tw, lane, acc);
         JF_WAVE_LDS_SYNC();
     }
@@ -2347,15 +2364,28 @@ hipError_t launch_fused(const FusedParams &P, int max_wgs, hipStream_t st) {
 int rt_waves_per_wg(int n_sources) { return n_sources <= kRtFewMaxSources ? kRtWavesFew : kRtWavesMany; }
 
 // n_wgs workgroups of rt_waves_per_wg(P.S) waves
+// head (may be null): the reverb stage's head of this block, run inside the launch by each source's wave (rv_head_wave);
+// only with rt_waves_per_wg(P.S) == kRtWavesFew and a block size the reverb has (64, 128, 256)
 hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const float *pos, float *out, int *done, int seq,
-                           int n_wgs, hipStream_t st) {
+                           int n_wgs, const ReverbParams *head, hipStream_t st) {
     if (P.K != 1 || n_wgs < 1) return hipErrorInvalidValue;
     const bool few = rt_waves_per_wg(P.S) == kRtWavesFew;
     const dim3 grid(n_wgs), block(64 * (few ? kRtWavesFew : kRtWavesMany));
     float2 *o = reinterpret_cast<float2 *>(out);
-#define JF_RT_LAUNCH(NOUT)                                                                                             \
-    if (few) hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesFew>), grid, block, 0, st, P, rt, pos, o, done, seq);  \
-    else hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesMany>), grid, block, 0, st, P, rt, pos, o, done, seq)
+    if (head != nullptr) {
+        if (!few || head->B != P.B || head->K != 1) return hipErrorInvalidValue;
+        switch (P.B / 64) {
+        case 1: hipLaunchKernelGGL((rt_block_kernel<1, kRtWavesFew, true>), grid, block, 0, st, P, rt, pos, o, done, seq, *head); break;
+        case 2: hipLaunchKernelGGL((rt_block_kernel<2, kRtWavesFew, true>), grid, block, 0, st, P, rt, pos, o, done, seq, *head); break;
+        case 4: hipLaunchKernelGGL((rt_block_kernel<4, kRtWavesFew, true>), grid, block, 0, st, P, rt, pos, o, done, seq, *head); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    const ReverbParams none{};
+#define JF_RT_LAUNCH(NOUT)                                                                                                          \
+    if (few) hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesFew, false>), grid, block, 0, st, P, rt, pos, o, done, seq, none);  \
+    else hipLaunchKernelGGL((rt_block_kernel<NOUT, kRtWavesMany, false>), grid, block, 0, st, P, rt, pos, o, done, seq, none)
     switch (P.B / 64) {
     case 1: JF_RT_LAUNCH(1); break;
     case 2: JF_RT_LAUNCH(2); break;

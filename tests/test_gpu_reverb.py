@@ -35,8 +35,9 @@ def _wet_stream(dry, n_total, ir, gain):
     return gain * wet
 
 
-def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False, form=0, part=0):
+def _run(jf, hrir, B, S, K, max_k, ir, gain, sigs, pos, blockwise=False, form=0, part=0, head_fused=False):
     eng = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max_k)
+    eng.set_reverb_head_fused(head_fused)
     eng.set_reverb_form(form)
     eng.set_reverb_partitioning(part)
     for s in range(S):
@@ -183,6 +184,48 @@ def test_reverb_off_and_unsupported_block(jf, hrir, castanets):
     b.close()
 
 
+@pytest.mark.parametrize("B,n_ir", [(128, 16 * 128 * 4 + 77), (256, 8 * 256 * 3 + 5), (64, 16 * 64 * 5), (128, 128 * 40 - 3), (256, 300)])
+def test_head_inside_the_realtime_kernel(jf, hrir, castanets, B, n_ir):
+    """One-block calls with the reverb's head run by the spatialiser's own waves (rt_block_kernel<.., reverb>: one launch per
+    audio block; jf_debug_set_reverb_head_fused) against the float64 model, against the head as a kernel of its own, and with
+    the two forms taking turns in ONE stream of blocks (every ring, counter and window they leave is the other's input): non-
+    uniformly partitioned responses (head of 2 M partitions, the big partitions on the side stream) and short uniform ones; 11
+    sources = two workgroups, the second with three waves; a reset and a new signal on the way."""
+    S, K = 11, 70
+    ir = _ir(n_ir, decay=3.0)
+    gain = 0.6
+    sigs = [castanets[3000 * s: 3000 * s + 9000 + 131 * s] for s in range(S)]
+    pos = _positions(jf, S, K)
+    pos[:, 3:] = pos[:, 3 % 3: 3 % 3 + 1]        # (the helper's radii are per source: keep them inside its 0.5 + 0.4 s range)
+    for s_ in range(3, S):
+        for b in range(K):
+            pos[b, s_] = jf.position_from_spherical(-30 + 9 * s_, (25 * s_ + 2 * b) % 360, 0.6 + 0.1 * s_)
+    want = _model(hrir, B, S, K, ir, gain, sigs, pos)
+    P = -(-n_ir // B)
+    tol = (2e-7 + 1e-7 * np.sqrt(P)) * max(1.0, np.abs(want).max()) * np.sqrt(S) * 2
+    outs = {}
+    for mode in ("fused", "own", "turns"):
+        e = jf.Engine(B, 512, S, hrir=hrir)
+        e.set_reverb_head_fused(mode != "own")
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+        e.set_reverb(ir, gain)
+        got = []
+        for b in range(K):
+            if mode == "turns" and b % 5 == 0:
+                e.set_reverb_head_fused((b // 5) % 2 == 0)
+            e.set_latched(pos[b])
+            got.append(e.process_block())
+            want_rt = "rt_block_kernel<%d,8%s>" % (B // 64, ",reverb" if (mode == "fused" or (mode == "turns" and (b // 5) % 2 == 0)) else "")
+            assert e.last_kernels()[-1] == want_rt or e.last_kernels()[-1].startswith("reverb_big_fft"), (b, e.last_kernels())
+        outs[mode] = np.array(got)
+        e.close()
+    assert np.abs(want).max() > 0.02
+    for mode, got in outs.items():
+        assert np.abs(got - want).max() <= tol, mode
+    assert not np.array_equal(outs["fused"], outs["own"])
+
+
 # ------------------------------------------------------------------------------- non-uniform partitioning --
 @pytest.mark.parametrize("B,n_big,ragged", [(128, 3, 0), (128, 7, 901), (64, 5, 17), (256, 3, 1000)])
 def test_nonuniform_partitioning_against_float64_and_the_uniform_form(jf, hrir, castanets, B, n_big, ragged):
@@ -305,37 +348,42 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
     e.close()
     assert b0 == K and np.array_equal(np.concatenate(got), b)
     a = _run(jf, hrir, B, S, K, 80, ir, 0.5, sigs, pos, form=1, part=2)                   # one call of five whole big blocks
-    c = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)                    # default: fused head kernel
+    c = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True)                    # default: the fused head kernel in front
+    c2 = _run(jf, hrir, B, S, K, 1, ir, 0.5, sigs, pos, blockwise=True, head_fused=True)   # the head inside the real-time kernel
     want = _model(hrir, B, S, K, ir, 0.5, sigs, pos)
     tol = (2e-7 + 1e-7 * np.sqrt(-(-len(ir) // B))) * max(1.0, np.abs(want).max()) * S
     assert np.abs(want).max() > 0.02
-    for x in (a, b, c):
+    for x in (a, b, c, c2):
         assert np.abs(x - want).max() <= tol
-    assert not np.array_equal(a, b)
-    e = jf.Engine(128, 512, 1, hrir=hrir)
-    e.set_reverb(_ir(88200), 1.0)
-    assert e.reverb_partitions() == (690, 32, 42, 2048)
-    for _ in range(16):
+    assert not np.array_equal(a, b) and not np.array_equal(c, c2)
+    for fused in (False, True):    # the head as a kernel of its own in front (default), or inside the real-time kernel's launch
+        head = [] if fused else ["reverb_mac_kernel<128,1,true>"]
+        rt = "rt_block_kernel<2,8,reverb>" if fused else "rt_block_kernel<2,8>"
+        e = jf.Engine(128, 512, 1, hrir=hrir)
+        e.set_reverb_head_fused(fused)
+        e.set_reverb(_ir(88200), 1.0)
+        assert e.reverb_partitions() == (690, 32, 42, 2048)
+        for _ in range(16):
+            e.process_block()
+        ks = e.last_kernels()      # the 16th block completes big block 0: X_1, TAIL(2) and its inverse on the side stream
+        assert ks == head + ["reverb_big_fft_kernel<2048,1>@side", "reverb_big_mac_kernel<2048,1>@side",
+                             "reverb_big_ifft_kernel<2048,1>@side", rt], ks
+        e.process_block()          # the 17th block is the first of big block 1: nothing but its head
+        assert e.last_kernels() == head + [rt]
+        e.set_reverb_async(False)  # from here on everything in line on the engine's stream
+        for _ in range(15):
+            e.process_block()
+        ks = e.last_kernels()      # the 32nd block completes big block 1: X_2 behind the head
+        assert ks == ([rt, "reverb_big_fft_kernel<2048,1>"] if fused else head + ["reverb_big_fft_kernel<2048,1>", rt]), ks
+        e.process_block()          # TAIL(2) is there already (the side stream formed it a big block early)
+        assert not any(k.startswith("reverb_big") for k in e.last_kernels())
+        for _ in range(16):
+            e.process_block()
+        ks = e.last_kernels()      # the 49th block is the first of big block 3: TAIL(3) in front of the head
+        assert ks == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048,1>"] + head + [rt], ks
         e.process_block()
-    ks = e.last_kernels()          # the 16th block completes big block 0: X_1, TAIL(2) and its inverse on the side stream
-    assert ks[:4] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048,1>@side", "reverb_big_mac_kernel<2048,1>@side",
-                      "reverb_big_ifft_kernel<2048,1>@side"], ks
-    e.process_block()              # the 17th block is the first of big block 1: nothing but its head
-    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
-    e.set_reverb_async(False)      # from here on everything in line on the engine's stream
-    for _ in range(15):
-        e.process_block()
-    ks = e.last_kernels()          # the 32nd block completes big block 1: X_2 behind the head
-    assert ks[:2] == ["reverb_mac_kernel<128,1,true>", "reverb_big_fft_kernel<2048,1>"], ks
-    e.process_block()              # TAIL(2) is there already (the side stream formed it a big block early)
-    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
-    for _ in range(16):
-        e.process_block()
-    ks = e.last_kernels()          # the 49th block is the first of big block 3: TAIL(3) in front of the head
-    assert ks[:3] == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048,1>", "reverb_mac_kernel<128,1,true>"], ks
-    e.process_block()
-    assert not any(k.startswith("reverb_big") for k in e.last_kernels())
-    e.close()
+        assert not any(k.startswith("reverb_big") for k in e.last_kernels())
+        e.close()
 
 
 def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
