@@ -128,6 +128,22 @@ typedef struct jf_hrtf_grid {
     const float *ring_step;      /* [n_rings] or NULL */
 } jf_hrtf_grid;
 int jf_kemar_grid(jf_hrtf_grid *out);            /* pointers into static storage of the library */
+/*
+ * The rings of a set from the directions of its measurements -- e.g. the (azimuth, elevation) columns of a SOFA file's
+ * SourcePosition, in degrees, read with any HDF5 tool: measurements whose elevations lie within tol_deg of each other form a
+ * ring; a ring's measurements must sit at i * 360 / count from azimuth 0 within tol_deg (any order; 359.99 counts as 0; the
+ * azimuths are taken as the engine's own -- convert the set's convention first).  layout receives the rings (point a
+ * jf_hrtf_grid at its arrays; ring_step holds 360 / count), row_of[i] the table row of measurement i: hrir[row_of[i]] = IR[i].
+ * JF_ERR_ARG (text in jf_last_error(NULL)) for a set that is not such a grid.
+ */
+typedef struct jf_grid_layout {
+    int n_rings;
+    float ring_elevation[JF_MAX_RINGS];
+    int ring_count[JF_MAX_RINGS];
+    float ring_step[JF_MAX_RINGS];
+} jf_grid_layout;
+int jf_grid_from_positions(size_t n, const float *azimuth_deg, const float *elevation_deg, float tol_deg, jf_grid_layout *layout,
+                           int *row_of);
 int jf_grid_rows(const jf_hrtf_grid *grid);      /* table rows of the grid, or a JF_ERR_* code */
 int jf_engine_create_grid(const jf_config *cfg, const jf_hrtf_grid *grid, const float *hrir, int taps, jf_engine **out);
 /* idx = {ring0 low, ring0 high, ring1 low, ring1 high} rows, omegas = {A, B, C, D, E, F} as in jf_interpolation */

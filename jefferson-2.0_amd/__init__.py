@@ -38,6 +38,14 @@ class JfHrtfGrid(C.Structure):
                 ("ring_step", C.POINTER(C.c_float))]
 
 
+JF_MAX_RINGS = 40
+
+
+class JfGridLayout(C.Structure):
+    _fields_ = [("n_rings", C.c_int), ("ring_elevation", C.c_float * JF_MAX_RINGS), ("ring_count", C.c_int * JF_MAX_RINGS),
+                ("ring_step", C.c_float * JF_MAX_RINGS)]
+
+
 class JfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"jefferson error {code}: {msg}")
@@ -52,6 +60,7 @@ _SIGS = {
     "jf_engine_create_grid": (C.c_int, [C.POINTER(JfConfig), C.POINTER(JfHrtfGrid), _f, C.c_int, C.POINTER(C.c_void_p)]),
     "jf_kemar_grid": (C.c_int, [C.POINTER(JfHrtfGrid)]),
     "jf_grid_rows": (C.c_int, [C.POINTER(JfHrtfGrid)]),
+    "jf_grid_from_positions": (C.c_int, [C.c_size_t, _f, _f, C.c_float, C.c_void_p, _i]),
     "jf_grid_interpolation": (C.c_int, [C.POINTER(JfHrtfGrid), C.c_float, C.c_float, _i, _f]),
     "jf_grid_pick": (C.c_int, [C.POINTER(JfHrtfGrid), C.c_float, C.c_float]),
     "jf_table_rows": (C.c_int, [C.c_void_p]),
@@ -261,6 +270,20 @@ class Grid:
         n = g.n_rings
         return Grid([g.ring_elevation[i] for i in range(n)], [g.ring_count[i] for i in range(n)],
                     [g.ring_step[i] for i in range(n)])
+
+    @staticmethod
+    def from_positions(azimuth_deg, elevation_deg, tol_deg=0.05):
+        """(Grid, row_of): the rings of a set from its measurements' directions (include/jefferson.h: jf_grid_from_positions)"""
+        az = np.ascontiguousarray(azimuth_deg, np.float32)
+        el = np.ascontiguousarray(elevation_deg, np.float32)
+        assert az.shape == el.shape and az.ndim == 1
+        lay = JfGridLayout()
+        row_of = np.zeros(len(az), np.int32)
+        rc = lib().jf_grid_from_positions(len(az), _fp(az), _fp(el), tol_deg, C.byref(lay), _ip(row_of))
+        if rc:
+            raise JfError(rc, lib().jf_last_error(None).decode())
+        n = lay.n_rings
+        return Grid(list(lay.ring_elevation[:n]), list(lay.ring_count[:n]), list(lay.ring_step[:n])), row_of
 
     def rows(self):
         n = lib().jf_grid_rows(C.byref(self.c))

@@ -954,6 +954,17 @@ static int grid_table(const jf_hrtf_grid *grid, RingTable *rt) {
     return rc ? fail(nullptr, rc, err) : JF_OK;
 }
 
+int jf_grid_from_positions(size_t n, const float *azimuth_deg, const float *elevation_deg, float tol_deg, jf_grid_layout *layout,
+                           int *row_of) {
+    return jf_guard([&]() -> int {
+    if (!layout) return fail(nullptr, JF_ERR_ARG, "null layout");
+    std::string err;
+    const int rc = host_grid_from_positions(n, azimuth_deg, elevation_deg, tol_deg, &layout->n_rings, layout->ring_elevation,
+                                            layout->ring_count, layout->ring_step, row_of, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+    });
+}
+
 int jf_grid_rows(const jf_hrtf_grid *grid) {
     return jf_guard([&]() -> int {
     RingTable rt;

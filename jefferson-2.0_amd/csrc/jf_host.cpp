@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <vector>
 
 #include "../../include/jefferson.h"
 
@@ -97,6 +99,57 @@ int host_grid_table(int n_rings, const float *ring_ele, const int *ring_count, c
     for (int r = 0; same && r < n_rings; r++)
         same = rt.ele[r] == k.ele[r] && rt.inc[r] == k.inc[r] && rt.offset[r + 1] == k.offset[r + 1];
     *out = same ? k : rt;
+    return JF_OK;
+}
+
+// include/jefferson.h: jf_grid_from_positions -- the rings of a set from the directions of its measurements
+int host_grid_from_positions(size_t n, const float *azi, const float *ele, float tol, int *n_rings, float *ring_ele,
+                             int *ring_count, float *ring_step, int *row_of, std::string *err) {
+    auto bad = [&](const std::string &m) {
+        if (err) *err = m;
+        return JF_ERR_ARG;
+    };
+    if (!azi || !ele || !n_rings || !ring_ele || !ring_count || !ring_step || !row_of) return bad("null argument");
+    if (n == 0 || n > 32000) return bad("1 .. 32000 measurements");
+    if (!(tol >= 0.0f && tol <= 5.0f)) return bad("tolerance outside [0, 5] degrees");
+    std::vector<float> a(n);
+    std::vector<int> idx(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!(ele[i] >= -90.0f && ele[i] <= 90.0f) || !(azi[i] > -1.0e6f && azi[i] < 1.0e6f))
+            return bad("measurement " + std::to_string(i) + ": elevation outside [-90, 90] or azimuth not finite");
+        float f = azi[i] - 360.0f * floorf(azi[i] / 360.0f);
+        if (!(f < 360.0f)) f = 0.0f;
+        if (360.0f - f <= tol) f -= 360.0f;  // 359.99 is azimuth 0 of its ring
+        a[i] = f;
+        idx[i] = (int)i;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return ele[x] < ele[y]; });
+    int rings = 0, rows = 0;
+    for (size_t lo = 0; lo < n;) {
+        size_t hi = lo + 1;
+        while (hi < n && ele[idx[hi]] - ele[idx[lo]] <= tol) hi++;
+        if (rings == kMaxRings) return bad("more than JF_MAX_RINGS elevation rings");
+        const int cnt = (int)(hi - lo);
+        std::stable_sort(idx.begin() + lo, idx.begin() + hi, [&](int x, int y) { return a[x] < a[y]; });
+        const float step = 360.0f / (float)cnt;
+        for (int i = 0; i < cnt; i++) {
+            const float want = (float)i * step, got = a[idx[lo + i]];
+            if (cnt > 1 && !(fabsf(got - want) <= tol))
+                return bad("ring at elevation " + std::to_string(ele[idx[lo]]) + ": measurement " + std::to_string(idx[lo + i]) +
+                           " at azimuth " + std::to_string(got) + " where a ring of " + std::to_string(cnt) + " from azimuth 0 has " +
+                           std::to_string(want));
+            row_of[idx[lo + i]] = rows + i;
+        }
+        ring_ele[rings] = ele[idx[lo]];
+        ring_count[rings] = cnt;
+        ring_step[rings] = cnt == 1 ? 361.0f : step;
+        rows += cnt;
+        rings++;
+        lo = hi;
+    }
+    for (int r = 1; r < rings; r++)
+        if (!(ring_ele[r] > ring_ele[r - 1])) return bad("two rings at one elevation");
+    *n_rings = rings;
     return JF_OK;
 }
 

@@ -26,6 +26,8 @@ int host_grid_table(int n_rings, const float *ring_ele, const int *ring_count, c
                     std::string *err);
 int host_grid_interpolation(const RingTable &rt, float ele, float azi, int idx[4], float omegas[6]);
 int host_grid_pick(const RingTable &rt, float ele, float azi);
+int host_grid_from_positions(size_t n, const float *azi, const float *ele, float tol, int *n_rings, float *ring_ele,
+                             int *ring_count, float *ring_step, int *row_of, std::string *err);
 void host_from_spherical(float ele, float azi, float r, float out[5]);        // SoundSource.cu:41-54
 int host_from_cartesian(float x, float y, float z, float out[5], float *r);   // SoundSource.cu:20-36
 

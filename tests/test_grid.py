@@ -121,3 +121,41 @@ def test_bad_grids_are_refused():
     # KEMAR's description is recognised whatever memory it comes from, and is 710 rows
     k = jf.Grid.kemar()
     assert k.rows() == 710 and k.count.tolist() == KEMAR_COUNTS
+
+
+def test_rings_from_measurement_directions():
+    """jf_grid_from_positions: what a caller with a SOFA file's SourcePosition array does to get a jf_hrtf_grid and the row
+    order of its impulse responses -- on KEMAR's own directions (whole degrees as the files are named: up to half a degree
+    off the uniform ring), on a shuffled irregular set, and on sets that are not ring grids."""
+    from jf_load import jf
+    pos = model64.table_positions()                       # (elevation, rounded azimuth) of the 710 rows
+    ele = np.array([e for e, _ in pos], np.float32)
+    azi = np.array([a for _, a in pos], np.float32)
+    g, row_of = jf.Grid.from_positions(azi, ele, tol_deg=0.51)
+    assert g.count.tolist() == KEMAR_COUNTS and g.ele.tolist() == list(range(-40, 91, 10))
+    assert np.array_equal(row_of, np.arange(710))         # the reference's loader order IS ring by ring, azimuth ascending
+    assert g.rows() == 710
+    # an irregular set in random order, azimuths given as 0 .. 360 with noise below the tolerance and one at 359.99
+    e_r, c_r, _ = irregular_grid()
+    rng = np.random.default_rng(4)
+    el, az, want_row = [], [], []
+    row = 0
+    for r, n in enumerate(c_r):
+        for i in range(n):
+            el.append(min(90.0, e_r[r] + rng.uniform(-0.02, 0.02)))
+            az.append((i * 360.0 / n + rng.uniform(-0.02, 0.02)) % 360.0)
+            want_row.append(row)
+            row += 1
+    az[0] = 359.99
+    perm = rng.permutation(len(el))
+    g2, row_of2 = jf.Grid.from_positions(np.array(az)[perm], np.array(el)[perm], tol_deg=0.05)
+    assert g2.count.tolist() == c_r and np.allclose(g2.ele, e_r, atol=0.03)
+    assert np.array_equal(row_of2, np.array(want_row)[perm])
+    assert np.allclose(g2.step[:-1], 360.0 / np.array(c_r[:-1], np.float32))
+    for bad_az, bad_el in (([0, 90, 180, 275], [0, 0, 0, 0]),            # not uniform
+                           ([10, 100, 190, 280], [0, 0, 0, 0]),           # does not start at azimuth 0
+                           ([0, 180, 0, 180], [0, 0, 0.01, 0.01]),        # two rings closer than the tolerance: duplicates in one
+                           ([0.0], [95.0])):
+        with pytest.raises(jf.JfError) as ex:
+            jf.Grid.from_positions(np.array(bad_az, np.float32), np.array(bad_el, np.float32), tol_deg=0.05)
+        assert ex.value.code == jf.JF_ERR_ARG
