@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
 #pragma unroll
     for (int t = 0; t < NTR; t++) {
         const int g = min(turn * NTR + t, n_items - 1);  // (an odd last item is done twice)
-        const int i = g / P.S, s = g - i * P.S;
+        const int i = g / P.S, s = g - i * P.S;  // (a source's transforms one after the other -- memory order, which the inverse gains 11 % from -- cost THIS kernel 15 %: 33.3 against 28.9 us)
         // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
         // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
         const float *ring = P.dryring + (size_t)s * P.Rn * B1;
@@ -661,6 +661,15 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
         const float2 *q = reinterpret_cast<const float2 *>(base + voff);
         return rv_v2{q->x, q->y};
     };
+#if JF_RV_BIG_NT_X
+    // the delay line is read once per launch: streamed past the caches' replacement order (non-temporal)
+    auto load_x = [&](const char *base) {
+        const rv_v2 *q = reinterpret_cast<const rv_v2 *>(base + voff);
+        return __builtin_nontemporal_load(q);
+    };
+#else
+    auto load_x = load_at;
+#endif
     auto slot_of = [&](int u) {  // slot of X_{anchor + i0 + u} (u may be far in the past)
         int slot = (P.anchor_slot_first + i0 + u) % P.R1;
         return slot < 0 ? slot + P.R1 : slot;
@@ -670,7 +679,7 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
     for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
     // the window: X(i), i = 1 .. KB - 1 (products past the end of the launch read whatever lies there and are not stored)
 #pragma unroll
-    for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_at(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
+    for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_x(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
     int xslot = slot_of(0);
 #if JF_RV_BIG_SCALAR_MAC
     auto step = [&](int j) {  // j = q mod KB, a constant after unrolling
@@ -702,7 +711,7 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
     int q_pf = 0;
     auto fetch = [&](int d) {
         hq[d] = load_at(hp);
-        xq[d] = load_at(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
+        xq[d] = load_x(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
         xslot = xslot == 0 ? P.R1 - 1 : xslot - 1;
         if (++q_pf < n_steps) hp += (size_t)B1 * 8;
     };
@@ -813,8 +822,14 @@ __global__ __launch_bounds__(kBigThreads, JF_RV_BIG_IFFT_WAVES) void reverb_big_
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
+#if JF_RV_BIG_NT_Y
+                const c2 yk_ = __builtin_nontemporal_load(reinterpret_cast<const c2 *>(y + q));
+                const c2 ym_ = __builtin_nontemporal_load(reinterpret_cast<const c2 *>(y + ((B1 - q) & (B1 - 1))));
+                const float2 yk = make_float2(yk_.x, yk_.y), ym = make_float2(ym_.x, ym_.y);
+#else
                 const float2 yk = y[q];
                 const float2 ym = y[(B1 - q) & (B1 - 1)];
+#endif
                 if (q == 0) {
                     v[t][r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
                 } else {

@@ -45,6 +45,17 @@ typedef c2 rv_v2;
 #ifndef JF_RV_BIG_PREFETCH
 #define JF_RV_BIG_PREFETCH 4
 #endif
+// reverb_big_mac_kernel: the delay line's spectra -- 247 MB per launch at config 5's batch shape, each read ONCE -- as non-temporal
+// loads.  The product kernel itself gains 1-4 % (69.3 against 70.4-72.8 us); every kernel BEHIND it gains more, because the
+// stream no longer washes their data out of the L2 and the Infinity Cache: inverse transforms 29.5 -> 26.3 us, forward 28.2 ->
+// 25.9, small transforms 12.4 -> 10.8, the spatialiser 136.8 -> 132.9; the step 0.2877-0.2912 -> 0.2744 ms (one box, one
+// call, A B C A B: profiles/r05/reverb_batch.md)
+#ifndef JF_RV_BIG_NT_X
+#define JF_RV_BIG_NT_X 1
+#endif
+#ifndef JF_RV_BIG_NT_Y
+#define JF_RV_BIG_NT_Y 0  // the inverse transforms' reads of the products (each read once, by them)
+#endif
 // reverb_big_fft_kernel: the split's twiddles loaded before the transform instead of behind its last pass: 45.4 -> 42.4 us per
 // launch at config 5's batch shape (rocprofv3, 320 launches, twice; -DJF_RV_BIG_SPLIT_TW_EARLY=0 is the old form)
 #ifndef JF_RV_BIG_SPLIT_TW_EARLY
