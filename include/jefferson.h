@@ -412,6 +412,11 @@ int jf_debug_set_reverb_async(jf_engine *e, int on);
  * 5 us slower per block at 256 sources, a head being one wave's chain there (profiles/r05/reverb_realtime.md).  Same sums of
  * the same products in another order: equal to float32 rounding, not bit for bit. */
 int jf_debug_set_reverb_head_fused(jf_engine *e, int on);
+/* A batch call of whole big blocks that ends on a big-block boundary reads none of the small transforms of its last blocks --
+ * they are state for a later call's head, and the next such call never looks at them -- so by default (on) it puts them off:
+ * its last transform leaves the samples in the dry ring, and the first call that takes a block through the head forms them
+ * from there (same samples, same transform: the same bits; 12 us of config 5's batch step).  on = 0: formed by every call. */
+int jf_debug_set_reverb_lazy_state(jf_engine *e, int on);
 /* The schedule of the non-uniformly partitioned reverb for a call of K blocks that starts at absolute block j0, with big blocks
  * of M blocks and TAIL formed up to big block fut_m (host logic only: no engine, no GPU; tests/test_reverb_plan.py replays
  * runs of calls against a model of the rings).  out = {m_lo, n_tr, ma, n_mid, n_ranges, kb0, kn0, kb1, kn1, copy_lo, copy_hi,

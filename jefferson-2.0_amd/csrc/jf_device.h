@@ -192,6 +192,11 @@ struct ReverbParams {
     int skip_lo = 0, skip_hi = 0;
     // the multiply-accumulate / finishing stage works on blocks kb .. kb + kn - 1 of the call (set by launch_reverb)
     int kb = 0, kn = 0;
+    // CATCH-UP (round 5): the K blocks are the last blocks of an EARLIER call whose small transforms were put off (a batch
+    // call of whole big blocks leaves them to whoever needs them: ReverbBigParams::state_out): their samples are read from the
+    // dry ring -- block k at ring position dry_pos0 + k B, the block before it B in front -- and only their spectra are
+    // written (slots head + k): no ring, no play position, no previous block (the call that put them off left those)
+    int catchup = 0;
 };
 
 // The non-uniformly partitioned reverb's second level: partitions of B1 = M * B taps (transform length 2 B1).
@@ -236,6 +241,15 @@ struct ReverbBigParams {
     int to_wet = 0;             // 0: Y_i -> fut ring block (fut_first + i) mod Fn;  1: -> the wet ring, blocks wet_k0 + M i .. + M - 1 of the call
     int fut_first = 0, wet_k0 = 0;
     int mac_wgs = 0;  // single products: at most this many workgroups, taking the items in turn (0: one per item)
+    // transforms of a batch call that ENDS on a big-block boundary and puts its small transforms off (jf_engine.cpp:
+    // rv_small_stale): the last transform of every source -- its 2 B1 samples are the call's last two big blocks -- also leaves
+    // what the small transforms' kernel would have left: those samples in the dry ring (later transforms and a catch-up read
+    // them there), the call's last block as `prev`, the play position behind the call
+    int state_out = 0;
+    float *dryring_out = nullptr;  // = dryring
+    float *prev_out = nullptr;     // [S][B]
+    int *dry_count_out = nullptr;  // [S]
+    int call_samples = 0;          // K B
 };
 
 // What the reverb stage does in one call (host side; launch_reverb)

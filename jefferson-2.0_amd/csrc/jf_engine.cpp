@@ -42,6 +42,7 @@ hipError_t launch_rt_block(const FusedParams &P, const RingTable &rt, const floa
 hipError_t launch_reverb_ir(const float *d_ir, int n_ir, int P, int B, float scale, const float2 *d_tw,
                             float2 *d_hspec, hipStream_t st);
 hipError_t launch_reverb(const ReverbParams &P, ReverbPlan *plan, hipStream_t st, int *form_used);
+hipError_t launch_reverb_catchup(const ReverbParams &P, hipStream_t st);
 int big_twiddle_pack_len(int B1);
 int big_twiddle_pack_index(int B1, int k);
 hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st);
@@ -204,6 +205,15 @@ struct jf_engine {
     int rv_head_fused = 0;       // jf_debug_set_reverb_head_fused
     bool post_tr = false;        // transforms left in line behind the fused head (run_reverb_stage -> jf_submit_block)
     ReverbBigParams post_tr_p;
+    // A batch call of whole big blocks that ENDS on a big-block boundary reads none of the small transforms of its last 2 M - 1
+    // blocks: they are state for a later call's head -- and the next such call never looks at them.  They are put off
+    // (rv_small_stale; the call's last transform leaves the samples in the dry ring, the previous block and the play position:
+    // ReverbBigParams::state_out) and formed from the dry ring by the first call that has a block for the head
+    // (launch_reverb_catchup: same samples, same transform, same bits).  12 us of config 5's 290 us batch step.
+    bool rv_small_stale = false;
+    bool last_catchup = false;   // the last call began with the catch-up (jf_debug_last_kernels)
+    bool last_small_fft = true;  // ... and launched the small transforms' kernel
+    int rv_lazy_small = 1;       // jf_debug_set_reverb_lazy_state
     int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
                                  // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md)
 };
@@ -325,6 +335,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out =
     R.mac_form = e->rv_form;
     ReverbPlan plan;
     plan.big = e->rv_P1 > 0;
+    bool defer_small = false, need_small = true;
     // One-block calls -- the real-time shape -- keep the big partitions' kernels off the block's critical path.  The head
     // covers TWO big blocks of taps (2 M partitions of B), so TAIL(m) = sum_{q >= 2} X_{m+1-q} H'_q needs nothing newer than
     // X_{m-1}, which exists a whole big block before big block m begins.  When a one-block call completes big block mb, the
@@ -379,7 +390,18 @@ static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out =
         auto mod = [](long long a, int n) { return (int)(((a % n) + n) % n); };
         const ReverbSchedule sc = host_reverb_schedule(j0, K, M, e->rv_fut_m);  // which X_m, FULL, TAIL and ranges: jf_host.cpp
         e->rv_fut_m = sc.fut_m;
+        // whole big blocks up to the call's end: the small transforms of its last blocks are put off (rv_small_stale) ...
+        defer_small = e->rv_lazy_small && sc.n_mid > 0 && sc.kn[1] == 0 && sc.n_tr > 0;
+        // ... and a call that takes a block through the head needs the ones an earlier call put off, first
+        need_small = sc.n_mid == 0 || sc.kn[0] > 0 || sc.kn[1] > 0;
         plan.transforms = G;
+        if (defer_small) {
+            plan.transforms.state_out = 1;
+            plan.transforms.dryring_out = e->d_rv_dryring;
+            plan.transforms.prev_out = e->d_rv_prev[p ^ 1];
+            plan.transforms.dry_count_out = e->d_rv_count[p ^ 1];
+            plan.transforms.call_samples = K * e->B;
+        }
         plan.transforms.n_tr = sc.n_tr;
         plan.transforms.tr_slot_first = mod(sc.m_lo, R1);
         plan.transforms.tr_rel_first = (int)((sc.m_lo - 2) * B1 - j0 * e->B);
@@ -400,6 +422,10 @@ static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out =
         R.copy_hi = sc.copy_hi;
         R.skip_lo = sc.skip_lo;
         R.skip_hi = sc.skip_hi;
+        if (defer_small) {
+            R.copy_hi = R.copy_lo;   // nothing is copied, nothing behind the front blocks is transformed
+            R.skip_hi = K;
+        }
         auto tail_for = [&](long long m) {  // TAIL(m) = sum_{q = 2 .. P1} X_{m+1-q} H'_q: the newest spectrum is X_{m-1}
             ReverbBigParams T = G;
             T.n_prod = 1;
@@ -441,6 +467,21 @@ static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out =
         if (plan.transforms.n_tr > e->rv_steps_max || n_mid > e->rv_steps_max)
             return fail(e, JF_ERR_STATE, "reverb: more big-partition steps in a call than buffers");
     }
+    e->last_small_fft = K - (R.skip_hi - R.skip_lo) > 0;
+    e->last_catchup = false;
+    if (e->rv_small_stale && need_small) {
+        // the last 2 M - 1 blocks before this call, from the dry ring: block rv_blocks - n .. rv_blocks - 1, slots rv_head - n ..
+        ReverbParams C = R;
+        const int n = 2 * e->rv_M - 1;
+        C.K = n;
+        C.catchup = 1;
+        C.head = (int)((((long long)e->rv_head - n) % e->rv_Rg + e->rv_Rg) % e->rv_Rg);
+        C.dry_pos0 = (int)((((e->rv_blocks - n) * e->B) % R.Rd + R.Rd) % R.Rd);
+        C.copy_lo = C.copy_hi = C.skip_lo = C.skip_hi = 0;
+        JF_HIP(e, launch_reverb_catchup(C, e->stream));
+        e->rv_small_stale = false;
+        e->last_catchup = true;
+    }
     plan.head_fused = head_out != nullptr && K == 1 && e->rv_head_fused && e->rv_form == 0 && e->profiling < 2 &&
                       e->rv_P <= kRvFusedHeadMax && rt_waves_per_wg(e->S) == 8 && (e->B == 64 || e->B == 128 || e->B == 256);
     {
@@ -466,6 +507,7 @@ static int run_reverb_stage(jf_engine *e, int p, int K, ReverbParams *head_out =
     if (er) JF_HIP(e, hipEventRecord(er->b, e->stream));
     e->rv_head = (e->rv_head + K) % e->rv_Rg;
     e->rv_blocks += K;
+    if (defer_small) e->rv_small_stale = true;  // (a stale state from before is obsolete now: older than the head reaches)
     return JF_OK;
 }
 
@@ -653,6 +695,7 @@ void quiesce_side(jf_engine *e) {
 void free_reverb(jf_engine *e) {
     quiesce_side(e);
     e->side_tr = false;
+    e->rv_small_stale = false;
     e->last_side.clear();
     (void)hipFree(e->d_rv_yacc);
     e->d_rv_yacc = nullptr;
@@ -1781,6 +1824,14 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
     });
 }
 
+int jf_debug_set_reverb_lazy_state(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    e->rv_lazy_small = on != 0;  // (transforms already put off are still formed by the call that needs them)
+    return JF_OK;
+    });
+}
+
 int jf_debug_set_reverb_head_fused(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
     if (!e) return JF_ERR_ARG;
@@ -1907,6 +1958,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
         std::string k;
         if (!e->last_rt && !e->last_prep_skipped) k = "prep_kernel;";
         if (e->rv_P > 0) {
+            if (e->last_catchup) k += "reverb_fft_kernel<" + bs + ">@ring;";
             const ReverbPlan &pl = e->last_plan;
             const std::string b1 = std::to_string(e->rv_B1);
             auto per_wg = [&](int) { return std::string(",1>;"); };  // transforms per workgroup and turn (persistent since round 5)
@@ -1931,7 +1983,7 @@ const char *jf_debug_last_kernels(jf_engine *e) {
                 k += stage_b(4);
                 if (pl.big) k += transforms(pl.transforms);
             } else {
-                k += "reverb_fft_kernel<" + bs + ">;";
+                if (e->last_small_fft) k += "reverb_fft_kernel<" + bs + ">;";
                 if (pl.big) {
                     if (pl.n_ranges > 1) k += stage_b(pl.forms[0]);
                     k += transforms(pl.transforms);

@@ -604,6 +604,22 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
                 v[t][r] = make_float2(sg.ptr[i0], sg.ptr[i1]);
             }
         }
+        // a call that puts its small transforms off: its last two big blocks of samples -- this source's last transform has them
+        // in registers -- into the dry ring, its last block as `prev`, the play position behind it (ReverbBigParams::state_out)
+        if (P.state_out && i == P.n_tr - 1 && turn * NTR + t < n_items && tid < B1 / 8) {
+            float *ring_out = P.dryring_out + (size_t)s * Rd;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int rel = rel0 + 2 * (tid + r * (B1 / 8));
+                if (rel >= 0) {  // (what lies before the call is in the ring already)
+                    int pos = P.dry_pos0 + rel;   // < 2 Rd: the ring is longer than a call
+                    pos = pos >= Rd ? pos - Rd : pos;
+                    *reinterpret_cast<float2 *>(ring_out + pos) = v[t][r];
+                    if (rel >= P.call_samples - P.B) *reinterpret_cast<float2 *>(P.prev_out + (size_t)s * P.B + (rel - (P.call_samples - P.B))) = v[t][r];
+                }
+            }
+            if (tid == 0) P.dry_count_out[s] = (int)(((unsigned)dc0 + (unsigned)P.call_samples) % (unsigned)L);
+        }
     }
     cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, s_w8, tid);
 #pragma unroll
@@ -1027,7 +1043,20 @@ static int launch_stage(const ReverbParams &P, ReverbPlan *plan, hipStream_t st)
 
 template <int B>
 static void launch_fft(const ReverbParams &P, hipStream_t st) {
-    hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3(((P.K - (P.skip_hi - P.skip_lo)) * P.S + 3) / 4), dim3(256), 0, st, P);
+    const int n = (P.K - (P.skip_hi - P.skip_lo)) * P.S;  // (a call of whole big blocks that puts its small transforms off: none)
+    if (n > 0) hipLaunchKernelGGL(reverb_fft_kernel<B>, dim3((n + 3) / 4), dim3(256), 0, st, P);
+}
+
+// the small transforms a batch call put off, from the dry ring (ReverbParams::catchup)
+hipError_t launch_reverb_catchup(const ReverbParams &P, hipStream_t st) {
+    if (!P.catchup || P.K <= 0) return hipErrorInvalidValue;
+    switch (P.B) {
+    case 64: launch_fft<64>(P, st); break;
+    case 128: launch_fft<128>(P, st); break;
+    case 256: launch_fft<256>(P, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_reverb_big_ir(const float *d_ir, int n_ir, int t0, int P1, int B1, float scale, const float2 *d_tw1,

@@ -224,6 +224,17 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
     const int cur0 = (int)(((unsigned)dc0 + (unsigned)(k * B)) % (unsigned)L);
     const int prv0 = (int)(((unsigned)dc0 + (unsigned)((k > 0 ? k - 1 : 0) * B)) % (unsigned)L);
     const float *prev_state = P.prev_in + (size_t)s * B;
+    if (P.catchup) {
+        // the block's and its predecessor's samples from the dry ring (a multiple of B long: a block never wraps inside)
+        const float *ring = P.dryring + (size_t)s * P.Rd;
+        int pc = (P.dry_pos0 + k * B) % P.Rd;
+        int pp = pc - B;
+        pp = pp < 0 ? pp + P.Rd : pp;
+        for (int m = lane; m < B; m += 64) {
+            const int n = 2 * m;
+            a[m] = *reinterpret_cast<const float2 *>(ring + (n < B ? pp + n : pc + (n - B)));
+        }
+    } else {
     if (k >= P.copy_lo && k < P.copy_hi) {
         // a block whose output the big partitions form directly (ReverbBigParams: FULL) and whose spectrum nobody will read:
         // its samples go to the dry ring, nothing else (never the call's last block, which leaves the state)
@@ -273,6 +284,7 @@ JF_DEV void rv_forward(const ReverbParams &P, int k, int s, float2 *a, float2 *b
             po[n] = sg.ptr[idx];
         }
         if (lane == 0) P.dry_count_out[s] = (int)(((unsigned)dc0 + (unsigned)(P.K * B)) % (unsigned)L);
+    }
     }
     JF_RV_SYNC();
     const float2 *Z = cfft_small<B, -1>(a, b, tw, lane);

@@ -386,6 +386,54 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
         e.close()
 
 
+@pytest.mark.parametrize("B", [128, 256])
+def test_small_transforms_put_off_by_calls_of_whole_big_blocks(jf, hrir, castanets, B):
+    """A batch call of whole big blocks that ends on a big-block boundary puts the small transforms of its last 2 M - 1
+    blocks off (state for a later call's head only); whoever takes a block through the head next forms them from the dry
+    ring.  Same samples, same transform: runs of calls that mix such calls with per-block calls, ragged batch calls, calls
+    that begin inside a big block, resets and a new signal must be bit-identical to an engine that forms them at once
+    (jf_debug_set_reverb_lazy_state), and both within tolerance of the float64 model."""
+    S = 3
+    M = 16 if B <= 128 else 8
+    # call sizes in blocks: whole big blocks (put off), again (the ones owed become obsolete), a block of its own (catch-up),
+    # ragged calls up to a boundary, a whole big block (put off), a batch call with a ragged end (catch-up), up to a boundary
+    # again, whole big blocks (put off), per-block calls (catch-up)
+    sizes = [2 * M, 3 * M, 1, 1, 5, M - 7, M, 2 * M + 3, M - 3, 2 * M, 1, 1]
+    K = sum(sizes)
+    ir = _ir(M * B * 5 + 77, decay=3.0)
+    gain = 0.6
+    sigs = [castanets[5000 * s: 5000 * s + 12000 + 91 * s] for s in range(S)]
+    pos = _positions(jf, S, K)
+    outs = {}
+    for lazy in (True, False):
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=max(sizes))
+        e.set_reverb_lazy_state(lazy)
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+        e.set_reverb(ir, gain)
+        got, b0, seen = [], 0, []
+        for n, k in enumerate(sizes):
+            if n == 2:
+                e.reset(1)                      # between a put-off state and its catch-up ...
+            if n == 10:
+                e.set_signal(2, castanets[:7000])    # ... and a new signal for a source whose old samples are still owed
+            if k == 1:
+                e.set_latched(pos[b0])
+                got.append(e.process_block()[None])
+            else:
+                got.append(e.process_batch(pos[b0:b0 + k]))
+            seen.append(any(x == "reverb_fft_kernel<%d>@ring" % B for x in e.last_kernels()))
+            b0 += k
+        e.close()
+        outs[lazy] = np.concatenate(got)
+        # catch-ups: the calls behind a call of whole big blocks that have a block for the head (never when formed at once)
+        # (a ragged batch call that begins where whole big blocks ended is one of them: call 7)
+        assert seen == ([False, False, True, False, False, False, False, True, False, False, True, False] if lazy
+                        else [False] * len(sizes)), seen
+    assert np.abs(outs[True]).max() > 0.02
+    assert np.array_equal(outs[True], outs[False])
+
+
 def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
     """A source reset, a new signal and a pause in the middle of a run, between steps of the big partitions: the
     non-uniform engine follows the uniform one (same calls) within the float32 tolerance of two decompositions."""
