@@ -417,6 +417,14 @@ int jf_debug_set_reverb_head_fused(jf_engine *e, int on);
  * its last transform leaves the samples in the dry ring, and the first call that takes a block through the head forms them
  * from there (same samples, same transform: the same bits; 12 us of config 5's batch step).  on = 0: formed by every call. */
 int jf_debug_set_reverb_lazy_state(jf_engine *e, int on);
+/* One-block calls through the one-launch real-time kernel launch the reverb stage of the NEXT block right behind their own
+ * spatialiser (on, the default): the stage needs the dry signals and its own state, not the positions the host sets for that
+ * block, so the next call finds the wet block there and launches the spatialiser alone -- the head kernel leaves the block's
+ * critical path (between two audio callbacks it has the whole block period).  Only a plain head goes ahead (no big block
+ * completed, no TAIL owed); a new signal, a reset, a new response, a batch call or a switch of the stage's knobs takes it back
+ * (the stream is waited for, the stage is done again by the call that needs it).  Bit-identical.  on = 0: every call runs its
+ * own stage first. */
+int jf_debug_set_reverb_ahead(jf_engine *e, int on);
 /* The schedule of the non-uniformly partitioned reverb for a call of K blocks that starts at absolute block j0, with big blocks
  * of M blocks and TAIL formed up to big block fut_m (host logic only: no engine, no GPU; tests/test_reverb_plan.py replays
  * runs of calls against a model of the rings).  out = {m_lo, n_tr, ma, n_mid, n_ranges, kb0, kn0, kb1, kn1, copy_lo, copy_hi,

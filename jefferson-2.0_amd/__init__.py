@@ -121,6 +121,7 @@ _SIGS = {
     "jf_debug_set_reverb_async": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_head_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_lazy_state": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_set_reverb_ahead": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_sources_set_latched": (C.c_int, [C.c_void_p, _f]),
     "jf_device_numa_node": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "jf_pin_thread_to_device": (C.c_int, [C.c_int]),
@@ -488,6 +489,10 @@ class Engine:
     def set_reverb_async(self, on):
         """one-block calls: the big partitions' kernels on a second stream (default) or in line"""
         self._chk(lib().jf_debug_set_reverb_async(self.h, int(bool(on))))
+
+    def set_reverb_ahead(self, on):
+        """one-block calls launch the next block's reverb stage behind their own spatialiser (default) or not"""
+        self._chk(lib().jf_debug_set_reverb_ahead(self.h, int(bool(on))))
 
     def set_reverb_lazy_state(self, on):
         """batch calls of whole big blocks put the small transforms of their last blocks off (default) or form them at once"""

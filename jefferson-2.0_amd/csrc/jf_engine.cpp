@@ -210,6 +210,26 @@ struct jf_engine {
     // (rv_small_stale; the call's last transform leaves the samples in the dry ring, the previous block and the play position:
     // ReverbBigParams::state_out) and formed from the dry ring by the first call that has a block for the head
     // (launch_reverb_catchup: same samples, same transform, same bits).  12 us of config 5's 290 us batch step.
+    // THE STAGE OF THE NEXT BLOCK, AHEAD (round 5).  The reverb stage of a block needs the dry signals and its own state, not the
+    // positions the host sets for that block: a one-block call through the real-time kernel therefore launches the NEXT block's
+    // stage right behind its own spatialiser (same stream: ordered by construction), and the next call finds the wet block
+    // there and launches the spatialiser alone -- the head kernel (8 us at config 5's 256 sources) leaves the block's critical
+    // path: between two audio callbacks it has 2.9 ms to itself; in calls back to back it overlaps with the host's turn-around.
+    // Only for a plain head (no big block completed, no TAIL owed, nothing put off); anything that changes what the stage read
+    // or wrote -- a new signal, a reset, a new response, a batch call, a switch of the stage's knobs -- DISCARDS it
+    // (rv_ahead_discard: wait for the stream, take the stage's bookkeeping back; its writes are overwritten by the stage
+    // done again).  Same kernels on the same data in the same order: bit-identical.
+    int rv_ahead_on = 1;          // jf_debug_set_reverb_ahead
+    bool rv_ahead = false;        // the next block's stage has been launched
+    struct {
+        int rv_head = 0, last_rv_form = 0;
+        long long rv_blocks = 0, rv_fut_m = 0;
+        ReverbPlan last_plan;
+        std::string last_side;
+        bool last_catchup = false, last_small_fft = true;
+    } rv_book;                    // the stage's bookkeeping before that launch
+    std::string kernels_frozen;   // jf_debug_last_kernels of the call that launched it (the stage's fields describe the NEXT block)
+    bool kernels_use_frozen = false;
     bool rv_small_stale = false;
     bool last_catchup = false;   // the last call began with the catch-up (jf_debug_last_kernels)
     bool last_small_fft = true;  // ... and launched the small transforms' kernel
@@ -556,10 +576,45 @@ static int ensure_interp_rows(jf_engine *e) {
     return JF_OK;
 }
 
+// The next block's stage launched ahead (jf_engine::rv_ahead) is taken back: see there.
+static int rv_ahead_discard(jf_engine *e) {
+    if (!e->rv_ahead) return JF_OK;
+    JF_HIP(e, hipStreamSynchronize(e->stream));  // nothing of it is still being written
+    e->rv_head = e->rv_book.rv_head;
+    e->rv_blocks = e->rv_book.rv_blocks;
+    e->rv_fut_m = e->rv_book.rv_fut_m;
+    e->last_rv_form = e->rv_book.last_rv_form;
+    e->last_plan = e->rv_book.last_plan;
+    e->last_side = e->rv_book.last_side;
+    e->last_catchup = e->rv_book.last_catchup;
+    e->last_small_fft = e->rv_book.last_small_fft;
+    e->rv_ahead = false;
+    e->kernels_use_frozen = false;
+    return JF_OK;
+}
+
+// May the stage of the block after the one just launched go ahead?  A plain head only: the block completes no big block (its
+// transforms would have to follow its spatialiser), owes no TAIL, the side stream has nothing urgent, nothing is put off.
+static bool rv_ahead_possible(const jf_engine *e) {
+    if (e->rv_P <= 0 || !e->rv_ahead_on || e->rv_form != 0 || e->profiling || e->rv_head_fused || e->rv_small_stale) return false;
+    if (e->S > e->rt_max_sources || e->S >= 2048) return false;  // (the one-launch path; the one-block head kernel's range)
+    if (e->paused.load(std::memory_order_relaxed)) return false;
+    if (e->rv_P1 > 0) {
+        if (e->rv_side_urgent || e->side_tr) return false;
+        const ReverbSchedule sc = host_reverb_schedule(e->rv_blocks, 1, e->rv_M, e->rv_fut_m);
+        if (sc.n_tr > 0 || sc.tail_early >= 0 || sc.tail_late >= 0) return false;
+    }
+    return true;
+}
+
 // prep -> [reverb] -> fused -> mix on the engine stream, K blocks starting at d_pos.
 // first_block: index of d_pos's first block in the uploaded trajectory (jf_batch_run), -1 for positions from elsewhere.
 int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int first_block = -1) {
     if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);  // fatal: see device_fault
+    {
+        const int rc = rv_ahead_discard(e);  // (a stage launched ahead by a one-block call: this call does its own)
+        if (rc) return rc;
+    }
     const int p = e->cur;
     EventPair *ep = nullptr, *ef = nullptr, *em = nullptr;
     // a pair of event records costs ~7 us of stream time: they may be put around every n-th run only (the runs in
@@ -1070,6 +1125,10 @@ int jf_source_set_signal(jf_engine *e, int src, const float *mono, size_t n) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
     if (!valid_src(e, src) || (n && !mono) || n > 0x7fffffffu) return fail(e, JF_ERR_ARG, "bad source or signal");
+    {
+        const int rc = rv_ahead_discard(e);  // (the stage launched ahead read the old signal)
+        if (rc) return rc;
+    }
     JF_HIP(e, hipStreamSynchronize(e->stream));
     if (e->rv_side && e->rv_side_busy) JF_HIP(e, hipStreamSynchronize(e->rv_side));  // its transforms read the signals
     // The device copy always has length >= PAD_LEN so that the kernel wraps the loop with
@@ -1153,6 +1212,10 @@ int jf_source_reset(jf_engine *e, int src) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
     if (!valid_src(e, src)) return fail(e, JF_ERR_ARG, "bad source index");
+    {
+        const int rc = rv_ahead_discard(e);
+        if (rc) return rc;
+    }
     JF_HIP(e, hipStreamSynchronize(e->stream));
     return reset_sources(e, src);
     });
@@ -1216,7 +1279,10 @@ int jf_submit_block(jf_engine *e) {
             e->ahead.valid = false;  // this block moves every source's old position
             ReverbParams head;
             bool head_fused = false;
-            {
+            e->kernels_use_frozen = false;
+            if (e->rv_ahead) {
+                e->rv_ahead = false;  // the stage of this block was launched behind the last block's spatialiser: rv_ahead
+            } else {
                 // the wet ring is then this block's signal (written by the stage's own kernel, or by the real-time kernel's
                 // waves themselves: head_fused)
                 const int rc = run_reverb_stage(e, p, 1, &head, &head_fused);
@@ -1260,6 +1326,22 @@ int jf_submit_block(jf_engine *e) {
             e->last_rt = true;
             e->rt_wgs = wgs;
             e->in_flight = true;
+            if (rv_ahead_possible(e)) {
+                // the NEXT block's stage, behind this block's spatialiser (jf_engine::rv_ahead)
+                e->kernels_frozen = jf_debug_last_kernels(e);
+                e->rv_book.rv_head = e->rv_head;
+                e->rv_book.rv_blocks = e->rv_blocks;
+                e->rv_book.rv_fut_m = e->rv_fut_m;
+                e->rv_book.last_rv_form = e->last_rv_form;
+                e->rv_book.last_plan = e->last_plan;
+                e->rv_book.last_side = e->last_side;
+                e->rv_book.last_catchup = e->last_catchup;
+                e->rv_book.last_small_fft = e->last_small_fft;
+                const int rc = run_reverb_stage(e, e->cur, 1);
+                if (rc) return rc;
+                e->rv_ahead = true;
+                e->kernels_use_frozen = true;
+            }
             return JF_OK;
         }
         JF_HIP(e, hipMemcpyAsync(e->d_pos_rt, e->h_pos_pinned, sizeof(float) * 5 * e->S, hipMemcpyHostToDevice,
@@ -1379,6 +1461,10 @@ int jf_reverb_set_ir(jf_engine *e, const float *ir, size_t n_ir, float gain) {
     DeviceGuard bind(e);
     if (!e || (n_ir && !ir) || n_ir > (size_t)1 << 26) return fail(e, JF_ERR_ARG, "bad impulse response");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
+    {
+        const int rc = rv_ahead_discard(e);
+        if (rc) return rc;
+    }
     JF_HIP(e, hipStreamSynchronize(e->stream));
     const bool was_on = e->rv_P > 0;
     free_reverb(e);
@@ -1675,6 +1761,11 @@ void *jf_engine_stream(jf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int jf_profile_enable(jf_engine *e, int enable) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     DeviceGuard bind(e);
     if (!e) return JF_ERR_ARG;
     JF_HIP(e, hipStreamSynchronize(e->stream));
@@ -1732,6 +1823,11 @@ int jf_debug_copy_from_device(jf_engine *e, const void *device_ptr, void *host, 
 
 int jf_debug_set_rt_max_sources(jf_engine *e, int n) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     if (!e || n < 0) return JF_ERR_ARG;
     e->rt_max_sources = n;
     return JF_OK;
@@ -1762,6 +1858,11 @@ int jf_debug_source_order(const jf_engine *e, int *order) {
 
 int jf_debug_set_reverb_form(jf_engine *e, int form) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     if (!e || form < 0 || form > 3) return JF_ERR_ARG;
     e->rv_form = form;
     return JF_OK;
@@ -1824,8 +1925,24 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how) {
     });
 }
 
+int jf_debug_set_reverb_ahead(jf_engine *e, int on) {
+    return jf_guard([&]() -> int {
+    if (!e) return JF_ERR_ARG;
+    DeviceGuard bind(e);
+    const int rc = rv_ahead_discard(e);
+    if (rc) return rc;
+    e->rv_ahead_on = on != 0;
+    return JF_OK;
+    });
+}
+
 int jf_debug_set_reverb_lazy_state(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     if (!e) return JF_ERR_ARG;
     e->rv_lazy_small = on != 0;  // (transforms already put off are still formed by the call that needs them)
     return JF_OK;
@@ -1834,6 +1951,11 @@ int jf_debug_set_reverb_lazy_state(jf_engine *e, int on) {
 
 int jf_debug_set_reverb_head_fused(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     if (!e) return JF_ERR_ARG;
     e->rv_head_fused = on != 0;
     return JF_OK;
@@ -1842,6 +1964,11 @@ int jf_debug_set_reverb_head_fused(jf_engine *e, int on) {
 
 int jf_debug_set_reverb_async(jf_engine *e, int on) {
     return jf_guard([&]() -> int {
+    if (e) {
+        DeviceGuard bind_(e);
+        const int rc_ = rv_ahead_discard(e);  // (the next block's stage may have gone ahead in the old form)
+        if (rc_) return rc_;
+    }
     if (!e) return JF_ERR_ARG;
     e->rv_async = on != 0;  // what the side stream has in flight is waited for by the next call's stage (run_reverb_stage)
     return JF_OK;
@@ -1953,6 +2080,7 @@ int jf_debug_last_source_group(const jf_engine *e) { return e ? e->last_group : 
 
 const char *jf_debug_last_kernels(jf_engine *e) {
     if (!e) return "";
+    if (e->kernels_use_frozen) return e->kernels_frozen.c_str();  // (the stage's fields describe the block launched ahead)
     try {
         const std::string nb = std::to_string(e->B / 64), bs = std::to_string(e->B);
         std::string k;

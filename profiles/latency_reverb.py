@@ -18,6 +18,8 @@ for uniform in ((False,) if os.environ.get("JF_RV_ONLY_NONUNIFORM") else (False,
     for s in range(S):
         e.set_signal(s, np.random.default_rng(1234 + s).uniform(-.5, .5, 44100).astype(np.float32))
         e.set_spherical(s, -40 + (s * 7) % 121, (s * 37) % 360, 1.0)
+    if os.environ.get("JF_RV_NO_AHEAD"):      # round 4's order: every call runs its own stage in front of its spatialiser
+        e.set_reverb_ahead(0)
     if os.environ.get("JF_RV_HEAD_OWN"):      # round 4's form: the head as a kernel of its own in front of the real-time kernel
         e.set_reverb_head_fused(0)
     e.set_reverb(ir, 0.5)

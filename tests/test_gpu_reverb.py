@@ -434,6 +434,96 @@ def test_small_transforms_put_off_by_calls_of_whole_big_blocks(jf, hrir, castane
     assert np.array_equal(outs[True], outs[False])
 
 
+@pytest.mark.parametrize("B,n_ir", [(128, 16 * 128 * 4 + 77), (256, 8 * 256 * 3 + 5), (128, 128 * 90 + 3), (64, 64 * 7)])
+def test_next_blocks_stage_launched_ahead(jf, hrir, castanets, B, n_ir):
+    """One-block calls launch the NEXT block's reverb stage behind their own spatialiser (jf_debug_set_reverb_ahead: the
+    stage needs no position) and the next call launches the spatialiser alone; a new signal, a reset, a batch call, a pause,
+    a new response, the callback's one-block-late ordering and switches of the stage's knobs in between take the stage back or
+    leave it pending, and whatever happens the blocks must be those of an engine that runs every stage in its own call, BIT
+    FOR BIT: non-uniform responses (plain heads go ahead, blocks that complete a big block or owe a TAIL do not), a long
+    uniform one (the whole stage goes ahead) and a short one."""
+    S = 5
+    rng = np.random.default_rng(B + n_ir)
+    ir = _ir(n_ir, decay=3.0)
+    sigs = [castanets[3000 * s: 3000 * s + 9000 + 131 * s] for s in range(S)]
+    steps = 150
+    ops = rng.integers(0, 100, steps)
+    outs = {}
+    ahead_seen = 0
+    for ahead in (True, False):
+        r2 = np.random.default_rng(77)
+        e = jf.Engine(B, 512, S, hrir=hrir, max_batch_blocks=20)
+        e.set_reverb_ahead(ahead)
+        for s_ in range(S):
+            e.set_signal(s_, sigs[s_])
+            e.set_spherical(s_, -30 + 20 * s_, 50 * s_, 0.6 + 0.2 * s_)
+        e.set_reverb(ir, 0.6)
+        got = []
+        have_prev = False
+        for t in range(steps):
+            op = int(ops[t])
+            if op < 6:
+                e.set_signal(int(r2.integers(0, S)), castanets[int(r2.integers(0, 30000)):][: int(r2.integers(200, 6000))])
+            elif op < 12:
+                e.reset(int(r2.integers(0, S)))
+            elif op < 18:
+                k = int(r2.integers(2, 21))
+                pos = jf.positions_from_spherical(np.broadcast_to(r2.integers(-40, 90, S).astype(np.float32), (k, S)),
+                                                  r2.integers(0, 360, (k, S)).astype(np.float32), np.ones((k, S), np.float32))
+                if have_prev:       # (a block submitted by jf_callback is still in flight: take it first)
+                    rc, y = e.collect_block()
+                    assert rc == 0
+                    got.append(y[None])
+                    have_prev = False
+                got.append(e.process_batch(pos))
+                continue
+            elif op < 22:
+                if have_prev:
+                    rc, y = e.collect_block()
+                    assert rc == 0
+                    got.append(y[None])
+                    have_prev = False
+                e.set_pause(True)
+                got.append(e.process_block()[None])      # silence, nothing consumed: a stage launched ahead stays pending
+                e.set_pause(False)
+                continue
+            elif op < 25:
+                e.set_reverb_async(bool(r2.integers(0, 2)))
+            elif op < 27:
+                if have_prev:       # (refused while a block is in flight)
+                    rc, y = e.collect_block()
+                    assert rc == 0
+                    got.append(y[None])
+                    have_prev = False
+                e.set_reverb(ir, 0.6)                    # the same response again: everything starts over
+            elif op < 40:
+                e.set_spherical(int(r2.integers(0, S)), float(r2.integers(-40, 90)), float(r2.integers(0, 360)), 1.0)
+            if op >= 90 or have_prev:                    # stretches of jf_callback (the block comes one call late)
+                if have_prev and op < 90:
+                    rc, y = e.collect_block()
+                    assert rc == 0
+                    got.append(y[None])
+                    have_prev = False
+                    got.append(e.process_block()[None])
+                else:
+                    if have_prev:
+                        rc, y = e.collect_block()
+                        assert rc == 0
+                        got.append(y[None])
+                    assert e.submit_block() == 0
+                    have_prev = True
+            else:
+                got.append(e.process_block()[None])
+        if have_prev:
+            rc, y = e.collect_block()
+            assert rc == 0
+            got.append(y[None])
+        outs[ahead] = np.concatenate(got)
+        e.close()
+    assert outs[True].shape == outs[False].shape and np.abs(outs[True]).max() > 0.005
+    assert np.array_equal(outs[True], outs[False])
+
+
 def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
     """A source reset, a new signal and a pause in the middle of a run, between steps of the big partitions: the
     non-uniform engine follows the uniform one (same calls) within the float32 tolerance of two decompositions."""
