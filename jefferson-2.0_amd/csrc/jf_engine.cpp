@@ -226,7 +226,7 @@ struct jf_engine {
         long long rv_blocks = 0, rv_fut_m = 0;
         ReverbPlan last_plan;
         std::string last_side;
-        bool last_catchup = false, last_small_fft = true;
+        bool last_catchup = false, last_small_fft = true, rv_side_busy = false, rv_side_urgent = false;
     } rv_book;                    // the stage's bookkeeping before that launch
     std::string kernels_frozen;   // jf_debug_last_kernels of the call that launched it (the stage's fields describe the NEXT block)
     bool kernels_use_frozen = false;
@@ -588,6 +588,9 @@ static int rv_ahead_discard(jf_engine *e) {
     e->last_side = e->rv_book.last_side;
     e->last_catchup = e->rv_book.last_catchup;
     e->last_small_fft = e->rv_book.last_small_fft;
+    e->side_tr = false;  // (what the stage wanted on the side stream had not been submitted yet)
+    e->post_tr = false;
+    // the stage may have made the engine's stream wait for the side stream (and cleared these): waited it has, so leave them
     e->rv_ahead = false;
     e->kernels_use_frozen = false;
     return JF_OK;
@@ -602,7 +605,10 @@ static bool rv_ahead_possible(const jf_engine *e) {
     if (e->rv_P1 > 0) {
         if (e->rv_side_urgent || e->side_tr) return false;
         const ReverbSchedule sc = host_reverb_schedule(e->rv_blocks, 1, e->rv_M, e->rv_fut_m);
-        if (sc.n_tr > 0 || sc.tail_early >= 0 || sc.tail_late >= 0) return false;
+        if (sc.tail_early >= 0 || sc.tail_late >= 0) return false;
+        // a block that completes a big block: only if its transforms and products go to the side stream (they are submitted
+        // behind ITS spatialiser, by the call that consumes the stage: side_tr stays pending till then)
+        if (sc.n_tr > 0 && !(e->rv_async && e->rv_side != nullptr)) return false;
     }
     return true;
 }
