@@ -35,6 +35,10 @@ int jf_shard_range(int n_total, int n_parts, int part, int *lo, int *hi);
  * (NULL: 0 .. n_gpus - 1).  n_gpus may not exceed n_sources.  Creates the engines and one RCCL communicator per GPU.
  */
 int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out);
+/* The same for an HRTF set on a grid of elevation rings of its own (jefferson.h: jf_engine_create_grid; the table is replicated
+ * on every GPU like KEMAR's): hrir [jf_grid_rows(grid)][2][taps]. */
+int jf_group_create_grid(const jf_config *cfg, int n_gpus, const int *devices, const jf_hrtf_grid *grid, const float *hrir,
+                         int taps, jf_group **out);
 void jf_group_destroy(jf_group *g);
 /* Text of the last error on this group (or of the last failed create when g == NULL). */
 const char *jf_group_last_error(const jf_group *g);

@@ -93,8 +93,9 @@ void jf_group_destroy(jf_group *g) {
 }
 
 /* one_device >= 0: every shard on that device, no communicator (jf_group_create_shards_on_device) */
-static int create_group(const jf_config *cfg, int n_gpus, const int *devices, int one_device, const float *hrir, int taps,
-                        jf_group **out) {
+/* grid: the HRTF set's own grid of elevation rings (jf_engine_create_grid), or NULL for the reference's KEMAR grid */
+static int create_group(const jf_config *cfg, int n_gpus, const int *devices, int one_device, const jf_hrtf_grid *grid,
+                        const float *hrir, int taps, jf_group **out) {
     if (!cfg || !hrir || !out) return fail(NULL, JF_ERR_ARG, "null argument", NULL);
     *out = NULL;
     if (n_gpus < 1 || n_gpus > cfg->n_sources) return fail(NULL, JF_ERR_ARG, "need 1 <= n_gpus <= n_sources", NULL);
@@ -135,9 +136,9 @@ static int create_group(const jf_config *cfg, int n_gpus, const int *devices, in
         jf_config c = *cfg;
         c.n_sources = hi - lo;
         c.device = g->dev[i];
-        rc = jf_engine_create(&c, hrir, taps, &g->eng[i]);
+        rc = grid ? jf_engine_create_grid(&c, grid, hrir, taps, &g->eng[i]) : jf_engine_create(&c, hrir, taps, &g->eng[i]);
         if (rc != JF_OK) {
-            fail(NULL, rc, "jf_engine_create", jf_last_error(NULL));
+            fail(NULL, rc, grid ? "jf_engine_create_grid" : "jf_engine_create", jf_last_error(NULL));
             break;
         }
         if (hipSetDevice(g->dev[i]) != hipSuccess ||
@@ -159,13 +160,19 @@ static int create_group(const jf_config *cfg, int n_gpus, const int *devices, in
 }
 
 int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const float *hrir, int taps, jf_group **out) {
-    return create_group(cfg, n_gpus, devices, -1, hrir, taps, out);
+    return create_group(cfg, n_gpus, devices, -1, NULL, hrir, taps, out);
+}
+
+int jf_group_create_grid(const jf_config *cfg, int n_gpus, const int *devices, const jf_hrtf_grid *grid, const float *hrir,
+                         int taps, jf_group **out) {
+    if (!grid) return fail(NULL, JF_ERR_ARG, "null grid", NULL);
+    return create_group(cfg, n_gpus, devices, -1, grid, hrir, taps, out);
 }
 
 int jf_group_create_shards_on_device(const jf_config *cfg, int n_shards, int device, const float *hrir, int taps,
                                      jf_group **out) {
     if (device < 0) return fail(NULL, JF_ERR_ARG, "device ordinal out of range", NULL);
-    return create_group(cfg, n_shards, NULL, device, hrir, taps, out);
+    return create_group(cfg, n_shards, NULL, device, NULL, hrir, taps, out);
 }
 
 int jf_group_debug_fail_next(jf_group *g, int shard) {

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from . import JfConfig, JfError, _f, _fp, lib as core_lib, NUM_HRTF
+from . import JfConfig, JfError, JfHrtfGrid, _f, _fp, lib as core_lib, NUM_HRTF
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjefferson_group.so")
@@ -14,6 +14,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson_group.h
 _SIGS = {
     "jf_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "jf_group_create": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.POINTER(C.c_int), _f, C.c_int, C.POINTER(C.c_void_p)]),
+    "jf_group_create_grid": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.POINTER(C.c_int), C.POINTER(JfHrtfGrid), _f, C.c_int,
+                                       C.POINTER(C.c_void_p)]),
     "jf_group_destroy": (None, [C.c_void_p]),
     "jf_group_last_error": (C.c_char_p, [C.c_void_p]),
     "jf_group_num_gpus": (C.c_int, [C.c_void_p]),
@@ -68,16 +70,20 @@ def shard_range(n_total, n_parts, part):
 
 
 class Group:
-    def __init__(self, B, hrtf_len, n_sources, hrir, n_gpus=1, devices=None, max_batch_blocks=1, flags=0, shards_on_device=0):
+    def __init__(self, B, hrtf_len, n_sources, hrir, n_gpus=1, devices=None, max_batch_blocks=1, flags=0, shards_on_device=0,
+                 grid=None):
         """shards_on_device = n > 0: n shards of the job on device 0 with a host sum instead of RCCL (test support,
-        jf_group_create_shards_on_device)."""
+        jf_group_create_shards_on_device).  grid: a jf.Grid of the HRTF set's own (jf_group_create_grid)."""
         L = lib()
         cfg = JfConfig(B, hrtf_len, n_sources, 0, max_batch_blocks, flags)
         hrir = np.ascontiguousarray(hrir, np.float32)
-        assert hrir.shape[0] == NUM_HRTF and hrir.shape[1] == 2
+        assert (grid is not None or hrir.shape[0] == NUM_HRTF) and hrir.shape[1] == 2
         h = C.c_void_p()
         dev = (C.c_int * n_gpus)(*devices) if devices is not None else None
-        if shards_on_device > 0:
+        if grid is not None:
+            self._grid = grid
+            rc = L.jf_group_create_grid(C.byref(cfg), n_gpus, dev, C.byref(grid.c), _fp(hrir), hrir.shape[2], C.byref(h))
+        elif shards_on_device > 0:
             rc = L.jf_group_create_shards_on_device(C.byref(cfg), int(shards_on_device), 0, _fp(hrir), hrir.shape[2], C.byref(h))
         else:
             rc = L.jf_group_create(C.byref(cfg), n_gpus, dev, _fp(hrir), hrir.shape[2], C.byref(h))

@@ -175,3 +175,46 @@ def test_blocks_on_a_grid_of_its_own_against_both_oracles(jf, castanets, which, 
     assert e.set_spherical(0, -75.0, 10.0, 1.0) == 0 and e.set_spherical(0, 91.0, 10.0, 1.0) == jf.JF_ERR_RANGE
     e.close()
     assert_within(np.array(got), mix64, sum_tol(TOL64, S), f"grid {which} B={B}: real-time kernel vs model64")
+
+
+def test_a_group_on_a_grid_of_its_own_and_rings_from_directions(jf, castanets):
+    """jf_group_create_grid (one GPU: a communicator of size 1) renders what jf_engine_create_grid renders; and an engine whose
+    grid and row order come from the measurements' directions (jf_grid_from_positions: a shuffled SOFA-style list) renders what
+    the engine created from the ring description renders, bit for bit."""
+    import importlib
+    grp = importlib.import_module("jefferson_amd.group")       # needs libjefferson_group.so (RCCL at build time)
+    ele, cnt, _ = irregular_grid()
+    g = jf.Grid(ele, cnt)
+    h = _synthetic_hrirs(g.rows())
+    S, K, B = 6, 6, 256
+    pos = _trajectory(jf, S, K, -60, 90)
+    sigs = [(0.45 * np.roll(castanets, 2003 * s)[:9000 + 97 * s]).astype(np.float32) for s in range(S)]
+    e = jf.Engine(B, 512, S, hrir=h, max_batch_blocks=K, grid=g)
+    for s in range(S):
+        e.set_signal(s, sigs[s])
+    want = e.process_batch(pos)
+    e.close()
+    G = grp.Group(B, 512, S, h, n_gpus=1, max_batch_blocks=K, grid=g)
+    for s in range(S):
+        G.set_signal(s, sigs[s])
+    got = G.process_batch(pos)
+    G.close()
+    assert np.abs(want).max() > 0.02 and np.array_equal(got, want)
+    # the same set as a shuffled list of directions
+    rng = np.random.default_rng(12)
+    el, az = [], []
+    for r, n in enumerate(cnt):
+        for i in range(n):
+            el.append(float(ele[r]))
+            az.append(i * 360.0 / n)
+    perm = rng.permutation(len(el))
+    g2, row_of = jf.Grid.from_positions(np.array(az, np.float32)[perm], np.array(el, np.float32)[perm], tol_deg=0.01)
+    h2 = np.zeros_like(h)
+    h2[row_of] = h[perm]              # measurement i (= row perm[i] of the ring-ordered table) goes to row row_of[i]
+    assert np.array_equal(h2, h)
+    e2 = jf.Engine(B, 512, S, hrir=h2, max_batch_blocks=K, grid=g2)
+    for s in range(S):
+        e2.set_signal(s, sigs[s])
+    got2 = e2.process_batch(pos)
+    e2.close()
+    assert np.array_equal(got2, want)
