@@ -117,8 +117,7 @@ int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_eng
  *     weights in elevation, on each ring the two measurements that enclose the azimuth with the wrap at 360 and weights
  *     that sum to 1; JF_MODE_FD_BASIC takes the nearest ring's nearest measurement.  The setters accept elevations in
  *     [-90, 90].  jf_grid_interpolation / jf_grid_pick are the host twins of the kernels' rule (same float32 steps).
- * A SOFA (HDF5) container is not read here: the image has no HDF5 library and the reference no such file; a caller
- * that has one fills this struct from its SourcePosition array and passes Data.IR as hrir.
+ * A set in a SOFA file: jf_engine_create_sofa below.
  */
 #define JF_MAX_RINGS 40
 typedef struct jf_hrtf_grid {
@@ -151,6 +150,46 @@ int jf_grid_interpolation(const jf_hrtf_grid *grid, float ele, float azi, int id
 int jf_grid_pick(const jf_hrtf_grid *grid, float ele, float azi);   /* nearest measurement's row */
 /* rows of this engine's HRTF table (710 for KEMAR) */
 int jf_table_rows(const jf_engine *e);
+
+/*
+ * HRTF sets in SOFA files (AES69 "Spatially Oriented Format for Acoustics": a netCDF-4, i.e. HDF5, container) -- the rest of
+ * "any HRTF database" (FuturePlans.md:21).  The library reads the container itself (csrc/jf_hdf5.c: own reader of the HDF5
+ * structures such files are made of, checked against files written by libhdf5; zlib for deflated chunks) -- no HDF5 or
+ * netCDF library is needed.
+ *   jf_sofa_read: Data.IR [M][R][N], SourcePosition (spherical "degree, degree, metre", or Cartesian: converted), the
+ *     sampling rate, Data.Delay (one row repeated when the file holds one), the SOFAConventions attribute.  Refused with
+ *     JF_ERR_IO and a text in jf_last_error(NULL): files that are not HDF5 / use HDF5 structures outside the reader's set,
+ *     DataType other than "FIR", missing variables, shapes that do not agree.  Buffers are the library's: jf_sofa_release.
+ *   jf_sofa_table: the set as a table for jf_engine_create_grid -- the rings from the measurements' directions
+ *     (jf_grid_from_positions: JF_ERR_ARG for a set that is not measured on rings of uniform azimuth steps), rows in ring
+ *     order, hrir [M][2][taps] (taps >= jf_sofa_taps: the file's N + the largest Data.Delay).  SOFA azimuths run
+ *     counter-clockwise (90 = left); the table's run the way KEMAR's file names do (90 = right): row azimuth =
+ *     360 - SOFA azimuth.  Receiver 0 is the left ear.  Whole-sample delays shift their impulse response; fractional ones
+ *     are refused (JF_ERR_IO), and so are sets with other than two receivers or a sampling rate other than 44100 Hz (the
+ *     reference's own check of its HRIR files, hrtf_signals.cu:68-75: the distance factor is written for that rate).
+ *   jf_engine_create_sofa: the two, then jf_engine_create_grid.  cfg->hrtf_len must hold jf_sofa_taps.
+ */
+typedef struct jf_sofa_set {
+    int n_measurements;   /* M */
+    int n_receivers;      /* R */
+    int n_samples;        /* N */
+    double sample_rate;   /* Hz */
+    float *ir;            /* [M][R][N] */
+    float *azimuth;       /* [M] degrees, SOFA's sense (counter-clockwise from the front) */
+    float *elevation;     /* [M] degrees up */
+    float *distance;      /* [M] metres */
+    float *delay;         /* [M][R] samples */
+    char conventions[48]; /* SOFAConventions, "" if the file has none */
+} jf_sofa_set;
+int jf_sofa_read(const char *path, jf_sofa_set *out);
+void jf_sofa_release(jf_sofa_set *set);
+int jf_sofa_taps(const jf_sofa_set *set);
+int jf_sofa_table(const jf_sofa_set *set, float tol_deg, jf_grid_layout *layout, float *hrir, int taps);
+int jf_engine_create_sofa(const jf_config *cfg, const char *path, float tol_deg, jf_engine **out);
+/* tests: a numeric dataset of any HDF5 file the reader understands, as doubles (malloc'd: jf_free); dims[8] */
+int jf_debug_hdf5_read(const char *path, const char *dataset, double **out, int *rank, unsigned long long *dims);
+/* tests: a string attribute of an object ("" or "/": the root group); JF_ERR_ARG if there is none */
+int jf_debug_hdf5_attr(const char *path, const char *object, const char *attr, char *out, size_t cap);
 
 /* closeEverything() / cleanup_hrtf_buffers() / ~GPUSoundSource (hrtf_signals.cu:100-105, GPUSoundSource.cu:532-548). */
 void jf_engine_destroy(jf_engine *e);

@@ -46,6 +46,12 @@ class JfGridLayout(C.Structure):
                 ("ring_step", C.c_float * JF_MAX_RINGS)]
 
 
+class JfSofaSet(C.Structure):
+    _fields_ = [("n_measurements", C.c_int), ("n_receivers", C.c_int), ("n_samples", C.c_int), ("sample_rate", C.c_double),
+                ("ir", C.POINTER(C.c_float)), ("azimuth", C.POINTER(C.c_float)), ("elevation", C.POINTER(C.c_float)),
+                ("distance", C.POINTER(C.c_float)), ("delay", C.POINTER(C.c_float)), ("conventions", C.c_char * 48)]
+
+
 class JfError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"jefferson error {code}: {msg}")
@@ -58,6 +64,13 @@ _SIGS = {
     "jf_engine_create": (C.c_int, [C.POINTER(JfConfig), _f, C.c_int, C.POINTER(C.c_void_p)]),
     "jf_engine_create_from_dir": (C.c_int, [C.POINTER(JfConfig), C.c_char_p, C.POINTER(C.c_void_p)]),
     "jf_engine_create_grid": (C.c_int, [C.POINTER(JfConfig), C.POINTER(JfHrtfGrid), _f, C.c_int, C.POINTER(C.c_void_p)]),
+    "jf_engine_create_sofa": (C.c_int, [C.POINTER(JfConfig), C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "jf_sofa_read": (C.c_int, [C.c_char_p, C.POINTER(JfSofaSet)]),
+    "jf_sofa_release": (None, [C.POINTER(JfSofaSet)]),
+    "jf_sofa_taps": (C.c_int, [C.POINTER(JfSofaSet)]),
+    "jf_sofa_table": (C.c_int, [C.POINTER(JfSofaSet), C.c_float, C.c_void_p, _f, C.c_int]),
+    "jf_debug_hdf5_read": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(C.c_double)), _i, C.POINTER(C.c_ulonglong)]),
+    "jf_debug_hdf5_attr": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "jf_kemar_grid": (C.c_int, [C.POINTER(JfHrtfGrid)]),
     "jf_grid_rows": (C.c_int, [C.POINTER(JfHrtfGrid)]),
     "jf_grid_from_positions": (C.c_int, [C.c_size_t, _f, _f, C.c_float, C.c_void_p, _i]),
@@ -255,6 +268,79 @@ def wav_write_stereo24(path, interleaved, fs=44100):
         raise JfError(rc, lib().jf_last_error(None).decode())
 
 
+class SofaSet:
+    """include/jefferson.h: jf_sofa_read -- the variables of a SOFA file as arrays (copies; the library's buffers are released)."""
+
+    def __init__(self, path):
+        self.c = None
+        c = JfSofaSet()
+        rc = lib().jf_sofa_read(os.fsencode(path), C.byref(c))
+        if rc:
+            raise JfError(rc, lib().jf_last_error(None).decode())
+        self.c = c
+        M, R, N = c.n_measurements, c.n_receivers, c.n_samples
+        self.M, self.R, self.N, self.sample_rate = M, R, N, c.sample_rate
+        self.conventions = c.conventions.decode(errors="replace")
+        arr = lambda p, shape: np.ctypeslib.as_array(p, shape=shape).copy()
+        self.ir = arr(c.ir, (M, R, N))
+        self.azimuth, self.elevation, self.distance = arr(c.azimuth, (M,)), arr(c.elevation, (M,)), arr(c.distance, (M,))
+        self.delay = arr(c.delay, (M, R))
+
+    def taps(self):
+        n = lib().jf_sofa_taps(C.byref(self.c))
+        if n < 0:
+            raise JfError(n, lib().jf_last_error(None).decode())
+        return n
+
+    def table(self, tol_deg=0.05, taps=None):
+        """(Grid, hrir [M][2][taps]) for Engine(..., hrir=, grid=): include/jefferson.h: jf_sofa_table"""
+        taps = self.taps() if taps is None else taps
+        lay = JfGridLayout()
+        hrir = np.zeros((self.M, 2, taps), np.float32)
+        rc = lib().jf_sofa_table(C.byref(self.c), tol_deg, C.byref(lay), _fp(hrir), taps)
+        if rc:
+            raise JfError(rc, lib().jf_last_error(None).decode())
+        n = lay.n_rings
+        return Grid(list(lay.ring_elevation[:n]), list(lay.ring_count[:n]), list(lay.ring_step[:n])), hrir
+
+    def close(self):
+        if self.c is not None:
+            lib().jf_sofa_release(C.byref(self.c))
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def hdf5_read(path, dataset):
+    """tests: a numeric dataset of an HDF5 file through the library's own reader (jf_hdf5.c), float64"""
+    p = C.POINTER(C.c_double)()
+    rank = C.c_int()
+    dims = (C.c_ulonglong * 8)()
+    rc = lib().jf_debug_hdf5_read(os.fsencode(path), dataset.encode(), C.byref(p), C.byref(rank), dims)
+    if rc:
+        raise JfError(rc, lib().jf_last_error(None).decode())
+    shape = tuple(int(dims[i]) for i in range(rank.value))
+    n = int(np.prod(shape)) if shape else 1
+    out = np.ctypeslib.as_array(p, shape=(n,)).copy().reshape(shape) if n else np.zeros(shape)
+    lib().jf_free(p)
+    return out
+
+
+def hdf5_attr(path, obj, attr):
+    """tests: a string attribute (None if the object has none of that name)"""
+    buf = C.create_string_buffer(512)
+    rc = lib().jf_debug_hdf5_attr(os.fsencode(path), obj.encode(), attr.encode(), buf, 512)
+    if rc == JF_ERR_ARG:
+        return None
+    if rc:
+        raise JfError(rc, lib().jf_last_error(None).decode())
+    return buf.value.decode(errors="replace")
+
+
 class Grid:
     """include/jefferson.h: jf_hrtf_grid (keeps its arrays alive)."""
 
@@ -306,11 +392,14 @@ class Grid:
 class Engine:
     """Thin object wrapper; method names follow the C ABI."""
 
-    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1, flags=0, grid=None):
+    def __init__(self, B, hrtf_len, n_sources, hrir=None, hrir_dir=None, device=0, max_batch_blocks=1, flags=0, grid=None,
+                 sofa=None, sofa_tol_deg=0.05):
         L = lib()
         cfg = JfConfig(B, hrtf_len, n_sources, device, max_batch_blocks, flags)
         h = C.c_void_p()
-        if grid is not None:
+        if sofa is not None:
+            rc = L.jf_engine_create_sofa(C.byref(cfg), os.fsencode(sofa), sofa_tol_deg, C.byref(h))
+        elif grid is not None:
             hrir = np.ascontiguousarray(hrir, np.float32)
             assert hrir.shape[1] == 2
             self._grid = grid

@@ -1106,6 +1106,79 @@ int jf_engine_create_grid(const jf_config *cfg, const jf_hrtf_grid *grid, const 
     });
 }
 
+// ---- SOFA files (jf_sofa.cpp over jf_hdf5.c) ----
+int jf_sofa_read(const char *path, jf_sofa_set *out) {
+    return jf_guard([&]() -> int {
+    if (!path || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
+    std::string err;
+    const int rc = sofa_read(path, out, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+    });
+}
+
+void jf_sofa_release(jf_sofa_set *set) { sofa_release(set); }
+
+int jf_sofa_taps(const jf_sofa_set *set) {
+    return jf_guard([&]() -> int {
+    std::string err;
+    const int rc = sofa_taps(set, &err);
+    return rc < 0 ? fail(nullptr, rc, err.empty() ? "not a set read by jf_sofa_read" : err) : rc;
+    });
+}
+
+int jf_sofa_table(const jf_sofa_set *set, float tol_deg, jf_grid_layout *layout, float *hrir, int taps) {
+    return jf_guard([&]() -> int {
+    std::string err;
+    const int rc = sofa_table(set, tol_deg, layout, hrir, taps, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+    });
+}
+
+int jf_engine_create_sofa(const jf_config *cfg, const char *path, float tol_deg, jf_engine **out) {
+    return jf_guard([&]() -> int {
+    if (out) *out = nullptr;
+    if (!cfg || !path || !out) return fail(nullptr, JF_ERR_ARG, "null argument");
+    jf_sofa_set set;
+    std::string err;
+    int rc = sofa_read(path, &set, &err);
+    if (rc) return fail(nullptr, rc, err);
+    struct Release {
+        jf_sofa_set *s;
+        ~Release() { sofa_release(s); }
+    } release{&set};
+    const int taps = sofa_taps(&set, &err);
+    if (taps < 0) return fail(nullptr, taps, std::string(path) + ": " + err);
+    if (taps > cfg->hrtf_len)
+        return fail(nullptr, JF_ERR_ARG, std::string(path) + ": impulse responses of " + std::to_string(taps) + " taps, hrtf_len is " + std::to_string(cfg->hrtf_len));
+    std::vector<float> hrir((size_t)set.n_measurements * 2 * (size_t)taps);
+    jf_grid_layout lay;
+    rc = sofa_table(&set, tol_deg, &lay, hrir.data(), taps, &err);
+    if (rc) return fail(nullptr, rc, std::string(path) + ": " + err);
+    RingTable rt;
+    rc = host_grid_table(lay.n_rings, lay.ring_elevation, lay.ring_count, lay.ring_step, &rt, &err);
+    if (rc) return fail(nullptr, rc, std::string(path) + ": " + err);
+    return create_engine(cfg, &rt, hrir.data(), taps, out);
+    });
+}
+
+int jf_debug_hdf5_read(const char *path, const char *dataset, double **out, int *rank, unsigned long long *dims) {
+    return jf_guard([&]() -> int {
+    if (!path || !dataset || !out || !rank || !dims) return fail(nullptr, JF_ERR_ARG, "null argument");
+    std::string err;
+    const int rc = hdf5_read(path, dataset, out, rank, dims, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+    });
+}
+
+int jf_debug_hdf5_attr(const char *path, const char *object, const char *attr, char *out, size_t cap) {
+    return jf_guard([&]() -> int {
+    if (!path || !object || !attr || !out || !cap) return fail(nullptr, JF_ERR_ARG, "null argument");
+    std::string err;
+    const int rc = hdf5_attr(path, object, attr, out, cap, &err);
+    return rc ? fail(nullptr, rc, err) : JF_OK;
+    });
+}
+
 int jf_engine_create_from_dir(const jf_config *cfg, const char *hrir_dir, jf_engine **out) {
     return jf_guard([&]() -> int {
     if (!cfg || !hrir_dir || !out) return fail(nullptr, JF_ERR_ARG, "null argument");

@@ -56,6 +56,18 @@ struct ReverbSchedule {
 };
 ReverbSchedule host_reverb_schedule(long long j0, int K, int M, long long fut_m);
 
+// SOFA files (jf_sofa.cpp; include/jefferson.h: jf_sofa_*)
+}  // namespace jf
+struct jf_sofa_set;
+struct jf_grid_layout;
+namespace jf {
+int sofa_read(const char *path, ::jf_sofa_set *out, std::string *err);
+void sofa_release(::jf_sofa_set *s);
+int sofa_taps(const ::jf_sofa_set *s, std::string *err);
+int sofa_table(const ::jf_sofa_set *s, float tol_deg, ::jf_grid_layout *layout, float *hrir, int taps, std::string *err);
+int hdf5_read(const char *path, const char *dataset, double **out, int *rank, unsigned long long *dims, std::string *err);
+int hdf5_attr(const char *path, const char *object, const char *attr, char *out, size_t cap, std::string *err);
+
 int wav_read_mono(const char *path, float **out, size_t *n_frames, int *sample_rate, std::string *err);
 int wav_write_stereo24(const char *path, const float *interleaved, size_t n_frames, int sample_rate,
                        std::string *err);

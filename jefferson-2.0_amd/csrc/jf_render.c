@@ -16,8 +16,11 @@
  *     before every block (the audio thread's own granularity), so a run is reproducible: a way-point is latched by the
  *     first block that starts with `count` at or past its mark.  `count` follows Audio.cu:121-139 (wraps at `length`).
  *
- * usage: jf_render <hrir_dir> <in.wav> <out.wav> [--block 256] [--azi 3] [--ele 5]
+ * usage: jf_render <hrir_dir | set.sofa> <in.wav> <out.wav> [--block 256] [--azi 3] [--ele 5]
  *                  [--dwell 172] [--rounds 72] [--step 5] [--radius 0.5] [--latency] [--script debugmode2]
+ *   <set.sofa>  a name that ends in ".sofa": the HRTF set of a SOFA file instead of the KEMAR directory
+ *               (jf_engine_create_sofa; --sofa-tol T: degrees a measurement may lie off its ring's uniform steps, 0.51 --
+ *               what sets whose azimuths were rounded to whole degrees, like KEMAR's, need)
  *   --latency  use jf_callback (the CUDA path's one-block latency, Audio.cu:104-117)
  *              instead of jf_process_block (the CPU path's ordering)
  *   --no-pin   leave the thread where the system put it (default: jf_pin_thread_to_device -- on a two-socket host a block
@@ -75,12 +78,13 @@ static double now_s(void) {
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <hrir_dir> <in.wav> <out.wav> [--block B] [--azi A] [--ele E] "
-                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N] [--script debugmode2] [--no-pin]\n", argv[0]);
+        fprintf(stderr, "usage: %s <hrir_dir | set.sofa> <in.wav> <out.wav> [--block B] [--azi A] [--ele E] "
+                        "[--dwell N] [--rounds R] [--step D] [--radius r] [--latency] [--batch N] [--script debugmode2] [--no-pin] "
+                        "[--sofa-tol T]\n", argv[0]);
         return 2;
     }
     int block = 256, dwell = 172, rounds = 72, latency = 0, batch = 0, script = 0, pin = 1;
-    float azi = 3, ele = 5, step = 5, radius = 0.5f;
+    float azi = 3, ele = 5, step = 5, radius = 0.5f, sofa_tol = 0.51f;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "--latency")) latency = 1;
         else if (!strcmp(argv[i], "--no-pin")) pin = 0;
@@ -92,6 +96,7 @@ int main(int argc, char **argv) {
         else if (i + 1 < argc && !strcmp(argv[i], "--rounds")) rounds = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--step")) step = (float)atof(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--radius")) radius = (float)atof(argv[++i]);
+        else if (i + 1 < argc && !strcmp(argv[i], "--sofa-tol")) sofa_tol = (float)atof(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--script") && !strcmp(argv[i + 1], "debugmode2")) script = 1, i++;
         else {
             fprintf(stderr, "unknown option %s\n", argv[i]);
@@ -115,7 +120,9 @@ int main(int argc, char **argv) {
     cfg.device = 0;
     cfg.max_batch_blocks = batch > 0 ? batch : 1;
     jf_engine *e = NULL;
-    if (jf_engine_create_from_dir(&cfg, argv[1], &e) != JF_OK) {
+    const size_t len1 = strlen(argv[1]);
+    const int sofa = len1 > 5 && !strcmp(argv[1] + len1 - 5, ".sofa");
+    if ((sofa ? jf_engine_create_sofa(&cfg, argv[1], sofa_tol, &e) : jf_engine_create_from_dir(&cfg, argv[1], &e)) != JF_OK) {
         fprintf(stderr, "engine: %s\n", jf_last_error(NULL));
         return 1;
     }
