@@ -11,7 +11,6 @@ The library reads the HDF5 container itself (csrc/jf_hdf5.c).  What pins that re
 import json
 import os
 import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -263,3 +262,57 @@ json.dump(index, open(f"{out}/index.json", "w"))
     if not index:
         pytest.skip("no third-party HDF5 files in this image")
     assert ok >= 50 and len(refused) <= 2, refused
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="the image's interpreter with h5py is not there")
+def test_files_h5py_writes_on_the_spot(tmp_path):
+    """What the committed containers do not reach: the format bounds of HDF5 1.8 (superblock 2 with version-3 layouts), a group
+    of 300 links and 200 attributes (version-2 B-trees of depth 1 over fractal heaps with several rows of direct blocks), and
+    the one refusal a reader of SOFA files should know about: an unlimited dimension written with the 1.10 format."""
+    script = tmp_path / "write.py"
+    script.write_text('''
+import sys, warnings
+warnings.simplefilter("ignore")
+import h5py, numpy as np
+d = sys.argv[1]
+rng = np.random.default_rng(1)
+a = rng.standard_normal((50, 2, 40))
+b = rng.integers(-1000, 1000, (300, 7)).astype(np.int16)
+np.savez(d + "/expected.npz", a=a, b=b)
+for tag, lv in (("v108", "v108"), ("e_v108", ("earliest", "v108")), ("v110", ("v110", "v110"))):
+    with h5py.File(d + "/t_" + tag + ".h5", "w", libver=lv, track_order=True) as f:
+        for i in range(12):
+            f.attrs.create("attr%d" % i, np.bytes_(b"value%d\\0" % i))
+        f.create_dataset("a", data=a, chunks=(7, 2, 16), compression="gzip", shuffle=True, fletcher32=True)
+        f.create_dataset("b", data=b, chunks=(64, 7), maxshape=(None, 7))
+        f.create_dataset("c", data=b[:5])
+        f.create_group("g").create_dataset("x", data=np.arange(10.))
+        for i in range(20):
+            f.create_dataset("v%d" % i, data=np.full(3, i, np.float32))
+for lv, tr in (("earliest", True), ("latest", False)):
+    with h5py.File(d + "/many_" + lv + ".h5", "w", libver=lv, track_order=tr) as f:
+        for i in range(300):
+            f.create_dataset("variable_with_a_long_name_%03d" % i, data=np.full(2, i, np.int32))
+        for i in range(200):
+            f.attrs.create("attribute_%03d" % i, np.bytes_(b"value %03d" % i))
+''')
+    r = subprocess.run([CONDA_PY, str(script), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        pytest.skip("h5py is not usable here: " + r.stderr[-300:])
+    E = np.load(tmp_path / "expected.npz")
+    for tag in ("v108", "e_v108", "v110"):
+        fn = str(tmp_path / f"t_{tag}.h5")
+        assert np.array_equal(jf.hdf5_read(fn, "a"), E["a"])
+        if tag == "v110":
+            with pytest.raises(jf.JfError) as ex:
+                jf.hdf5_read(fn, "b")
+            assert ex.value.code == jf.JF_ERR_IO and "unlimited" in str(ex.value)
+        else:
+            assert np.array_equal(jf.hdf5_read(fn, "b"), E["b"].astype(np.float64))
+        assert np.array_equal(jf.hdf5_read(fn, "c"), E["b"][:5].astype(np.float64))
+        assert jf.hdf5_read(fn, "g/x").tolist() == list(range(10)) and jf.hdf5_read(fn, "v19").tolist() == [19.0] * 3
+        assert jf.hdf5_attr(fn, "/", "attr11") == "value11"
+    for lv in ("earliest", "latest"):
+        fn = str(tmp_path / f"many_{lv}.h5")
+        assert all(jf.hdf5_read(fn, "variable_with_a_long_name_%03d" % i).tolist() == [i, i] for i in range(300))
+        assert all(jf.hdf5_attr(fn, "/", "attribute_%03d" % i) == "value %03d" % i for i in range(200))
