@@ -659,10 +659,17 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
 // of reverb_mac_tiled_kernel).  A wave covers 64 bins (one per lane) of ALL partitions, in ascending order -- no reduction
 // between waves, and the sums are the same whatever KB is.  The packed pair in bin 0 is carried as if it were complex;
 // reverb_big_ifft_kernel recomputes it.
-constexpr int kBigMacWaves = 8;
+// Waves per workgroup: 8 for the single products of the side stream (a narrow launch beside the blocks' kernels:
+// profiles/r04/rt_waves.md), 4 for the batch form's tiles of 16 -- the same 16 waves per CU in twice as many workgroups that
+// start and end apart: 69.6 / 70.6 -> 67.4 / 68.2 us per launch at config 5's batch shape (profiles/r05/reverb_batch.md)
+#ifndef JF_RV_BIG_MAC_WAVES
+#define JF_RV_BIG_MAC_WAVES 4
+#endif
+constexpr int kBigMacWaves = 8, kBigMacWavesTiled = JF_RV_BIG_MAC_WAVES;
 template <int B1, int KB>
 JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
-    constexpr int WGS_PER_SPEC = B1 / (64 * kBigMacWaves);  // workgroups side by side over the bins
+    constexpr int kWaves = KB == 1 ? kBigMacWaves : kBigMacWavesTiled;
+    constexpr int WGS_PER_SPEC = B1 / (64 * kWaves);  // workgroups side by side over the bins
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = item % WGS_PER_SPEC;
@@ -671,7 +678,7 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
     const int s = rest / n_tiles, i0 = (rest - s * n_tiles) * KB;  // first product of the tile
     const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
     const char *hp = reinterpret_cast<const char *>(P.hspec1 + (size_t)P.h_first * B1);
-    unsigned voff = 8u * (unsigned)(64 * (kBigMacWaves * slice + wave) + lane);
+    unsigned voff = 8u * (unsigned)(64 * (kWaves * slice + wave) + lane);
     asm volatile("" : "+v"(voff));
     auto load_at = [&](const char *base) {
         const float2 *q = reinterpret_cast<const float2 *>(base + voff);
@@ -758,11 +765,11 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
         if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
 }
 
-// One workgroup per item (64 kBigMacWaves bins of one tile of one source) -- or, for single products on the side stream
+// One workgroup per item (64 bins per wave of one tile of one source) -- or, for single products on the side stream
 // (mac_wgs > 0), that many workgroups taking the items in turn: a launch that does not fill the GPU's wave slots, so that the
 // kernels of the blocks it runs beside find room at once (jf_engine.cpp: run_reverb_stage).
 template <int B1, int KB>
-__global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac_kernel(const ReverbBigParams P) {
+__global__ __launch_bounds__(64 * (KB == 1 ? kBigMacWaves : kBigMacWavesTiled)) void reverb_big_mac_kernel(const ReverbBigParams P) {
     if constexpr (KB == 1) {
         constexpr int per_spec = B1 / (64 * kBigMacWaves);
         const int n_items = per_spec * P.n_prod * P.S;
@@ -1104,10 +1111,10 @@ static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
 static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
-    constexpr int per_spec = B1 / (64 * kBigMacWaves);
+    constexpr int per_spec = B1 / (64 * kBigMacWaves), per_spec_tiled = B1 / (64 * kBigMacWavesTiled);
     if (P.n_prod >= 4) {
         const int tiles = (P.n_prod + 15) / 16;
-        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec * tiles * P.S), dim3(64 * kBigMacWaves), 0, st, P);
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec_tiled * tiles * P.S), dim3(64 * kBigMacWavesTiled), 0, st, P);
     } else {
         const int n_items = per_spec * P.n_prod * P.S;
         const int wgs = P.mac_wgs > 0 && P.mac_wgs < n_items ? P.mac_wgs : n_items;
