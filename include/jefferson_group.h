@@ -39,6 +39,8 @@ int jf_group_create(const jf_config *cfg, int n_gpus, const int *devices, const 
  * on every GPU like KEMAR's): hrir [jf_grid_rows(grid)][2][taps]. */
 int jf_group_create_grid(const jf_config *cfg, int n_gpus, const int *devices, const jf_hrtf_grid *grid, const float *hrir,
                          int taps, jf_group **out);
+/* ... and for a set in a SOFA file (jefferson.h: jf_engine_create_sofa: read once on the host, the table replicated) */
+int jf_group_create_sofa(const jf_config *cfg, int n_gpus, const int *devices, const char *path, float tol_deg, jf_group **out);
 void jf_group_destroy(jf_group *g);
 /* Text of the last error on this group (or of the last failed create when g == NULL). */
 const char *jf_group_last_error(const jf_group *g);

@@ -169,6 +169,27 @@ int jf_group_create_grid(const jf_config *cfg, int n_gpus, const int *devices, c
     return create_group(cfg, n_gpus, devices, -1, grid, hrir, taps, out);
 }
 
+int jf_group_create_sofa(const jf_config *cfg, int n_gpus, const int *devices, const char *path, float tol_deg, jf_group **out) {
+    if (out) *out = NULL;
+    if (!cfg || !path || !out) return fail(NULL, JF_ERR_ARG, "null argument", NULL);
+    jf_sofa_set set;
+    int rc = jf_sofa_read(path, &set);
+    if (rc != JF_OK) return fail(NULL, rc, path, jf_last_error(NULL));
+    const int taps = jf_sofa_taps(&set);
+    float *hrir = taps > 0 ? (float *)malloc(sizeof(float) * (size_t)set.n_measurements * 2 * (size_t)taps) : NULL;
+    jf_grid_layout lay;
+    if (taps < 0) rc = fail(NULL, taps, path, jf_last_error(NULL));
+    else if (!hrir) rc = fail(NULL, JF_ERR_NOMEM, "out of host memory", NULL);
+    else if ((rc = jf_sofa_table(&set, tol_deg, &lay, hrir, taps)) != JF_OK) rc = fail(NULL, rc, path, jf_last_error(NULL));
+    if (rc == JF_OK) {
+        const jf_hrtf_grid grid = {lay.n_rings, lay.ring_elevation, lay.ring_count, lay.ring_step};
+        rc = create_group(cfg, n_gpus, devices, -1, &grid, hrir, taps, out);
+    }
+    free(hrir);
+    jf_sofa_release(&set);
+    return rc;
+}
+
 int jf_group_create_shards_on_device(const jf_config *cfg, int n_shards, int device, const float *hrir, int taps,
                                      jf_group **out) {
     if (device < 0) return fail(NULL, JF_ERR_ARG, "device ordinal out of range", NULL);

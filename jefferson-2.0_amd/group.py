@@ -16,6 +16,7 @@ _SIGS = {
     "jf_group_create": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.POINTER(C.c_int), _f, C.c_int, C.POINTER(C.c_void_p)]),
     "jf_group_create_grid": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.POINTER(C.c_int), C.POINTER(JfHrtfGrid), _f, C.c_int,
                                        C.POINTER(C.c_void_p)]),
+    "jf_group_create_sofa": (C.c_int, [C.POINTER(JfConfig), C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
     "jf_group_destroy": (None, [C.c_void_p]),
     "jf_group_last_error": (C.c_char_p, [C.c_void_p]),
     "jf_group_num_gpus": (C.c_int, [C.c_void_p]),
@@ -71,16 +72,20 @@ def shard_range(n_total, n_parts, part):
 
 class Group:
     def __init__(self, B, hrtf_len, n_sources, hrir, n_gpus=1, devices=None, max_batch_blocks=1, flags=0, shards_on_device=0,
-                 grid=None):
+                 grid=None, sofa=None, sofa_tol_deg=0.05):
         """shards_on_device = n > 0: n shards of the job on device 0 with a host sum instead of RCCL (test support,
-        jf_group_create_shards_on_device).  grid: a jf.Grid of the HRTF set's own (jf_group_create_grid)."""
+        jf_group_create_shards_on_device).  grid: a jf.Grid of the HRTF set's own (jf_group_create_grid).  sofa: the set of a
+        SOFA file instead of hrir (jf_group_create_sofa)."""
         L = lib()
         cfg = JfConfig(B, hrtf_len, n_sources, 0, max_batch_blocks, flags)
-        hrir = np.ascontiguousarray(hrir, np.float32)
-        assert (grid is not None or hrir.shape[0] == NUM_HRTF) and hrir.shape[1] == 2
         h = C.c_void_p()
         dev = (C.c_int * n_gpus)(*devices) if devices is not None else None
-        if grid is not None:
+        if sofa is None:
+            hrir = np.ascontiguousarray(hrir, np.float32)
+            assert (grid is not None or hrir.shape[0] == NUM_HRTF) and hrir.shape[1] == 2
+        if sofa is not None:
+            rc = L.jf_group_create_sofa(C.byref(cfg), n_gpus, dev, os.fsencode(sofa), sofa_tol_deg, C.byref(h))
+        elif grid is not None:
             self._grid = grid
             rc = L.jf_group_create_grid(C.byref(cfg), n_gpus, dev, C.byref(grid.c), _fp(hrir), hrir.shape[2], C.byref(h))
         elif shards_on_device > 0:

@@ -87,6 +87,28 @@ def test_engine_from_a_sofa_file(jf, castanets, name):
     assert_within(from_file, want32, sum_tol(TOL32, S), f"sofa {name}: vs oracle32")
 
 
+def test_group_from_a_sofa_file(jf, castanets):
+    """jf_group_create_sofa (one GPU: a communicator of size 1) renders what jf_engine_create_sofa renders"""
+    import importlib
+    grp = importlib.import_module("jefferson_amd.group")       # needs libjefferson_group.so (RCCL at build time)
+    path = os.path.join(SOFA, "nc4.sofa")
+    S, K, B = 6, 6, 128
+    pos = _trajectory(jf, S, K)
+    sigs = [(0.45 * np.roll(castanets, 2003 * s)[:9000 + 97 * s]).astype(np.float32) for s in range(S)]
+    e = jf.Engine(B, 512, S, sofa=path, sofa_tol_deg=0.01, max_batch_blocks=K)
+    G = grp.Group(B, 512, S, None, n_gpus=1, max_batch_blocks=K, sofa=path, sofa_tol_deg=0.01)
+    for s in range(S):
+        e.set_signal(s, sigs[s])
+        G.set_signal(s, sigs[s])
+    want, got = e.process_batch(pos), G.process_batch(pos)
+    e.close()
+    G.close()
+    assert np.abs(want).max() > 0.02 and np.array_equal(got, want)
+    with pytest.raises(jf.JfError) as ex:
+        grp.Group(B, 512, S, None, n_gpus=1, sofa=os.path.join(SOFA, "mono.sofa"))
+    assert ex.value.code == jf.JF_ERR_IO and "receivers" in str(ex.value)
+
+
 def test_hrtf_len_must_hold_the_sets_taps(jf):
     with pytest.raises(jf.JfError) as ex:
         jf.Engine(256, 16, 1, sofa=os.path.join(SOFA, "nc4.sofa"))      # 24 taps
