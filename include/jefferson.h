@@ -164,7 +164,8 @@ int jf_table_rows(const jf_engine *e);
  *     (jf_grid_from_positions: JF_ERR_ARG for a set that is not measured on rings of uniform azimuth steps), rows in ring
  *     order, hrir [M][2][taps] (taps >= jf_sofa_taps: the file's N + the largest Data.Delay).  SOFA azimuths run
  *     counter-clockwise (90 = left); the table's run the way KEMAR's file names do (90 = right): row azimuth =
- *     360 - SOFA azimuth.  Receiver 0 is the left ear.  Whole-sample delays shift their impulse response; fractional ones
+ *     360 - SOFA azimuth.  Receiver 0 is the left ear.  A set on KEMAR's own rings gets the reference's description of them
+ *     (jf_kemar_grid: the rounded steps), so an engine created from it IS jf_engine_create -- the reference's rule and blocks.  Whole-sample delays shift their impulse response; fractional ones
  *     are refused (JF_ERR_IO), and so are sets with other than two receivers or a sampling rate other than 44100 Hz (the
  *     reference's own check of its HRIR files, hrtf_signals.cu:68-75: the distance factor is written for that rate).
  *   jf_engine_create_sofa: the two, then jf_engine_create_grid.  cfg->hrtf_len must hold jf_sofa_taps.

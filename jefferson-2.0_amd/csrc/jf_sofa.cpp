@@ -227,6 +227,15 @@ int sofa_table(const jf_sofa_set *s, float tol_deg, jf_grid_layout *layout, floa
     const int rc = host_grid_from_positions(M, az.data(), s->elevation, tol_deg, &layout->n_rings, layout->ring_elevation,
                                             layout->ring_count, layout->ring_step, row_of.data(), err);
     if (rc) return rc;
+    // KEMAR's own rings (-40 .. 90 in tens, 56 60 72 ... 1 measurements): the reference's description of them, its ROUNDED
+    // steps included (hrtf_signals.cu:8), so that jf_engine_create_grid recognises the grid and the engine IS
+    // jf_engine_create -- the reference's rule, the reference's blocks -- whether the set came as WAV files or as a SOFA file
+    const RingTable &k = ring_table();
+    bool kemar = layout->n_rings == k.n_rings;
+    for (int r = 0; kemar && r < k.n_rings; r++)
+        kemar = layout->ring_elevation[r] == k.ele[r] && layout->ring_count[r] == k.offset[r + 1] - k.offset[r];
+    if (kemar)
+        for (int r = 0; r < k.n_rings; r++) layout->ring_step[r] = kemar_ring_steps()[r];
     memset(hrir, 0, sizeof(float) * M * 2 * (size_t)taps);
     for (size_t i = 0; i < M; i++)
         for (int ear = 0; ear < 2; ear++) {

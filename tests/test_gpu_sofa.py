@@ -122,7 +122,7 @@ def test_hrtf_len_must_hold_the_sets_taps(jf):
 def test_kemar_as_a_sofa_file(jf, hrir, castanets, tmp_path):
     """KEMAR's 710 impulse responses written by libhdf5 as a SimpleFreeFieldHRIR file -- shuffled, azimuths the whole degrees
     of the files' names in SOFA's counter-clockwise sense, deflated float64 -- and read back by the library: the table's
-    rows are the reference loader's rows (spectra bit for bit), and blocks equal those of the engine built from the arrays."""
+    rows are the reference loader's rows (spectra bit for bit), and the engine is jf_engine_create's engine."""
     pos = model64.table_positions()
     np.save(tmp_path / "hrir.npy", hrir)
     np.save(tmp_path / "ele.npy", np.array([e for e, _ in pos], np.float64))
@@ -158,15 +158,23 @@ np.save(d + "/order.npy", order)
     ref = jf.Engine(256, 512, 4, hrir=hrir, max_batch_blocks=6)
     assert e.table_rows() == 710 and np.array_equal(e.read_table(), ref.read_table())
     ref.close()
-    e2 = jf.Engine(256, 512, 4, hrir=hrir, grid=grid, max_batch_blocks=6)
+    # KEMAR's rings are recognised: the reference's description (its rounded steps), the reference's rule -- the engine from the
+    # SOFA file IS jf_engine_create (and, with the flag, the corrected rule's engine), FD_BASIC included
+    assert np.array_equal(grid.step, jf.Grid.kemar().step)
     tr = _trajectory(jf, 4, 6)
-    out = []
-    for eng in (e, e2):
-        for s in range(4):
-            eng.set_signal(s, (0.4 * np.roll(castanets, 1500 * s)[:8000]).astype(np.float32))
-        out.append(eng.process_batch(tr))
-        eng.close()
-    assert np.abs(out[0]).max() > 0.02 and np.array_equal(out[0], out[1])
+    tr[:, :, 0] = np.maximum(tr[:, :, 0], -40)            # (the reference's range)
+    for flags in (0, jf.JF_FLAG_CORRECTED_INTERPOLATION):
+        out = []
+        for eng in (e if flags == 0 else jf.Engine(256, 512, 4, sofa=path, sofa_tol_deg=0.51, max_batch_blocks=6, flags=flags),
+                    jf.Engine(256, 512, 4, hrir=hrir, max_batch_blocks=6, flags=flags)):
+            for s in range(4):
+                eng.set_signal(s, (0.4 * np.roll(castanets, 1500 * s)[:8000]).astype(np.float32))
+            a = eng.process_batch(tr[:4])
+            eng.set_mode(jf.JF_MODE_FD_BASIC)
+            out.append(np.concatenate([a, eng.process_batch(tr[4:])]))
+            assert eng.set_spherical(0, -60.0, 0.0, 1.0) == jf.JF_ERR_RANGE
+            eng.close()
+        assert np.abs(out[0]).max() > 0.02 and np.array_equal(out[0], out[1])
 
 
 def test_offline_driver_on_a_sofa_file(jf, tmp_path):
