@@ -765,6 +765,107 @@ JF_DEV void big_mac_item(const ReverbBigParams &P, int item) {
         if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
 }
 
+// The tiled form with the response's spectra through LDS (JF_RV_BIG_MAC_LDS_H): the waves of a workgroup take the SAME 64 bins
+// of kBigMacWavesTiled different sources, so the H_q they multiply by are the same: each wave fetches a quarter of a group
+// of KB partitions' H into LDS a group ahead, and a step reads its H with one ds_read_b64.  A wave's vector-memory
+// instructions per step: 1.25 instead of 2 (the delay line's X, which nobody shares, and a quarter of an H).  Same sums in the
+// same order as big_mac_item.
+// 66.8 -> 59.2-60.5 us per launch at config 5's batch shape on one box, 70 -> 64.5 on another (profiles/r05/reverb_batch.md): a
+// compute unit tracks a bounded number of vector-memory INSTRUCTIONS in flight, and half of them were loads of H out of the L2.
+#ifndef JF_RV_BIG_MAC_LDS_H
+#define JF_RV_BIG_MAC_LDS_H 1
+#endif
+template <int B1, int KB>
+JF_DEV void big_mac_item_shared(const ReverbBigParams &P, int item) {
+    constexpr int W = kBigMacWavesTiled, HPW = KB / W, kSlices = B1 / 64;
+    static_assert(KB % W == 0 && KB > 1, "every wave fetches the same number of a group's partitions");
+    __shared__ rv_v2 s_h[2][KB][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_tiles = (P.n_prod + KB - 1) / KB;
+    const int slice = item % kSlices, rest = item / kSlices;
+    const int s_raw = (rest / n_tiles) * W + wave;
+    const bool live = s_raw < P.S;  // (a wave without a source works on the last one's data and stores nothing: the barriers need it)
+    const int s = live ? s_raw : P.S - 1;
+    const int i0 = (rest % n_tiles) * KB;
+    const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
+    const char *hbase = reinterpret_cast<const char *>(P.hspec1 + (size_t)P.h_first * B1);
+    unsigned voff = 8u * (unsigned)(64 * slice + lane);
+    asm volatile("" : "+v"(voff));
+    auto load_at = [&](const char *base) {
+        const float2 *q = reinterpret_cast<const float2 *>(base + voff);
+        return rv_v2{q->x, q->y};
+    };
+#if JF_RV_BIG_NT_X
+    auto load_x = [&](const char *base) {
+        const rv_v2 *q = reinterpret_cast<const rv_v2 *>(base + voff);
+        return __builtin_nontemporal_load(q);
+    };
+#else
+    auto load_x = load_at;
+#endif
+    auto slot_of = [&](int u) {
+        int slot = (P.anchor_slot_first + i0 + u) % P.R1;
+        return slot < 0 ? slot + P.R1 : slot;
+    };
+    const int n_groups = (P.n_part + KB - 1) / KB;
+    rv_v2 hn[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; k++) hn[k] = load_at(hbase + (size_t)(wave * HPW + k) * ((size_t)B1 * 8));
+    rv_v2 acc[KB], xr[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
+#pragma unroll
+    for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_x(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
+    int xslot = slot_of(0);
+    constexpr int D = JF_RV_BIG_PREFETCH < KB ? JF_RV_BIG_PREFETCH : KB;
+    static_assert(KB % D == 0, "the queue index of a step is a constant after unrolling");
+    rv_v2 xq[D];
+    auto fetch = [&](int d) {
+        xq[d] = load_x(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));  // X(-q)
+        xslot = xslot == 0 ? P.R1 - 1 : xslot - 1;
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d);
+#pragma unroll
+    for (int k = 0; k < HPW; k++) s_h[0][wave * HPW + k][lane] = hn[k];
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < n_groups; g++) {
+        const bool more = g + 1 < n_groups;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < HPW; k++) hn[k] = load_at(hbase + (size_t)((g + 1) * KB + wave * HPW + k) * ((size_t)B1 * 8));
+        }
+        const rv_v2 *hl = &s_h[g & 1][0][lane];
+        rv_v2 hnext = hl[0];
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+            const rv_v2 h = hnext;
+            if (j + 1 < KB) hnext = hl[(j + 1) * 64];
+            xr[(KB - j) % KB] = xq[j % D];
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(j % D);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KB; i++) acc[i] = pfma_re(xr[(i + KB - j) % KB], h, acc[i]);
+#pragma unroll
+            for (int i = 0; i < KB; i++) acc[i] = pfma_im_rot(xr[(i + KB - j) % KB], h, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < HPW; k++) s_h[(g + 1) & 1][wave * HPW + k][lane] = hn[k];
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    float2 *y = P.ybig + ((size_t)s * P.n_prod + i0) * B1 + (voff >> 3);
+#pragma unroll
+    for (int i = 0; i < KB; i++)
+        if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
+}
+
 // One workgroup per item (64 bins per wave of one tile of one source) -- or, for single products on the side stream
 // (mac_wgs > 0), that many workgroups taking the items in turn: a launch that does not fill the GPU's wave slots, so that the
 // kernels of the blocks it runs beside find room at once (jf_engine.cpp: run_reverb_stage).
@@ -776,7 +877,11 @@ __global__ __launch_bounds__(64 * (KB == 1 ? kBigMacWaves : kBigMacWavesTiled)) 
 #pragma unroll 1
         for (int item = blockIdx.x; item < n_items; item += gridDim.x) big_mac_item<B1, KB>(P, item);
     } else {
+#if JF_RV_BIG_MAC_LDS_H
+        big_mac_item_shared<B1, KB>(P, blockIdx.x);
+#else
         big_mac_item<B1, KB>(P, blockIdx.x);
+#endif
     }
 }
 
@@ -1111,10 +1216,16 @@ static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
 static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
-    constexpr int per_spec = B1 / (64 * kBigMacWaves), per_spec_tiled = B1 / (64 * kBigMacWavesTiled);
+    constexpr int per_spec = B1 / (64 * kBigMacWaves);
+    [[maybe_unused]] constexpr int per_spec_tiled = B1 / (64 * kBigMacWavesTiled);
     if (P.n_prod >= 4) {
         const int tiles = (P.n_prod + 15) / 16;
-        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(per_spec_tiled * tiles * P.S), dim3(64 * kBigMacWavesTiled), 0, st, P);
+#if JF_RV_BIG_MAC_LDS_H
+        const int grid = (B1 / 64) * tiles * ((P.S + kBigMacWavesTiled - 1) / kBigMacWavesTiled);
+#else
+        const int grid = per_spec_tiled * tiles * P.S;
+#endif
+        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(grid), dim3(64 * kBigMacWavesTiled), 0, st, P);
     } else {
         const int n_items = per_spec * P.n_prod * P.S;
         const int wgs = P.mac_wgs > 0 && P.mac_wgs < n_items ? P.mac_wgs : n_items;
