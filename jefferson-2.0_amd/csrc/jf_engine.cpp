@@ -912,6 +912,10 @@ int create_engine(const jf_config *cfg, const RingTable *grid, const float *hrir
             e->interp_use = e->interp_avail ? 2 : 0;
             if (env && e->interp_avail && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
         }
+        if (const char *env = getenv("JF_RV_SIDE_WGS")) {  // tuning runs only (profiles/rt_ab.sh)
+            const int n = atoi(env);
+            if (n >= 8 && n <= 65536) e->rv_side_wgs = n;
+        }
         // the 710 measured rows only; the pre-interpolated ones come with the first run that takes them (ensure_interp_rows)
         e->rt = grid ? *grid : ring_table();
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * (size_t)e->rt.n_rows * 512));
@@ -2170,8 +2174,11 @@ const char *jf_debug_last_kernels(jf_engine *e) {
             const std::string b1 = std::to_string(e->rv_B1);
             auto per_wg = [&](int) { return std::string(",1>;"); };  // transforms per workgroup and turn (persistent since round 5)
             auto products = [&](const ReverbBigParams &g) {
-                return g.n_prod > 0 ? "reverb_big_mac_kernel<" + b1 + "," + (g.n_prod >= 4 ? "16" : "1") + ">;reverb_big_ifft_kernel<" +
-                                          b1 + per_wg(g.n_prod) : std::string();
+                if (g.n_prod <= 0) return std::string();
+                const std::string mac = g.n_prod >= 4 ? "reverb_big_mac_kernel<" + b1 + ",16>"
+                                        : JF_RV_BIG_MAC1_SHARED && g.mac_wgs == 0 ? "reverb_big_mac1_kernel<" + b1 + ">"
+                                                                                  : "reverb_big_mac_kernel<" + b1 + ",1>";
+                return mac + ";reverb_big_ifft_kernel<" + b1 + per_wg(g.n_prod);
             };
             auto transforms = [&](const ReverbBigParams &g) {
                 return g.n_tr > 0 ? "reverb_big_fft_kernel<" + b1 + per_wg(g.n_tr) : std::string();

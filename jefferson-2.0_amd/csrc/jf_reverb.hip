@@ -866,6 +866,84 @@ JF_DEV void big_mac_item_shared(const ReverbBigParams &P, int item) {
         if (i0 + i < P.n_prod) y[(size_t)i * B1] = make_float2(acc[i].x, acc[i].y);
 }
 
+// Single products (one-block calls: the side stream) the same way -- JF_RV_BIG_MAC1_SHARED: the eight waves of a workgroup take
+// the same 64 bins of eight sources; the response's spectra for those bins go to LDS once per workgroup (up to 64 partitions
+// at a time); a wave then has nothing but the delay line's X to load, and loads it U partitions ahead (the plain form waits
+// for every partition's two loads before it asks for the next: 42 round trips in a row).  Same sums in the same order.
+// configs[4]'s shape: 82.9 -> 37.2 us per launch over 256 workgroups.  Used IN LINE (launch_big_products_t says why not
+// beside the blocks).
+// (JF_RV_BIG_MAC1_SHARED: jf_device.h)
+#ifndef JF_RV_BIG_MAC1_AHEAD
+#define JF_RV_BIG_MAC1_AHEAD 8
+#endif
+template <int B1>
+JF_DEV void big_mac_single_shared(const ReverbBigParams &P, int item, rv_v2 (*s_h)[64], int &h_slice) {
+    constexpr int W = kBigMacWaves, kSlices = B1 / 64, U = JF_RV_BIG_MAC1_AHEAD, kChunk = 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = item % kSlices, rest = item / kSlices;
+    const int i0 = rest % P.n_prod;
+    const int s_raw = (rest / P.n_prod) * W + wave;
+    const bool live = s_raw < P.S;
+    const int s = live ? s_raw : P.S - 1;
+    const char *fdl0 = reinterpret_cast<const char *>(P.fdl1 + (size_t)s * P.R1 * B1);
+    const char *hbase = reinterpret_cast<const char *>(P.hspec1 + (size_t)P.h_first * B1);
+    unsigned voff = 8u * (unsigned)(64 * slice + lane);
+    asm volatile("" : "+v"(voff));
+    auto load_at = [&](const char *base) {
+        const float2 *q = reinterpret_cast<const float2 *>(base + voff);
+        return rv_v2{q->x, q->y};
+    };
+#if JF_RV_BIG_NT_X
+    auto load_x = [&](const char *base) {
+        const rv_v2 *q = reinterpret_cast<const rv_v2 *>(base + voff);
+        return __builtin_nontemporal_load(q);
+    };
+#else
+    auto load_x = load_at;
+#endif
+    int xslot = (P.anchor_slot_first + i0) % P.R1;
+    xslot = xslot < 0 ? xslot + P.R1 : xslot;
+    rv_v2 acc = rv_v2{0.f, 0.f};
+    for (int c0 = 0; c0 < P.n_part; c0 += kChunk) {
+        const int nc = P.n_part - c0 < kChunk ? P.n_part - c0 : kChunk;
+        if (h_slice != slice || P.n_part > kChunk) {  // (a workgroup's items keep their bins when the grid is a multiple of kSlices)
+            __syncthreads();                           // everybody is done with what is there
+            for (int q = wave; q < nc; q += W) s_h[q][lane] = load_at(hbase + (size_t)(c0 + q) * ((size_t)B1 * 8));
+            __syncthreads();
+            h_slice = P.n_part > kChunk ? -1 : slice;
+        }
+        // the delay line's spectra U partitions at a time, the next U requested before these are used
+        rv_v2 xa[U], xb[U];
+        auto fetch = [&](rv_v2 (&x)[U], int q0) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (q0 + u < nc) {
+                    x[u] = load_x(fdl0 + (size_t)(unsigned)xslot * ((size_t)B1 * 8));
+                    xslot = xslot == 0 ? P.R1 - 1 : xslot - 1;
+                }
+        };
+        auto use = [&](const rv_v2 (&x)[U], int q0) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (q0 + u < nc) {
+                    const rv_v2 h = s_h[q0 + u][lane];
+                    acc = pfma_re(x[u], h, acc);
+                    acc = pfma_im_rot(x[u], h, acc);
+                }
+        };
+        fetch(xa, 0);
+        for (int q0 = 0; q0 < nc; q0 += 2 * U) {
+            fetch(xb, q0 + U);
+            use(xa, q0);
+            fetch(xa, q0 + 2 * U);
+            use(xb, q0 + U);
+        }
+    }
+    if (!live) return;
+    P.ybig[((size_t)s * P.n_prod + i0) * B1 + (voff >> 3)] = make_float2(acc.x, acc.y);
+}
+
 // One workgroup per item (64 bins per wave of one tile of one source) -- or, for single products on the side stream
 // (mac_wgs > 0), that many workgroups taking the items in turn: a launch that does not fill the GPU's wave slots, so that the
 // kernels of the blocks it runs beside find room at once (jf_engine.cpp: run_reverb_stage).
@@ -883,6 +961,16 @@ __global__ __launch_bounds__(64 * (KB == 1 ? kBigMacWaves : kBigMacWavesTiled)) 
         big_mac_item<B1, KB>(P, blockIdx.x);
 #endif
     }
+}
+
+// single products in line (big_mac_single_shared): one workgroup per 64 bins of eight sources, or fewer taking them in turn
+template <int B1>
+__global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac1_kernel(const ReverbBigParams P) {
+    __shared__ rv_v2 s_h[64][64];
+    int h_slice = -1;
+    const int n_items = (B1 / 64) * P.n_prod * ((P.S + kBigMacWaves - 1) / kBigMacWaves);
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) big_mac_single_shared<B1>(P, item, s_h, h_slice);
 }
 
 #ifndef JF_RV_BIG_IFFT_WQ_REGS
@@ -1216,7 +1304,7 @@ static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
 static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
-    constexpr int per_spec = B1 / (64 * kBigMacWaves);
+    [[maybe_unused]] constexpr int per_spec = B1 / (64 * kBigMacWaves);
     [[maybe_unused]] constexpr int per_spec_tiled = B1 / (64 * kBigMacWavesTiled);
     if (P.n_prod >= 4) {
         const int tiles = (P.n_prod + 15) / 16;
@@ -1227,9 +1315,17 @@ static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
 #endif
         hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 16>), dim3(grid), dim3(64 * kBigMacWavesTiled), 0, st, P);
     } else {
-        const int n_items = per_spec * P.n_prod * P.S;
-        const int wgs = P.mac_wgs > 0 && P.mac_wgs < n_items ? P.mac_wgs : n_items;
-        hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(wgs), dim3(64 * kBigMacWaves), 0, st, P);
+        // beside the blocks of one-block calls (mac_wgs > 0: the side stream) the plain form, narrow: 83 us per launch at
+        // configs[4], spread thinly over four blocks -- the shared form is done in 37 us and the block it meets pays for it
+        // (mean 23.9 against 24.5 us per block, p99 38 against 35.5: profiles/r05/reverb_realtime.md); in line the shared form
+        if (JF_RV_BIG_MAC1_SHARED && P.mac_wgs == 0) {
+            const int n_items = (B1 / 64) * P.n_prod * ((P.S + kBigMacWaves - 1) / kBigMacWaves);
+            hipLaunchKernelGGL((reverb_big_mac1_kernel<B1>), dim3(n_items), dim3(64 * kBigMacWaves), 0, st, P);
+        } else {
+            const int n_items = per_spec * P.n_prod * P.S;
+            const int wgs = P.mac_wgs > 0 && P.mac_wgs < n_items ? P.mac_wgs : n_items;
+            hipLaunchKernelGGL((reverb_big_mac_kernel<B1, 1>), dim3(wgs), dim3(64 * kBigMacWaves), 0, st, P);
+        }
     }
     const int n = P.n_prod * P.S;
     // persistent grids: what the device holds at once (the surplus of a larger grid would only queue)

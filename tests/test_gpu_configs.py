@@ -253,7 +253,7 @@ def test_config4_tiled_reverb_kernel_at_690_partitions(jf, hrir, castanets, S, K
             assert "reverb_mac_tiled_kernel<128,16>" in ks, ks
         else:
             # calls of whole big blocks: the big partitions form every block's wet signal, no block goes through the head
-            assert f"reverb_big_mac_kernel<2048,{16 if K >= 64 else 1}>" in ks, ks
+            assert ("reverb_big_mac_kernel<2048,16>" if K >= 64 else "reverb_big_mac1_kernel<2048>") in ks, ks
             # (persistent workgroups, one transform per turn, since round 5)
             assert "reverb_big_fft_kernel<2048,1>" in ks and "reverb_big_ifft_kernel<2048,1>" in ks, ks
             assert not any(k.startswith("reverb_mac") for k in ks), ks

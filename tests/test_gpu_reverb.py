@@ -380,7 +380,7 @@ def test_nonuniform_blockwise_equals_batch_and_the_default_takes_it(jf, hrir, ca
         for _ in range(16):
             e.process_block()
         ks = e.last_kernels()      # the 49th block is the first of big block 3: TAIL(3) in front of the head
-        assert ks == ["reverb_big_mac_kernel<2048,1>", "reverb_big_ifft_kernel<2048,1>"] + head + [rt], ks
+        assert ks == ["reverb_big_mac1_kernel<2048>", "reverb_big_ifft_kernel<2048,1>"] + head + [rt], ks
         e.process_block()
         assert not any(k.startswith("reverb_big") for k in e.last_kernels())
         e.close()
