@@ -47,6 +47,7 @@ BLOCKS_PER_STEP = int(os.environ.get("JF_BLOCKS_PER_STEP", "128"))
 # --reverb (batch form): 256 blocks of 128 = the same 0.74 s of audio per launch (32: -35 %, 64: -21 %, 128: -8 %)
 REVERB_BLOCKS_PER_STEP = int(os.environ.get("JF_REVERB_BLOCKS_PER_STEP", "256"))
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth (MI355X_MICROARCH.md, L2): 64 B per clock and CU at the vector L1s
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming read achieves from HBM (same guide)
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md; needs packed FMAs: 2 x 78.6)
 TOL32 = 4e-7                # HIP vs float32 oracle, per source (tests/)
@@ -580,6 +581,24 @@ def main():
         roof["algorithmic_bytes_per_launch"] = abytes / launches
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
         fpmc = None if ir is not None else pmc   # with --reverb the counters are the multiply-accumulate kernel's
+        # How busy the compute units' vector-memory return path is (round 5, profiles/r05/l1_bound.md): a vector L1 returns 64
+        # bytes per clock (256 CUs x 64 B x ~2.1 GHz = the guide's 34.5 TB/s for the L2s, the same pipe from the other
+        # side).  From the kernel's own load count -- the algorithmic figure above counts 6.65 rows per source-block, the
+        # kernel loads ~4.2 (old and new filter sets mostly share their rows): 16-byte row loads of 1 KB per wave, eight
+        # 8-byte window loads of 512 B.  Neither this pipe nor the vector unit is saturated: the kernel waits on its chain of
+        # dependent load stages at four waves per SIMD (half the row-load stages at unchanged arithmetic: -12.5 %).
+        if fpmc and fpmc.get("SQ_INSTS_VMEM_RD") and fpmc.get("GRBM_GUI_ACTIVE") and fused_s > 0:
+            loads = fpmc["SQ_INSTS_VMEM_RD"]                      # wave-instructions per launch
+            win = 8.0 * S * KB                                     # the windows' (8 B per lane)
+            l1_bytes = max(loads - win, 0.0) * 1024.0 + min(loads, win) * 512.0
+            cyc = fpmc["GRBM_GUI_ACTIVE"] / 8.0                   # (summed over the 8 XCDs) cycles of one launch under the counters
+            roof["l1"] = {"what": "bytes the vector L1s return to registers per launch, from the kernel's own load count",
+                          "bytes_per_launch": l1_bytes, "achieved": l1_bytes / (fused_s / launches) / 1e9, "unit": "GB/s",
+                          "peak": L2_PEAK_GBS, "peak_source": "MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s = 64 B per clock and CU",
+                          "frac": l1_bytes / (fused_s / launches) / 1e9 / L2_PEAK_GBS,
+                          "bytes_per_clock_and_cu": l1_bytes / cyc / 256.0,
+                          "clock_ghz_under_the_counters": cyc / (fused_s / launches) / 1e9,
+                          "loads_per_source_block": loads / (S * KB), "evidence": "profiles/r05/l1_bound.md", "source": pmc_note}
         if fpmc and "FETCH_SIZE" in fpmc and "WRITE_SIZE" in fpmc:
             # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads 1/2 of a wide
             # coalesced stream -> x2; WRITE_SIZE is exact for 16-B-per-lane stores
