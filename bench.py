@@ -585,8 +585,8 @@ def main():
         # bytes per clock (256 CUs x 64 B x ~2.1 GHz = the guide's 34.5 TB/s for the L2s, the same pipe from the other
         # side).  From the kernel's own load count -- the algorithmic figure above counts 6.65 rows per source-block, the
         # kernel loads ~4.2 (old and new filter sets mostly share their rows): 16-byte row loads of 1 KB per wave, eight
-        # 8-byte window loads of 512 B.  Neither this pipe nor the vector unit is saturated: the kernel waits on its chain of
-        # dependent load stages at four waves per SIMD (half the row-load stages at unchanged arithmetic: -12.5 %).
+        # 8-byte window loads of 512 B.  Half busy, and not what the kernel waits for (closer rows -3..-4.5 %, more loads in
+        # flight nothing): reported so that the third resource is on the line beside the vector unit and HBM.
         if fpmc and fpmc.get("SQ_INSTS_VMEM_RD") and fpmc.get("GRBM_GUI_ACTIVE") and fused_s > 0:
             loads = fpmc["SQ_INSTS_VMEM_RD"]                      # wave-instructions per launch
             win = 8.0 * S * KB                                     # the windows' (8 B per lane)

@@ -71,6 +71,9 @@ constexpr int kModeBasic = 1, kModeCorrected = 2, kModeInterpRows = 4;  // bits 
 #ifndef JF_RV_BIG_MAC1_SHARED
 #define JF_RV_BIG_MAC1_SHARED 1  // reverb, single products of the big partitions IN LINE: the shared form (jf_reverb.hip: big_mac_single_shared)
 #endif
+#ifndef JF_STAGE_DEPTH
+#define JF_STAGE_DEPTH 2  // pair kernel: stages of a half-filter's row loads in flight
+#endif
 #ifndef JF_UNIT_ZIGZAG
 #define JF_UNIT_ZIGZAG 2  // order of the units over the rounds of the pair kernel (see there): 2 rotated, 1 zigzag, 0 plain
 #endif

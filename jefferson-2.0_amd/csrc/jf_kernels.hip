@@ -961,27 +961,29 @@ JF_DEV void filtered_half(const float4 *__restrict__ htab, unsigned lofs, const 
     // the kernel waits for: profiles/r02_experiments.md).
     constexpr int QC = (JF_STAGE_LOADS / NT) > 4 ? 4 : ((JF_STAGE_LOADS / NT) < 1 ? 1 : (JF_STAGE_LOADS / NT));
     constexpr int NS = 4 / QC;
-    float4 h[2][QC][NT];
+    // JF_STAGE_DEPTH stages in flight (2; 3 or 4 = more landing registers: what a stage's wait costs is in profiles/r05/l1_bound.md)
+    constexpr int DEPTH = JF_STAGE_DEPTH < NS ? JF_STAGE_DEPTH : NS;
+    float4 h[DEPTH][QC][NT];
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int q = 0; q < QC; q++)
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                h[st & 1][q][t] =
+                h[st % DEPTH][q][t] =
                     *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(hp[t] + 64 * (QC * st + q)) + boff);
     };
-    load_stage(0);
-    if (NS > 1) load_stage(1);
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++) load_stage(st);
     __builtin_amdgcn_sched_barrier(0);
     float2 xh[4];
     fetch(xh);
 #pragma unroll
     for (int st = 0; st < NS; st++) {
-        if (st >= 1 && st + 1 < NS) load_stage(st + 1);
+        if (st >= 1 && st + DEPTH - 1 < NS) load_stage(st + DEPTH - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < QC; q++) {
-            const float4(&hq)[NT] = h[st & 1][q];
+            const float4(&hq)[NT] = h[st % DEPTH][q];
             c2 haL, haR, hbL = c2{0.f, 0.f}, hbR = c2{0.f, 0.f};
             weighted_ears<NT>(hq, a, haL, haR);
             if (BOTH) weighted_ears<NT>(hq, b, hbL, hbR);
