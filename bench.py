@@ -385,6 +385,12 @@ def main():
         eng.set_signal(s, wl.source_signal_and_start(sid)[0])
     if os.environ.get("JF_SOURCE_GROUP"):
         eng.set_source_group(int(os.environ["JF_SOURCE_GROUP"]))  # tuning runs only
+    # tuning runs only (profiles/r04_interp_*.sh, rt_ab.sh): the library itself reads nothing from the environment since
+    # round 6 -- the A/B scripts' variables are turned into calls of jefferson_debug.h's setters here
+    if os.environ.get("JF_INTERP_TABLE") in ("0", "1", "2"):
+        eng.set_interp_table(int(os.environ["JF_INTERP_TABLE"]))
+    if os.environ.get("JF_RV_SIDE_WGS"):
+        eng.set_reverb_side_workgroups(int(os.environ["JF_RV_SIDE_WGS"]))
     if ir is not None:
         if os.environ.get("JF_RV_PARTITIONING"):   # 1 = uniform partitions (round 3's form), 2 = non-uniform; default: by length
             eng.set_reverb_partitioning(int(os.environ["JF_RV_PARTITIONING"]))

@@ -111,18 +111,7 @@ int jf_group_synchronize(jf_group *g);
  */
 int jf_group_failed(const jf_group *g);
 
-/*
- * Test support: what of the several-GPU host code a one-GPU box can exercise with MORE THAN ONE shard.
- * jf_group_create_shards_on_device: n_shards engines, all on `device`, no RCCL communicator (RCCL refuses duplicate
- * devices); batch runs leave every shard's mix in its buffer and jf_group_batch_fetch adds them on the host in shard order
- * -- the sharding, the per-shard repack of the trajectory, the routing of the per-source calls, the job-wide controls and the
- * FAILED transitions are the production code, only the wire is replaced.
- * jf_group_debug_fail_next: the next processing step or control call that reaches shard `shard` fails with JF_ERR_DEVICE
- * without touching the engine (-1 disarms).
- */
-int jf_group_create_shards_on_device(const jf_config *cfg, int n_shards, int device, const float *hrir, int taps,
-                                     jf_group **out);
-int jf_group_debug_fail_next(jf_group *g, int shard);
+/* (Test support -- several shards of a job on ONE device, forced failures -- is declared in jefferson_debug.h.) */
 
 #ifdef __cplusplus
 }

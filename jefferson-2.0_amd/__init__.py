@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # JF_LIB selects an A/B build of the same library (csrc/Makefile `variant`); default = the product
 LIB_PATH = os.environ.get("JF_LIB") or os.path.join(_HERE, "libjefferson_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson.h")
+DEBUG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jefferson_debug.h")  # taps, timing hooks, tuning switches
 
 JF_OK, JF_ERR_ARG, JF_ERR_RANGE, JF_ERR_DEVICE, JF_ERR_IO, JF_ERR_STATE, JF_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 JF_FLAG_CORRECTED_INTERPOLATION = 1
@@ -104,6 +105,7 @@ _SIGS = {
     "jf_batch_upload_positions": (C.c_int, [C.c_void_p, C.c_int, _f]),
     "jf_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "jf_synchronize": (C.c_int, [C.c_void_p]),
+    "jf_batch_fetch": (C.c_int, [C.c_void_p, C.c_int, _f]),
     "jf_batch_mix_device": (C.c_void_p, [C.c_void_p]),
     "jf_batch_partial_device": (C.c_void_p, [C.c_void_p]),
     "jf_engine_stream": (C.c_void_p, [C.c_void_p]),
@@ -135,6 +137,7 @@ _SIGS = {
     "jf_debug_set_reverb_head_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_lazy_state": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_debug_set_reverb_ahead": (C.c_int, [C.c_void_p, C.c_int]),
+    "jf_debug_set_reverb_side_workgroups": (C.c_int, [C.c_void_p, C.c_int]),
     "jf_sources_set_latched": (C.c_int, [C.c_void_p, _f]),
     "jf_device_numa_node": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "jf_pin_thread_to_device": (C.c_int, [C.c_int]),
@@ -152,7 +155,7 @@ _SIGS = {
 
 
 def exported_symbols():
-    """Names every include/jefferson.h entry point must be exported under."""
+    """Names every entry point of include/jefferson.h and include/jefferson_debug.h must be exported under."""
     return sorted(_SIGS)
 
 
@@ -401,7 +404,7 @@ class Engine:
             rc = L.jf_engine_create_sofa(C.byref(cfg), os.fsencode(sofa), sofa_tol_deg, C.byref(h))
         elif grid is not None:
             hrir = np.ascontiguousarray(hrir, np.float32)
-            assert hrir.shape[1] == 2
+            assert hrir.ndim == 3 and hrir.shape[0] == grid.rows() and hrir.shape[1] == 2  # the C side reads rows x 2 x taps floats
             self._grid = grid
             rc = L.jf_engine_create_grid(C.byref(cfg), C.byref(grid.c), _fp(hrir), hrir.shape[2], C.byref(h))
         elif hrir_dir is not None:
@@ -498,6 +501,12 @@ class Engine:
     def synchronize(self):
         self._chk(lib().jf_synchronize(self.h))
 
+    def batch_fetch(self, n_blocks):
+        """the engine's own mix of the last batch_run (d_out_mix = NULL), [n_blocks][2B], on the host"""
+        out = np.empty((n_blocks, 2 * self.B), np.float32)
+        self._chk(lib().jf_batch_fetch(self.h, int(n_blocks), _fp(out)))
+        return out
+
     def mix_device_ptr(self):
         return lib().jf_batch_mix_device(self.h)
 
@@ -583,12 +592,17 @@ class Engine:
         """one-block calls launch the next block's reverb stage behind their own spatialiser (default) or not"""
         self._chk(lib().jf_debug_set_reverb_ahead(self.h, int(bool(on))))
 
+    def set_reverb_side_workgroups(self, n):
+        """workgroups of the product kernel on the reverb's side stream (tuning runs)"""
+        self._chk(lib().jf_debug_set_reverb_side_workgroups(self.h, int(n)))
+
     def set_reverb_lazy_state(self, on):
         """batch calls of whole big blocks put the small transforms of their last blocks off (default) or form them at once"""
         self._chk(lib().jf_debug_set_reverb_lazy_state(self.h, int(bool(on))))
 
     def set_reverb_head_fused(self, on):
-        """one-block calls: the reverb's head inside the real-time kernel's launch (default) or as a kernel of its own"""
+        """one-block calls: the reverb's head inside the real-time kernel's launch, or as a kernel of its own (default: measured 5 us
+        faster per block)"""
         self._chk(lib().jf_debug_set_reverb_head_fused(self.h, int(bool(on))))
 
     def reverb_partitions(self):

@@ -21,6 +21,7 @@
 
 #include "../../include/jefferson.h"
 #include "../../include/jefferson_group.h"
+#include "../../include/jefferson_debug.h" /* `shards N`: several shards on the one device, forced failures */
 
 static unsigned long long rng_state = 88172645463325252ULL;
 static float frand(void) { /* xorshift64*, uniform in [-0.5, 0.5) */
@@ -261,8 +262,7 @@ static int test_shards(int n_shards) {
     CHECK(jf_batch_upload_positions(one, K * RUNS, pos));
     CHECK(jf_group_batch_upload_positions(grp, K * RUNS, pos));
     CHECK(jf_batch_run(one, K, K, NULL));
-    CHECK(jf_synchronize(one));
-    CHECK(jf_debug_copy_from_device(one, jf_batch_mix_device(one), a, sizeof(float) * 2 * B * K));
+    CHECK(jf_batch_fetch(one, K, a));
     CHECK(jf_group_batch_run(grp, K, K));
     if (jf_group_batch_run(grp, 0, K) != JF_ERR_STATE) return 1; /* one run in flight */
     CHECK(jf_group_batch_fetch(grp, b));

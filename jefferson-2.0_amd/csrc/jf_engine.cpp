@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/jefferson.h"
+#include "../../include/jefferson_debug.h"
 #include "jf_device.h"
 #include "jf_host.h"
 
@@ -80,7 +81,7 @@ struct jf_engine {
     // The kInterpRows pre-interpolated rows (jf_device.h; 386 MB behind the 710 measured rows) are built LAZILY: by the first
     // run whose policy takes them (run_blocks), or when jf_debug_set_interp_table(e, 1) / a read of those rows asks -- never for
     // an engine that only ever runs sources that move every block, and not for the eight shards of a job on one device.
-    bool interp_avail = false;  // the engine may have them (no JF_FLAG_NO_INTERP_TABLE, no JF_INTERP_TABLE=0, no failed allocation)
+    bool interp_avail = false;  // the engine may have them (no JF_FLAG_NO_INTERP_TABLE, no failed allocation)
     bool interp_built = false;  // d_htab holds them
     // ... and which batch calls use them (jf_debug_set_interp_table): 0 none, 1 all, 2 (default) decided per run.  A source
     // that stays where it is reads its one row out of the caches block after block (12-18 % faster than weighting four
@@ -656,7 +657,11 @@ int run_blocks(jf_engine *e, const float *d_pos, int K, float *d_mix_out, int fi
         const double moved = (double)(e->traj_moved[first_block + K] - e->traj_moved[first_block]) / (double)n_items;
         rows = moved <= kInterpMovedMax;
     }
-    if (rows && !e->interp_built) {  // the first run that takes them builds them
+    // a one-block call is the audio callback's (jf_submit_block with more sources than the one-launch kernel takes, or while
+    // profiling): it never pays the 386 MB allocation, the build and the stream synchronisation -- it weights per block
+    // (bit-identical) until a batch run, or the pre-warm call jf_debug_set_interp_table(e, 1), has built the rows
+    if (rows && !e->interp_built && K == 1 && first_block < 0) rows = false;
+    if (rows && !e->interp_built) {  // the first batch run that takes them builds them
         const int rc = ensure_interp_rows(e);
         if (rc) return rc;
         rows = e->interp_built;
@@ -906,16 +911,9 @@ int create_engine(const jf_config *cfg, const RingTable *grid, const float *hrir
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_main, hipEventDisableTiming));
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_side, hipEventDisableTiming));
         for (int kind = 0; kind < 3; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
-        {
-            const char *env = getenv("JF_INTERP_TABLE");
-            e->interp_avail = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE) && !(env && strcmp(env, "0") == 0);
-            e->interp_use = e->interp_avail ? 2 : 0;
-            if (env && e->interp_avail && (strcmp(env, "1") == 0 || strcmp(env, "2") == 0)) e->interp_use = atoi(env);
-        }
-        if (const char *env = getenv("JF_RV_SIDE_WGS")) {  // tuning runs only (profiles/rt_ab.sh)
-            const int n = atoi(env);
-            if (n >= 8 && n <= 65536) e->rv_side_wgs = n;
-        }
+        // (nothing of the engine's behaviour is read from the environment: jefferson_debug.h's setters are the overrides)
+        e->interp_avail = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE);
+        e->interp_use = e->interp_avail ? 2 : 0;
         // the 710 measured rows only; the pre-interpolated ones come with the first run that takes them (ensure_interp_rows)
         e->rt = grid ? *grid : ring_table();
         JF_HIP(e, hipMalloc(&e->d_htab, sizeof(float4) * (size_t)e->rt.n_rows * 512));
@@ -1836,6 +1834,23 @@ int jf_sources_set_latched(jf_engine *e, const float *records) {
     }
     return JF_OK;
     });
+}
+
+int jf_batch_fetch(jf_engine *e, int n_blocks, float *out_mix) {
+    return jf_guard([&]() -> int {
+    DeviceGuard bind(e);
+    if (!e || !out_mix || n_blocks <= 0 || n_blocks > e->maxK) return fail(e, JF_ERR_ARG, "bad fetch arguments");
+    JF_HIP(e, hipMemcpyAsync(out_mix, e->d_mix, sizeof(float) * 2 * e->B * (size_t)n_blocks, hipMemcpyDeviceToHost, e->stream));
+    JF_HIP(e, hipStreamSynchronize(e->stream));
+    if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);
+    return JF_OK;
+    });
+}
+
+int jf_debug_set_reverb_side_workgroups(jf_engine *e, int workgroups) {
+    if (!e || workgroups < 8 || workgroups > 65536) return JF_ERR_ARG;
+    e->rv_side_wgs = workgroups;
+    return JF_OK;
 }
 
 float *jf_batch_mix_device(jf_engine *e) { return e ? e->d_mix : nullptr; }

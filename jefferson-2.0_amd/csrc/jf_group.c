@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/jefferson_group.h"
+#include "../../include/jefferson_debug.h" /* the engines' streams: the reduce is enqueued behind their kernels */
 
 struct jf_group {
     int n;         /* GPUs */

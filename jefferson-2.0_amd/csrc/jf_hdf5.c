@@ -274,12 +274,17 @@ static int bt2_leaf(jf_h5 *f, uint64_t addr, unsigned nrec, unsigned rec_size, b
     return 0;
 }
 
-static int bt2_walk(jf_h5 *f, uint64_t addr, bt2_fn fn, void *ctx) {
+/* `type` is the tree's record type the caller's callback understands (5: a group's links by name, 8: an object's
+ * attributes by name) and `min_rec` the number of bytes that callback reads of a record: the file's own record size is
+ * only trusted to be at least that (a record size of 1 walked the callbacks off the end of the file: ADVICE r05) */
+static int bt2_walk(jf_h5 *f, uint64_t addr, unsigned type, unsigned min_rec, bt2_fn fn, void *ctx) {
     const uint8_t *p = at(f, addr, 16 + (uint64_t)f->so + 2 + (uint64_t)f->sl);
     if (!p) return -1;
     if (memcmp(p, "BTHD", 4) != 0 || p[4] != 0) return fail(f, "HDF5: no version-2 B-tree at address %llu", (unsigned long long)addr);
+    if (p[5] != type) return fail(f, "HDF5: a version-2 B-tree of type %u where type %u belongs", (unsigned)p[5], type);
     const uint64_t node_size = rd(p + 6, 4);
     const unsigned rec_size = (unsigned)rd(p + 10, 2), depth = (unsigned)rd(p + 12, 2);
+    if (rec_size < min_rec) return fail(f, "HDF5: B-tree records of %u bytes, shorter than the %u their type needs", rec_size, min_rec);
     const uint64_t root = rd_off(f, p + 16);
     const unsigned nrec = (unsigned)rd(p + 16 + f->so, 2);
     if (rec_size == 0 || node_size < 16) return fail(f, "HDF5: B-tree with empty records");
@@ -442,7 +447,7 @@ static int group_links(jf_h5 *f, uint64_t addr, h5_links *out) {
             h5_fheap fh;
             dense_link_ctx ctx = {&fh, out};
             rc = fheap_open(f, heap, &fh);
-            if (rc == 0) rc = bt2_walk(f, bt, dense_link_rec, &ctx);
+            if (rc == 0) rc = bt2_walk(f, bt, 5, 4 + (unsigned)fh.id_len, dense_link_rec, &ctx); /* hash + heap ID */
         }
     }
     free(ms);
@@ -496,8 +501,10 @@ static int parse_space(jf_h5 *f, const uint8_t *p, uint64_t size, h5_space *s) {
     if (ver == 1) o = 8;
     else if (ver == 2) {
         o = 4;
-        if (p[3] == 2) { /* null dataspace */
-            s->rank = 0;
+        if (p[3] == 2) { /* null dataspace: handed out as one dimension of extent 0, so that a caller's product of the
+                          * extents is the element count (rank 0 is a scalar: one element) */
+            s->rank = 1;
+            s->dims[0] = 0;
             s->n = 0;
             return 0;
         }
@@ -821,7 +828,9 @@ int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRA
                 c.nominal = t.size;
                 for (int d = 0; rc == 0 && d < sp.rank; d++) {
                     c.cdim[d] = rd(pd + 4 * (uint64_t)d, 4);
-                    if (c.cdim[d] == 0 || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
+                    /* (a chunk of a fixed-size dataset is never wider than the dataset: bounds what a damaged file can make
+                     * unfilter() and place_chunk() allocate per chunk by the dataset's own size, checked above) */
+                    if (c.cdim[d] == 0 || c.cdim[d] > sp.dims[d] || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
                     else c.nominal *= c.cdim[d];
                 }
                 if (rc == 0) {
@@ -836,7 +845,7 @@ int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRA
                 c.nominal = t.size;
                 for (int d = 0; rc == 0 && d < sp.rank; d++) {
                     c.cdim[d] = rd(p + 5 + (uint64_t)eb * d, eb);
-                    if (c.cdim[d] == 0 || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
+                    if (c.cdim[d] == 0 || c.cdim[d] > sp.dims[d] || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
                     else {
                         c.nominal *= c.cdim[d];
                         n_chunks *= (sp.dims[d] + c.cdim[d] - 1) / c.cdim[d];
@@ -883,7 +892,7 @@ int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRA
         }
     }
     if (rc == 0) {
-        double *out = (double *)malloc(sizeof(double) * (size_t)(sp.n ? sp.n : 1));
+        double *out = (double *)calloc((size_t)(sp.n ? sp.n : 1), sizeof(double));
         if (!out) rc = fail(f, "out of memory");
         else {
             for (uint64_t i = 0; i < sp.n; i++) out[i] = to_double(raw + i * t.size, &t);
@@ -1008,7 +1017,7 @@ int jf_h5_attr_str(jf_h5 *f, uint64_t addr, const char *name, char *out, size_t 
             h5_fheap fh;
             ctx.heap = &fh;
             rc = fheap_open(f, heap, &fh);
-            if (rc == 0) rc = bt2_walk(f, bt, dense_attr_rec, &ctx);
+            if (rc == 0) rc = bt2_walk(f, bt, 8, (unsigned)fh.id_len + 9, dense_attr_rec, &ctx); /* heap ID, flags, creation order, hash */
         }
     }
     free(ms);

@@ -123,6 +123,10 @@ int sofa_read(const char *path, jf_sofa_set *out, std::string *err) {
     }
     size_t n_rate = 1;
     for (int i = 0; i < rank; i++) n_rate *= d[i];
+    if (rank > 1) {
+        *err = std::string(path) + ": Data.SamplingRate is neither a scalar nor [I] / [M]";
+        return JF_ERR_IO;
+    }
     if (n_rate < 1) {
         *err = std::string(path) + ": empty Data.SamplingRate";
         return JF_ERR_IO;

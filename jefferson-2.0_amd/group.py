@@ -82,7 +82,7 @@ class Group:
         dev = (C.c_int * n_gpus)(*devices) if devices is not None else None
         if sofa is None:
             hrir = np.ascontiguousarray(hrir, np.float32)
-            assert (grid is not None or hrir.shape[0] == NUM_HRTF) and hrir.shape[1] == 2
+            assert hrir.ndim == 3 and hrir.shape[0] == (grid.rows() if grid is not None else NUM_HRTF) and hrir.shape[1] == 2
         if sofa is not None:
             rc = L.jf_group_create_sofa(C.byref(cfg), n_gpus, dev, os.fsencode(sofa), sofa_tol_deg, C.byref(h))
         elif grid is not None:

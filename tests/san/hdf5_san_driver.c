@@ -15,7 +15,7 @@ static unsigned rnd(void) {
     rs ^= rs << 17;
     return (unsigned)(rs >> 11);
 }
-static long opened = 0, reads = 0, reads_ok = 0;
+static long opened = 0, reads = 0, reads_ok = 0, directed = 0;
 
 static void exercise(const char *path) {
     jf_h5 *f;
@@ -87,9 +87,36 @@ int main(int argc, char **argv) {
             fclose(fp);
             exercise(tmp);
         }
+        /* directed: every version-2 B-tree header of the file gets a record size smaller than what its record
+         * type's callback reads, and its root pointed at a leaf that ends with the file -- the records' heap IDs would be
+         * read past the buffer; the reader must refuse the tree */
+        for (long o = 0; o + 34 <= n; o++) {
+            if (memcmp(b + o, "BTHD", 4) != 0) continue;
+            for (unsigned rec = 1; rec <= 7; rec += 2) {
+                const unsigned nrec = 3;
+                const long len = n + 6 + (long)(nrec * rec);
+                unsigned char *x = calloc(1, (size_t)len);
+                if (!x) return 3;
+                memcpy(x, b, (size_t)n);
+                memcpy(x + n, "BTLF", 4);
+                x[n + 5] = b[o + 5]; /* the tree's own type */
+                x[o + 10] = (unsigned char)rec, x[o + 11] = 0; /* record size */
+                x[o + 12] = x[o + 13] = 0;                   /* depth 0: the root is a leaf */
+                for (int k8 = 0; k8 < 8; k8++) x[o + 16 + k8] = (unsigned char)((unsigned long long)n >> (8 * k8));
+                x[o + 24] = (unsigned char)nrec, x[o + 25] = 0;
+                fp = fopen(tmp, "wb");
+                if (!fp) return 3;
+                fwrite(x, 1, (size_t)len, fp);
+                fclose(fp);
+                free(x);
+                exercise(tmp);
+                directed++;
+            }
+        }
         free(b);
         free(m);
     }
+    printf("%ld directed B-tree cases; ", directed);
     printf("opened %ld files, %ld of %ld dataset reads succeeded\n", opened, reads_ok, reads);
     return opened > 0 && reads_ok > 0 ? 0 : 1;
 }

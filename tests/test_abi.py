@@ -15,27 +15,72 @@ import oracle_lib
 from conftest import GOLD, ROOT
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "jefferson.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+def _strip_comments(src):
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def _header_functions(name="jefferson.h"):
+    src = _strip_comments(open(os.path.join(ROOT, "include", name)).read())
     return sorted(set(re.findall(r"\b(jf_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(jf):
-    names = _header_functions()
-    assert len(names) >= 35
+    public, debug = _header_functions(), _header_functions("jefferson_debug.h")
+    debug = [n for n in debug if not n.startswith("jf_group_")]   # libjefferson_group.so's test support: its own test below
+    assert len(public) >= 35 and not set(public) & set(debug)
     L = ctypes.CDLL(jf.LIB_PATH)
-    missing = [n for n in names if not hasattr(L, n)]
+    missing = [n for n in public + debug if not hasattr(L, n)]
     assert not missing, missing
-    # and the binding covers the whole header
-    assert sorted(jf.exported_symbols()) == names
+    # and the binding covers both headers
+    assert sorted(jf.exported_symbols()) == sorted(public + debug)
+
+
+def test_public_header_is_the_drop_in_boundary_only():
+    """include/jefferson.h holds what INTEGRATION.md binds and nothing else: no jf_debug_* / jf_profile_*
+    export, no device pointer or stream accessor, nothing read from the environment by the product."""
+    names = _header_functions()
+    assert not [n for n in names if n.startswith(("jf_debug_", "jf_profile_"))]
+    assert not {"jf_engine_stream", "jf_batch_mix_device", "jf_batch_partial_device"} & set(names)
+    dbg = _header_functions("jefferson_debug.h")
+    assert "jf_engine_stream" in dbg and "jf_profile_enable" in dbg and "jf_debug_stage_taps" in dbg
+    csrc = os.path.join(ROOT, "jefferson-2.0_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".c", ".hip", ".h")) and f not in ("jf_ctest.c", "jf_render.c"):
+            for m in re.findall(r'getenv\("(\w+)"\)', open(os.path.join(csrc, f)).read()):
+                assert m == "JF_ALLOW_EXPERIMENT", (f, m)   # the refusal of wrong-result builds, not a tuning knob
+
+
+_CITE = re.compile(r"\b[A-Za-z_]+\.(?:cuh?|cpp|md|vcxproj|sh):\d+")
 
 
 def test_header_cites_reference_interfaces():
+    """EVERY function of the public header stands under a comment that names the reference interface it replaces (file:line,
+    relative to Jefferson/src/): the comment right in front of it -- shared by the declarations that follow it without another
+    comment in between -- or the one on its own line."""
     src = open(os.path.join(ROOT, "include", "jefferson.h")).read()
     for cite in ("Audio.cu:94", "Audio.cu:164-175", "SoundSource.cu:20-36", "SoundSource.cu:41-54",
                  "hrtf_signals.cu:107-153", "GPUSoundSource.cu:463-471", "cudaPart.cu:21-63"):
         assert cite in src, cite
+    # walk the header: comments and the code between them
+    parts = re.split(r"(/\*.*?\*/)", src, flags=re.S)
+    last_block_comment, uncited, seen = "", [], 0
+    for i, part in enumerate(parts):
+        if part.startswith("/*"):
+            before = parts[i - 1] if i else ""
+            own_line = before == "" or before.rstrip(" \t").endswith("\n") or before.strip() == ""
+            if own_line:
+                last_block_comment = part
+            continue
+        trailing = parts[i + 1] if i + 1 < len(parts) and parts[i + 1].startswith("/*") else ""
+        decls = list(re.finditer(r"\b(jf_[a-z0-9_]+)\s*\(", part))
+        for k, m in enumerate(decls):
+            seen += 1
+            # a trailing comment belongs to the last declaration in front of it
+            own = trailing if k == len(decls) - 1 and not part[m.end():].count(";\n") else ""
+            if not (_CITE.search(last_block_comment) or _CITE.search(own)):
+                uncited.append(m.group(1))
+    assert seen >= 35
+    assert not uncited, uncited
 
 
 def test_no_gpu_means_loud_failure(jf, hrir):
@@ -340,7 +385,9 @@ def test_group_library_exports_and_header(jf):
     grp = _group(jf)
     L = ctypes.CDLL(grp.LIB_PATH)
     text = open(grp.HEADER_PATH).read()
-    declared = set(re.findall(r"\b(jf_(?:group_\w+|shard_range))\s*\(", text))
+    text_dbg = open(os.path.join(ROOT, "include", "jefferson_debug.h")).read()   # its test support is declared there
+    declared = set(re.findall(r"\b(jf_(?:group_\w+|shard_range))\s*\(", _strip_comments(text) + _strip_comments(text_dbg)))
+    assert not re.findall(r"\bjf_group_(?:debug_\w+|create_shards_on_device)\s*\(", _strip_comments(text))
     assert declared == set(grp.exported_symbols())
     for name in declared:
         assert hasattr(L, name), name
