@@ -751,6 +751,13 @@ static double to_double(const uint8_t *p, const h5_type *t) {
     return t->is_signed ? (double)(int64_t)u : (double)u;
 }
 
+/* unfilter() and place_chunk() allocate a chunk's nominal size per stored chunk: a damaged chunk shape must not cost
+ * gigabytes either (the bound of the dataset itself, below: deflate gains a factor of a thousand at the very most; chunks of
+ * extendable datasets ARE wider than the dataset's current extent, so the extent is no bound) */
+static int chunk_bound(jf_h5 *f, uint64_t nominal) {
+    return nominal > 1024 * f->size + ((uint64_t)1 << 20) ? fail(f, "HDF5: chunks far larger than their file") : 0;
+}
+
 int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRANK], double **data) {
     *data = NULL;
     h5_msgs *ms = (h5_msgs *)malloc(sizeof(h5_msgs));
@@ -828,11 +835,10 @@ int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRA
                 c.nominal = t.size;
                 for (int d = 0; rc == 0 && d < sp.rank; d++) {
                     c.cdim[d] = rd(pd + 4 * (uint64_t)d, 4);
-                    /* (a chunk of a fixed-size dataset is never wider than the dataset: bounds what a damaged file can make
-                     * unfilter() and place_chunk() allocate per chunk by the dataset's own size, checked above) */
-                    if (c.cdim[d] == 0 || c.cdim[d] > sp.dims[d] || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
+                    if (c.cdim[d] == 0 || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
                     else c.nominal *= c.cdim[d];
                 }
+                if (rc == 0) rc = chunk_bound(f, c.nominal);
                 if (rc == 0) {
                     const uint64_t bt = rd_off(f, pa);
                     if (bt != UNDEF) rc = chunk_btree(&c, bt, 0);
@@ -845,12 +851,13 @@ int jf_h5_read_f64(jf_h5 *f, uint64_t addr, int *rank, uint64_t dims[JF_H5_MAXRA
                 c.nominal = t.size;
                 for (int d = 0; rc == 0 && d < sp.rank; d++) {
                     c.cdim[d] = rd(p + 5 + (uint64_t)eb * d, eb);
-                    if (c.cdim[d] == 0 || c.cdim[d] > sp.dims[d] || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
+                    if (c.cdim[d] == 0 || c.nominal > MAX_FILE_BYTES / c.cdim[d]) rc = fail(f, "HDF5: odd chunk dimensions");
                     else {
                         c.nominal *= c.cdim[d];
                         n_chunks *= (sp.dims[d] + c.cdim[d] - 1) / c.cdim[d];
                     }
                 }
+                if (rc == 0) rc = chunk_bound(f, c.nominal);
                 if (rc == 0) {
                     const uint8_t *q = p + 5 + (uint64_t)eb * nd;
                     uint64_t left = sz - (5 + (uint64_t)eb * nd);
