@@ -276,96 +276,74 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 256 warm-up steps (80 ms) because the first ~100 steps after an idle GPU run 10-15 % slower
-    # (clock ramp; profiles/r01_experiments.md), then 1024 timed steps = 131 072 blocks x 1024 sources (0.29 s)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
-    ap.add_argument("--move-every", type=int, default=1,
-                    help="the sources' azimuth advances every n-th block (default 1 = configs[2]'s moving sources; 172 = the "
-                         "dwell of the reference's benchmarkTesting): variants, not the default bench line")
-    ap.add_argument("--reverb", action="store_true",
-                    help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
-                         "(partitioned FDL convolution ahead of the spatialiser); not the default bench line")
-    ap.add_argument("--realtime", action="store_true",
-                    help="with --reverb: one block per call (the audio callback's shape), where the delay line "
-                         "is read from HBM: roofline of the per-block multiply-accumulate kernel")
-    ap.add_argument("--rv-sources", type=int, default=256,
-                    help="with --reverb: sources (512 puts the real-time form's 362 MB delay line past the 256 MB "
-                         "Infinity Cache: the HBM-bound measurement)")
-    ap.add_argument("--rv-ir-seconds", type=float, default=2.0,
-                    help="with --reverb: length of the impulse response (4.0 = media/s1_r1_b_441_mono.wav's: 1379 partitions)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes")
-    ap.add_argument("--event-stride", type=int, default=8,
-                    help="HIP events around every n-th fused launch of the timed region (1: around every one)")
-    ap.add_argument("--cpu-sample-blocks", type=int, default=256)
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+def reverb_response(n_ir):
+    """exponentially decaying noise, seed 99 (2.0 s = 88 200 taps for configs[4]), unit energy"""
+    rng = np.random.default_rng(99)
+    ir = rng.standard_normal(n_ir) * np.exp(-6.9 * np.arange(n_ir) / float(n_ir))
+    return (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
 
-    world_env = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and world_env is None:
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(world_env or "1")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # started by a launcher (WORLD_SIZE set): the ranks form a process group and the mix goes through the reduce even
-    # when the group has one rank -- the N > 1 code path on a one-GPU box (tests/test_gpu_engine.py)
-    use_dist = world_env is not None
 
-    # --reverb: the counters of the stage's product kernel -- batch calls: the big partitions' (or, with uniform partitions,
-    # the tiled kernel); one-block calls: the head's kernel, which runs every block
-    rv_pmc_kernels = ("reverb_mac_kernel",) if args.realtime else ("reverb_big_mac_kernel", "reverb_mac_tiled_kernel")
-    pmc, pmc_note = None, ("not collected: the counter passes run only at N = 1 (a profiled child per rank would "
-                           "share the GPUs with the measurement)" if world > 1 else "not collected (--no-pmc / --pmc-child)")
-    if world == 1 and not args.pmc_child and not args.no_pmc:
-        extra = ((["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
-                 + (["--move-every", str(args.move_every)] if args.move_every != 1 else [])
-                 + (["--realtime"] if args.realtime else [])
-                 + (["--rv-sources", str(args.rv_sources), "--rv-ir-seconds", str(args.rv_ir_seconds)] if args.reverb else []))
-        pmc, pmc_note = collect_pmc(extra, rv_pmc_kernels if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
+def leg_pmc_kernels(args):
+    """--reverb: the counters of the stage's product kernel -- batch calls: the big partitions' (or, with uniform partitions,
+    the tiled kernel); one-block calls: the head's kernel, which runs every block"""
+    return ("reverb_mac_kernel",) if args.realtime else ("reverb_big_mac_kernel", "reverb_mac_tiled_kernel")
 
-    backend = os.environ.get("JF_DIST_BACKEND", "nccl")
-    torch = dist = None
-    if not args.pmc_child:
-        import torch
-        import torch.distributed as dist
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-        # JF_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the multi-rank path
-        # on a 1-GPU box (RCCL refuses duplicate devices); the measured configuration is always nccl.
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if use_dist:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from jf_load import jf
-    # The rank's host thread on the NUMA node its GPU hangs off (include/jefferson.h: jf_pin_thread_to_device; what
-    # `numactl --cpunodebind` does for a launcher that does not): launches, the poll of the per-block legs and the pinned
-    # buffers stay on one socket.  JF_NO_PIN=1 leaves the thread where the system put it; the line says which.
-    host_info = {"numa_node_of_gpu": None, "thread_pinned_to_it": False}
-    try:
-        host_info["numa_node_of_gpu"] = jf.device_numa_node(local_rank)
-        if not os.environ.get("JF_NO_PIN"):
-            host_info["thread_pinned_to_it"] = bool(jf.pin_thread_to_device(local_rank))
-    except jf.JfError:
-        pass
-    wl = load_workload()
-    gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
-    hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
+def precollect_pmc(args, world):
+    """The counter passes of one configuration (collect_pmc), or (None, why not)."""
+    if world > 1:
+        return None, ("not collected: the counter passes run only at N = 1 (a profiled child per rank would share the GPUs with "
+                      "the measurement)")
+    if args.pmc_child or args.no_pmc:
+        return None, "not collected (--no-pmc / --pmc-child)"
+    extra = ((["--stationary"] if args.stationary else []) + (["--reverb"] if args.reverb else [])
+             + (["--move-every", str(args.move_every)] if args.move_every != 1 else [])
+             + (["--realtime"] if args.realtime else [])
+             + (["--rv-sources", str(args.rv_sources), "--rv-ir-seconds", str(args.rv_ir_seconds)] if args.reverb else []))
+    return collect_pmc(extra, leg_pmc_kernels(args) if args.reverb else ("fused_pair_kernel", "fused_block_kernel"))
 
+
+def also_configurations(args):
+    """{name: args of the leg}: what the default line reports beside its headline -- every figure of
+    BASELINE.json's other single-GPU configurations in the one record a machine the builder never touched produces."""
+    import copy
+    rv = copy.copy(args)
+    rv.reverb, rv.steps, rv.warmup = True, max(32, args.steps), max(8, args.warmup)
+    st = copy.copy(args)
+    st.stationary, st.steps = True, max(20, args.steps)
+    rv.also_leg = st.also_leg = True
+    return {"reverb": rv, "reverb_realtime_us": None, "stationary": st}
+
+
+def brief(out, keep_roofline):
+    """A leg's full line cut down to what the "also" record carries."""
+    if out is None:
+        return None
+    b = {k: out.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "prewarm_steps", "ms_per_step", "real_time_factor",
+                                 "verified", "step_split_ms")}
+    b["config"] = {k: out["config"].get(k) for k in ("workload", "sources_per_gpu", "block", "blocks_per_step", "source_group",
+                                                     "kernels", "interp_table")}
+    r = out.get("roofline") or {}
+    b["roofline"] = {k: r.get(k) for k in keep_roofline if k in r}
+    if out.get("cpu_baseline"):
+        b["cpu_baseline"] = {k: out["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "gpu_over_cpu")}
+    if out.get("verification"):
+        b["verification"] = {k: out["verification"].get(k) for k in ("max_abs_err_mix", "mix_peak", "bound_mix", "max_abs_err_group_blocks",
+                                                                     "bound_group_blocks", "against")}
+    return b
+
+
+def run_leg(args, ctx, pmc, pmc_note):
+    """One configuration from engine creation to its result line (a dict on rank 0, None elsewhere): warm-up, the timed region
+    bracketed by barriers and synchronisation, the roofline of its dominant kernel, the CPU baseline and the check of the last
+    timed step against the oracle.  main() runs the headline configuration through it and then -- same process, fresh engines
+    -- the secondary ones whose figures go under the line's "also" key."""
+    torch, dist, jf, wl, hrir = ctx["torch"], ctx["dist"], ctx["jf"], ctx["wl"], ctx["hrir"]
+    rank, local_rank, world, use_dist, backend, host_info = (ctx[k] for k in ("rank", "local_rank", "world", "use_dist", "backend", "host_info"))
+    rv_pmc_kernels = leg_pmc_kernels(args)
+    out = None
     global B
+    B = 256
     S = SOURCES_PER_GPU
     K, W, KB = args.steps, args.warmup, BLOCKS_PER_STEP
     if args.pmc_child:
@@ -373,10 +351,7 @@ def main():
     ir = None
     if args.reverb:
         B, S, KB = 128, args.rv_sources, (1 if args.realtime else REVERB_BLOCKS_PER_STEP)
-        n_ir = int(round(args.rv_ir_seconds * 44100))
-        rng = np.random.default_rng(99)  # exponentially decaying noise, seed 99, 2.0 s
-        ir = rng.standard_normal(n_ir) * np.exp(-6.9 * np.arange(n_ir) / float(n_ir))
-        ir = (ir / np.sqrt((ir ** 2).sum())).astype(np.float32)
+        ir = reverb_response(int(round(args.rv_ir_seconds * 44100)))
     src_lo = rank * S  # weak scaling: every rank brings its own 1024 sources
     src_ids = np.arange(src_lo, src_lo + S)
 
@@ -413,7 +388,7 @@ def main():
             eng.batch_run((i * KB) % n_pos, KB)
         eng.synchronize()
         eng.close()
-        return
+        return None
 
     # The mix lands in a torch tensor so that RCCL can reduce it in place.  Two buffers: the
     # (latency-bound, K * 2 KB) reduce of step i runs on RCCL's stream while the engine's stream
@@ -785,7 +760,7 @@ def main():
             out["step_split_ms"] = {"reverb_stage": t * 1e3, "spatialiser_fused_kernel": prof["fused_ms"] / timed,
                                     "whole_step": dt / K * 1e3}
             out["metric"] = "source-frames/s (sources x frames/sec) at 128-sample blocks, reverb + spatialiser"
-        if world == 1 and ir is None:
+        if world == 1 and ir is None and not getattr(args, "also_leg", False):
             try:
                 out["single_source_block_latency_us"] = single_source_latency_us(jf, hrir)
             except Exception as ex:
@@ -818,9 +793,131 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = value / base["value"]
             out["verified"] = ok
             out["verification"] = check
-        print(json.dumps(out), flush=True)
 
     eng.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    # defaults: 256 warm-up steps (80 ms) because the first ~100 steps after an idle GPU run 10-15 % slower
+    # (clock ramp; profiles/r01_experiments.md), then 1024 timed steps = 131 072 blocks x 1024 sources (0.29 s)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--stationary", action="store_true", help="sources do not move (no crossfade)")
+    ap.add_argument("--move-every", type=int, default=1,
+                    help="the sources' azimuth advances every n-th block (default 1 = configs[2]'s moving sources; 172 = the "
+                         "dwell of the reference's benchmarkTesting): variants, not the default bench line")
+    ap.add_argument("--reverb", action="store_true",
+                    help="BASELINE.json configs[4]: 256 sources, 128-sample blocks, 2 s convolution-reverb IR "
+                         "(partitioned FDL convolution ahead of the spatialiser); not the default bench line")
+    ap.add_argument("--realtime", action="store_true",
+                    help="with --reverb: one block per call (the audio callback's shape), where the delay line "
+                         "is read from HBM: roofline of the per-block multiply-accumulate kernel")
+    ap.add_argument("--rv-sources", type=int, default=256,
+                    help="with --reverb: sources (512 puts the real-time form's 362 MB delay line past the 256 MB "
+                         "Infinity Cache: the HBM-bound measurement)")
+    ap.add_argument("--rv-ir-seconds", type=float, default=2.0,
+                    help="with --reverb: length of the impulse response (4.0 = media/s1_r1_b_441_mono.wav's: 1379 partitions)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="the default line without its \"also\" record (config 5 in batch form and in real time, the stationary variant)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="HIP events around every n-th fused launch of the timed region (1: around every one)")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=256)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # started by a launcher (WORLD_SIZE set): the ranks form a process group and the mix goes through the reduce even
+    # when the group has one rank -- the N > 1 code path on a one-GPU box (tests/test_gpu_engine.py)
+    use_dist = world_env is not None
+
+    # The secondary configurations of the default line ("also"): config 5 in batch form and in real time, and the stationary
+    # variant of the headline -- run after the headline's timed region and verification, in this process, on fresh engines.
+    default_line = not (args.reverb or args.stationary or args.realtime or args.move_every != 1 or args.pmc_child
+                        or os.environ.get("JF_BENCH_NARROW") is not None)
+    also_legs = also_configurations(args) if (default_line and world == 1 and not args.no_also) else {}
+    # every leg's hardware counters FIRST: the profiled children must have come and gone before this process touches the GPU
+    pmc, pmc_note = precollect_pmc(args, world)
+    also_pmc = {name: precollect_pmc(a, world) for name, a in also_legs.items() if name != "reverb_realtime_us"}
+
+    backend = os.environ.get("JF_DIST_BACKEND", "nccl")
+    torch = dist = None
+    if not args.pmc_child:
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        # JF_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the multi-rank path
+        # on a 1-GPU box (RCCL refuses duplicate devices); the measured configuration is always nccl.
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+
+    from jf_load import jf
+    # The rank's host thread on the NUMA node its GPU hangs off (include/jefferson.h: jf_pin_thread_to_device; what
+    # `numactl --cpunodebind` does for a launcher that does not): launches, the poll of the per-block legs and the pinned
+    # buffers stay on one socket.  JF_NO_PIN=1 leaves the thread where the system put it; the line says which.
+    host_info = {"numa_node_of_gpu": None, "thread_pinned_to_it": False}
+    try:
+        host_info["numa_node_of_gpu"] = jf.device_numa_node(local_rank)
+        if not os.environ.get("JF_NO_PIN"):
+            host_info["thread_pinned_to_it"] = bool(jf.pin_thread_to_device(local_rank))
+    except jf.JfError:
+        pass
+    wl = load_workload()
+    gold = os.path.join(ROOT, "tests", "golden", "kemar_hrir_710x2x128_i16.npy")
+    hrir = np.load(gold).astype(np.float32) / np.float32(32768.0)
+
+    ctx = {"torch": torch, "dist": dist, "jf": jf, "wl": wl, "hrir": hrir, "rank": rank, "local_rank": local_rank, "world": world,
+           "use_dist": use_dist, "backend": backend, "host_info": host_info}
+    t_head = time.perf_counter()
+    out = run_leg(args, ctx, pmc, pmc_note)
+    if args.pmc_child:
+        return
+    if rank == 0 and out is not None:
+        if also_legs:
+            also = {"what": "the other single-GPU configurations, run after the headline's timed region and verification in the same "
+                            "process on fresh engines; the headline's value / config / roofline above are untouched by them",
+                    "headline_leg_s": time.perf_counter() - t_head}
+            for name, a in also_legs.items():
+                t_leg = time.perf_counter()
+                try:
+                    if name == "reverb_realtime_us":
+                        rv = also_legs["reverb"]
+                        n_ir = int(round(rv.rv_ir_seconds * 44100))
+                        also[name] = realtime_reverb_call_us(jf, hrir, rv.rv_sources, 128, reverb_response(n_ir), RV_GAIN)
+                    else:
+                        full = run_leg(a, ctx, *also_pmc[name])
+                        also[name] = brief(full, ("kernel", "bound", "avg_stage_ms", "algorithmic_bytes_per_step", "achieved", "peak",
+                                                  "unit", "frac", "traffic", "traffic_is", "frac_of_achievable_6300", "level")
+                                           if name == "reverb" else ("kernel", "bound", "avg_launch_ms", "achieved", "peak", "unit", "frac", "frac_pmc", "hbm"))
+                except Exception as ex:   # a secondary leg must not cost the headline its line
+                    also[name] = {"error": f"{type(ex).__name__}: {ex}"}
+                if isinstance(also[name], dict):
+                    also[name]["leg_s"] = time.perf_counter() - t_leg
+            out["also"] = also
+        elif default_line and world > 1:
+            out["also"] = None
+            out["also_null_because"] = "the secondary configurations are single-GPU ones: reported by the N = 1 line"
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -829,6 +829,17 @@ def test_whole_bench_under_the_launcher_with_one_rank():
     n_cpu = len(os.sched_getaffinity(0))
     assert out["cpu_baseline"]["cores"] > 1 or n_cpu == 1
     assert out["roofline"]["frac"] > 0.05 and out["value"] > 1e10
+    # the secondary configurations of the default line (round 6): config 5 in batch form with its HBM roofline, verified against
+    # the oracle's reverb stage; config 5 one block per call; the stationary variant -- each on a fresh engine behind the headline
+    also = out["also"]
+    rv = also["reverb"]
+    assert rv["verified"] is True and rv["steps"] >= 32 and rv["config"]["blocks_per_step"] == 256, rv
+    assert rv["roofline"]["bound"] == "hbm" and 0.2 < rv["roofline"]["frac"] < 1.0 and rv["roofline"]["avg_stage_ms"] > 0
+    assert rv["roofline"]["algorithmic_bytes_per_step"] > 4e8 and "reverb_big_mac_kernel" in rv["roofline"]["kernel"]
+    assert rv["value"] > 5e9 and rv["cpu_baseline"]["value"] > 0
+    assert also["reverb_realtime_us"]["calls"] == 1600 and 5 < also["reverb_realtime_us"]["median"] < 200
+    st = also["stationary"]
+    assert st["verified"] is True and st["value"] > out["value"] and st["config"]["interp_table"]["rows_read_by_the_timed_runs"] == 1
 
 
 def test_a_live_engine_survives_bad_arguments_and_keeps_working(hrir):
