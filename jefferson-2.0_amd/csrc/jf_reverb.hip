@@ -525,88 +525,129 @@ JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwidd
 
 constexpr int kBigThreads = 256;
 
+// Scalar loads of per-source records (SrcSignal, play positions, SrcState): through a generic pointer they are VECTOR loads with
+// a wait in front of everything that depends on them (the kernel's own stores might alias); none of these arrays is written by
+// the kernel that reads it (the counts and states are ping-pong pairs), so they go through the constant address space.
+#define JF_RV_CONST __attribute__((address_space(4)))
+template <class T>
+JF_DEV const T JF_RV_CONST *rv_const(const T *p) {
+    return (const T JF_RV_CONST *)p;
+}
+
+// The 2 B1 samples of transform i of source s as the first pass's input -- x[t] = z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8
+// -- REQUESTED, not waited for: the persistent transform kernel asks for the next turn's samples before it works on this one's
+// (round 6).  What lies before the call's first sample comes from the dry ring (written by earlier calls), the rest from the
+// looped signal itself at the play position -- a batch call need not copy its own input anywhere.
+template <int B1>
+JF_DEV void big_fft_fetch(const ReverbBigParams &P, int i, int s, int tid, float2 (&x)[8]) {
+    const float *ring = P.dryring + (size_t)s * P.Rn * B1;
+    const int Rd = P.Rn * B1;
+    const SrcSignal JF_RV_CONST *sgc = rv_const(P.dry + s);
+    const float *sptr = sgc->ptr;
+    const int L = sgc->length, dc0 = *rv_const(P.dry_count_in + s);
+    const int rel0 = P.tr_rel_first + i * B1;
+    // signal index of the first sample at or behind the call's start (one division per item, none per sample: the
+    // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
+    const int first_in = rel0 < 0 ? 0 : rel0;
+    const unsigned start = ((unsigned)dc0 + (unsigned)first_in) % (unsigned)L;
+    // Where the 2 B1 samples lie is the same for the whole workgroup.  The two usual cases -- all of them one stretch of the
+    // looped signal (transforms inside a batch call), all of them one stretch of the dry ring (the side stream's, and a
+    // call's first transform) -- are eight 8-byte loads at a scalar base + 8 tid + 2 KB r: no per-sample index arithmetic.
+    const float *stretch = nullptr;
+    if (rel0 >= 0 && start + 2u * (unsigned)B1 <= (unsigned)L) {
+        stretch = (const float *)__builtin_assume_aligned(sptr, 4) + start;
+    } else if (rel0 + 2 * B1 <= 0) {
+        int pos = P.dry_pos0 + rel0;
+        pos = pos < 0 ? pos + Rd : pos;
+        if (pos >= 0 && pos + 2 * B1 <= Rd) stretch = ring + pos;
+    }
+    const int m0 = tid < B1 / 8 ? tid : 0;
+    if (stretch != nullptr) {
+        const float JF_RV_GLOBAL *gs = (const float JF_RV_GLOBAL *)stretch;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const c2 pr = *reinterpret_cast<const c2 JF_RV_GLOBAL *>(gs + 2 * (m0 + r * (B1 / 8)));
+            x[r] = make_float2(pr.x, pr.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int m = m0 + r * (B1 / 8);
+            const int rel = rel0 + 2 * m;  // even; the ring / signal boundary (rel = 0) never splits a pair
+            if (rel < 0) {
+                int pos = P.dry_pos0 + rel;
+                pos = pos < 0 ? pos + Rd : pos;
+                x[r] = *reinterpret_cast<const float2 *>(ring + pos);
+            } else {
+                unsigned i0 = start + (unsigned)(rel - first_in);
+#pragma unroll
+                for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
+                const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
+                x[r] = make_float2(sptr[i0], sptr[i1]);
+            }
+        }
+    }
+}
+
+#ifndef JF_RV_BIG_FFT_AHEAD
+#define JF_RV_BIG_FFT_AHEAD 1  // the next turn's samples requested before this turn's passes (0: round 5's order)
+#endif
+
 // X_m of transform i of the launch (m = first + i) for source s: spectrum of the 2 B1 dry samples of big blocks m - 2, m - 1
-// into fdl1 (packed: bin 0 = (X[0], X[B1])).  NTR transforms per workgroup (items g = NTR blockIdx + t of the n_tr S).
-template <int B1, int NTR>
+// into fdl1 (packed: bin 0 = (X[0], X[B1])).  One transform per workgroup and turn; item g = i S + s (a source's transforms one
+// after the other -- memory order, which the inverse gains 11 % from -- cost THIS kernel 15 %: 33.3 against 28.9 us, round 5).
+// PERSISTENT (round 5): a workgroup takes the turns w = blockIdx.x, blockIdx.x + gridDim.x, ... -- the twiddles are loaded once
+// per workgroup instead of once per transform (they were as many bytes through the vector L1 as the samples).
+// SOFTWARE-PIPELINED (round 6): the kernel was a chain of waits -- the source's record (a vector load through a generic
+// pointer), then its samples, then four passes, then the stores -- in which the vector unit was half idle and so was the
+// memory system (profiles/r06/reverb_transforms.md).  Now the record is a scalar load and turn w + gridDim.x's samples are
+// requested before turn w's passes begin: sixteen registers per thread hold them while the passes run: 29.0 -> 26.2-26.8 us per
+// launch at config 5's batch shape (one box, A B A B; JF_RV_BIG_FFT_AHEAD = 0 is the order of round 5: 28.7).
+template <int B1>
 __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_buf[NTR][rv_big_len(B1)];
+    __shared__ float2 s_buf[1][rv_big_len(B1)];
     const int tid0 = threadIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
     __shared__ float2 s_w8[BigTwiddles<B1, kBigThreads>::kW8Len];
     BigTwiddles<B1, kBigThreads>::stage_w8(P.tw1, s_w8, tid0);  // (the first pass ends with a barrier: staged before anybody reads)
     tw.load(P.tw1, tid0);
     const int n_items = P.n_tr * P.S;
-    const int n_turns = (n_items + NTR - 1) / NTR;
-#if JF_RV_BIG_SPLIT_TW_EARLY
     // the split's twiddles (they depend on the thread only): once per workgroup, no global load behind the last pass
     float2 wsplit[B1 / kBigThreads];
 #pragma unroll
     for (int u = 0; u < B1 / kBigThreads; u++) wsplit[u] = P.tw1[tid0 + u * kBigThreads];
+    // (i, s) of a turn, stepped without a division per turn
+    const int step_i = (int)gridDim.x / P.S, step_s = (int)gridDim.x - step_i * P.S;
+    int ni = (int)blockIdx.x / P.S, ns = (int)blockIdx.x - ni * P.S;
+    float2 vn[8];
+#if JF_RV_BIG_FFT_AHEAD
+    if ((int)blockIdx.x < n_items) big_fft_fetch<B1>(P, ni, ns, tid0, vn);
 #endif
-    // PERSISTENT (round 5): a workgroup takes the turns w = blockIdx.x, blockIdx.x + gridDim.x, ... -- the twiddles are loaded
-    // once per workgroup instead of once per transform (they were as many bytes through the vector L1 as the samples), and the
-    // workgroups of a compute unit, each in another phase of load / passes / store, keep memory and vector unit busy together
 #pragma unroll 1
-    for (int turn = blockIdx.x; turn < n_turns; turn += gridDim.x) {
-    // (opaque per turn: the compiler otherwise hoists every LDS address of the four passes out of the loop: ~60 registers)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    float2 v[NTR][8];  // z[m] = x[2m] + j x[2m + 1], m = tid + r B1 / 8: the first pass's input
-#pragma unroll
-    for (int t = 0; t < NTR; t++) {
-        const int g = min(turn * NTR + t, n_items - 1);  // (an odd last item is done twice)
-        const int i = g / P.S, s = g - i * P.S;  // (a source's transforms one after the other -- memory order, which the inverse gains 11 % from -- cost THIS kernel 15 %: 33.3 against 28.9 us)
-        // The 2 B1 samples: what lies before the call's first sample comes from the dry ring (written by earlier calls), the
-        // rest from the looped signal itself at the play position -- a batch call need not copy its own input anywhere.
-        const float *ring = P.dryring + (size_t)s * P.Rn * B1;
-        const int Rd = P.Rn * B1;
-        const SrcSignal sg = P.dry[s];
-        const int L = sg.length, dc0 = P.dry_count_in[s];
-        const int rel0 = P.tr_rel_first + i * B1;
-        // signal index of the first sample at or behind the call's start (one division per item, none per sample: the
-        // signal is at least 1024 long, so 2 B1 samples wrap at most four times)
-        const int first_in = rel0 < 0 ? 0 : rel0;
-        const unsigned start = ((unsigned)dc0 + (unsigned)first_in) % (unsigned)L;
-        // Where the 2 B1 samples lie is the same for the whole workgroup.  The two usual cases -- all of them one stretch of the
-        // looped signal (transforms inside a batch call), all of them one stretch of the dry ring (the side stream's, and a
-        // call's first transform) -- are eight 8-byte loads at base + 2 m: no per-sample index arithmetic (it was a fifth of
-        // the kernel's vector instructions, and its 4-byte flat loads twice the load instructions).
-        const float *stretch = nullptr;
-        if (rel0 >= 0 && start + 2u * (unsigned)B1 <= (unsigned)L) {
-            stretch = (const float *)__builtin_assume_aligned(sg.ptr, 4) + start;
-        } else if (rel0 + 2 * B1 <= 0) {
-            int pos = P.dry_pos0 + rel0;
-            pos = pos < 0 ? pos + Rd : pos;
-            if (pos >= 0 && pos + 2 * B1 <= Rd) stretch = ring + pos;
+    for (int turn = blockIdx.x; turn < n_items; turn += gridDim.x) {
+        // (opaque per turn: the compiler otherwise hoists every LDS address of the four passes out of the loop: ~60 registers)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int i = ni, s = ns;
+        ns += step_s;
+        ni += step_i;
+        if (ns >= P.S) {
+            ns -= P.S;
+            ni++;
         }
-        if (stretch != nullptr) {
-            const float JF_RV_GLOBAL *gs = (const float JF_RV_GLOBAL *)stretch;
+        float2 v[1][8];
+#if JF_RV_BIG_FFT_AHEAD
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-                const c2 pr = *reinterpret_cast<const c2 JF_RV_GLOBAL *>(gs + 2 * m);
-                v[t][r] = make_float2(pr.x, pr.y);
-            }
-        } else
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int m = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-            const int rel = rel0 + 2 * m;  // even; the ring / signal boundary (rel = 0) never splits a pair
-            if (rel < 0) {
-                int pos = P.dry_pos0 + rel;
-                pos = pos < 0 ? pos + Rd : pos;
-                v[t][r] = *reinterpret_cast<const float2 *>(ring + pos);
-            } else {
-                unsigned i0 = start + (unsigned)(rel - first_in);
-#pragma unroll
-                for (int w = 0; w < 4; w++) i0 = i0 >= (unsigned)L ? i0 - (unsigned)L : i0;
-                const unsigned i1 = i0 + 1 == (unsigned)L ? 0u : i0 + 1;
-                v[t][r] = make_float2(sg.ptr[i0], sg.ptr[i1]);
-            }
-        }
+        for (int r = 0; r < 8; r++) v[0][r] = vn[r];
+        if (turn + (int)gridDim.x < n_items) big_fft_fetch<B1>(P, ni, ns, tid, vn);
+#else
+        big_fft_fetch<B1>(P, i, s, tid, v[0]);
+#endif
         // a call that puts its small transforms off: its last two big blocks of samples -- this source's last transform has them
         // in registers -- into the dry ring, its last block as `prev`, the play position behind it (ReverbBigParams::state_out)
-        if (P.state_out && i == P.n_tr - 1 && turn * NTR + t < n_items && tid < B1 / 8) {
+        if (P.state_out && i == P.n_tr - 1 && tid < B1 / 8) {
+            const int Rd = P.Rn * B1;
+            const int rel0 = P.tr_rel_first + i * B1;
             float *ring_out = P.dryring_out + (size_t)s * Rd;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -614,43 +655,39 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
                 if (rel >= 0) {  // (what lies before the call is in the ring already)
                     int pos = P.dry_pos0 + rel;   // < 2 Rd: the ring is longer than a call
                     pos = pos >= Rd ? pos - Rd : pos;
-                    *reinterpret_cast<float2 *>(ring_out + pos) = v[t][r];
-                    if (rel >= P.call_samples - P.B) *reinterpret_cast<float2 *>(P.prev_out + (size_t)s * P.B + (rel - (P.call_samples - P.B))) = v[t][r];
+                    *reinterpret_cast<float2 *>(ring_out + pos) = v[0][r];
+                    if (rel >= P.call_samples - P.B) *reinterpret_cast<float2 *>(P.prev_out + (size_t)s * P.B + (rel - (P.call_samples - P.B))) = v[0][r];
                 }
             }
-            if (tid == 0) P.dry_count_out[s] = (int)(((unsigned)dc0 + (unsigned)P.call_samples) % (unsigned)L);
-        }
-    }
-    cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, s_w8, tid);
-#pragma unroll
-    for (int t = 0; t < NTR; t++) {
-        const int g = turn * NTR + t;
-        if (g >= n_items) break;
-        const int i = g / P.S, s = g - i * P.S;
-        const float2 *Z = s_buf[t];
-        const int slot = (P.tr_slot_first + i) % P.R1;
-        float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
-#pragma unroll
-        for (int u = 0; u < B1 / kBigThreads; u++) {
-            const int q = tid + u * kBigThreads;
-            const float2 zk = Z[rv_big_at(q)];
-            const float2 zm = Z[rv_big_at((B1 - q) & (B1 - 1))];
-            const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-            const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-#if JF_RV_BIG_SPLIT_TW_EARLY
-            const float2 wo = rv_mulc(o, wsplit[u]);
-#else
-            const float2 wo = rv_mulc(o, P.tw1[q]);
-#endif
-            float2 x = make_float2(e.x + wo.y, e.y - wo.x);
-            if (q == 0) {
-                x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
-                P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
+            if (tid == 0) {
+                const unsigned L = (unsigned)rv_const(P.dry + s)->length, dc0 = (unsigned)*rv_const(P.dry_count_in + s);
+                P.dry_count_out[s] = (int)((dc0 + (unsigned)P.call_samples) % L);
             }
-            out[q] = x;
         }
-    }
-    __syncthreads();  // the buffers are read out before the next turn's first pass writes them
+        cfft_wg<B1, -1, kBigThreads>(v, s_buf, tw, s_w8, tid);
+        {
+            const float2 *Z = s_buf[0];
+            const int slot = (P.tr_slot_first + i) % P.R1;
+            float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
+            // Z[q] at rd0 + 288 u, Z[B1 - q] at the mirror thread's places counted down (rv_big_at(i) = i + (i >> 3); thread 0's
+            // partner for u = 0 is itself)
+#pragma unroll
+            for (int u = 0; u < B1 / kBigThreads; u++) {
+                const int q = tid + u * kBigThreads;
+                const float2 zk = Z[rv_big_at(q)];
+                const float2 zm = Z[rv_big_at((B1 - q) & (B1 - 1))];
+                const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+                const float2 wo = rv_mulc(o, wsplit[u]);
+                float2 x = make_float2(e.x + wo.y, e.y - wo.x);
+                if (q == 0) {
+                    x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
+                    P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
+                }
+                out[q] = x;
+            }
+        }
+        __syncthreads();  // the buffer is read out before the next turn's first pass writes it
     }
 }
 
@@ -973,120 +1010,154 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac1_kernel(cons
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) big_mac_single_shared<B1>(P, item, s_h, h_slice);
 }
 
-#ifndef JF_RV_BIG_IFFT_WQ_REGS
-#define JF_RV_BIG_IFFT_WQ_REGS 0
+// What a turn of the inverse kernel needs from memory, requested together and used in straight-line code: the product's
+// spectrum Y[q], q = tid + r B1 / 8, and Y[B1 - q] (the second set of loads hits the lines the first one fetches); wave 0: the
+// compact bin-0 pairs X0[anchor + i - q] of up to 128 partitions (more are fetched when they are used); the source's wet-ring
+// position (a scalar load).
+template <int B1>
+struct BigIfftInput {
+    float2 yk[8], ym[8];
+    float2 x0[2];  // wave 0: lane's partitions q = lane, lane + 64
+    int c0;        // SrcState::count of the source (to_wet)
+    JF_DEV void fetch(const ReverbBigParams &P, int g, int tid) {
+        const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
+        const c2 JF_RV_GLOBAL *y = (const c2 JF_RV_GLOBAL *)(P.ybig + (size_t)g * B1);
+        auto ld = [](const c2 JF_RV_GLOBAL *p) {
+            const c2 t = *p;
+            return make_float2(t.x, t.y);
+        };
+        const int q0 = tid < B1 / 8 ? tid : 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#if JF_RV_BIG_NT_Y
+            const c2 t = __builtin_nontemporal_load(y + q0 + r * (B1 / 8));
+            yk[r] = make_float2(t.x, t.y);
+#else
+            yk[r] = ld(y + q0 + r * (B1 / 8));
 #endif
-#ifndef JF_RV_BIG_IFFT_WAVES
-#define JF_RV_BIG_IFFT_WAVES 0
-#endif
-// Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.  NTR products
-// per workgroup and turn (items g = NTR w + t of the n_prod S, w = blockIdx.x, blockIdx.x + gridDim.x, ...).
-// PERSISTENT with the next turn's input in flight (round 5): a workgroup that loads, transforms and stores one after the other
-// leaves the memory system idle while it computes and the vector unit idle while it loads, and three or four such workgroups
-// per compute unit that start together stay in step (round 4: 39 us per launch for 100 MB, 2.6 TB/s, vector pipe a third
-// busy, LDS conflicts or not).  Here the spectra of turn w + gridDim.x are requested BEFORE turn w's passes and untangled
-// into the first pass's registers when that turn begins: raw[t][r] = (Y[q], Y[B1 - q]), q = tid + r B1 / 8.
-template <int B1, int NTR>
-__global__ __launch_bounds__(kBigThreads, JF_RV_BIG_IFFT_WAVES) void reverb_big_ifft_kernel(const ReverbBigParams P) {
-    __shared__ float2 s_buf[NTR][rv_big_len(B1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) ym[r] = ld(y + ((B1 - (q0 + r * (B1 / 8))) & (B1 - 1)));
+        if (tid < 64) {
+            const c2 JF_RV_GLOBAL *xc = (const c2 JF_RV_GLOBAL *)(P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int q = tid + 64 * c;
+                int slot = (P.anchor_slot_first + i - q) % P.R1;
+                if (slot < 0) slot += P.R1;
+                x0[c] = q < P.n_part ? ld(xc + slot) : make_float2(0.f, 0.f);
+            }
+        }
+        c0 = P.to_wet ? rv_const(P.st_in + s)->count : 0;
+    }
+};
+
+// Product i of source s -> B1 time samples: TAIL(m) into the fut ring, or FULL(m) straight into the wet ring.  One product per
+// workgroup and turn (items g = s n_prod + i of the n_prod S in MEMORY order, turns w = blockIdx.x, blockIdx.x + gridDim.x, ...).
+// Round 5 made the kernel persistent (twiddles once per workgroup).  ROUND 6: a turn was still a chain of waits -- the bin-0
+// pairs (two dependent loads and a six-step reduce in front of everything), then EIGHT branches (q == 0 ?) each with its own
+// three loads and its own wait, then the passes, then a vector load of the source's state in front of the stores.  Now a
+// turn's whole input is requested at once (BigIfftInput: the spectrum twice, the bin-0 pairs, the wet-ring position as a
+// scalar load), the untangling twiddles W^q and the response's bin-0 pairs live in registers, and the untangling is
+// straight-line code (bin 0 by a select): 26.5 -> 24.3 us per launch at config 5's batch shape (one box, A B A B).  Measured and
+// NOT kept (profiles/r06/reverb_transforms.md, profiles/r06_transform_experiments.patch): the next turn's input requested a turn
+// ahead (126 registers, four workgroups per compute unit: 27.7 us), Y[B1 - q] from the mirror thread through LDS (28.2), W^q
+// fetched per turn (27.3), the register count forced down to six workgroups per compute unit (spills: 25.8).
+template <int B1>
+__global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
+    __shared__ float2 s_buf[1][rv_big_len(B1)];
     const int tid0 = threadIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
     __shared__ float2 s_w8[BigTwiddles<B1, kBigThreads>::kW8Len];
     BigTwiddles<B1, kBigThreads>::stage_w8(P.tw1, s_w8, tid0);  // (the first pass ends with a barrier: staged before anybody reads)
     tw.load(P.tw1, tid0);
     const int n_items = P.n_prod * P.S;
-    const int n_turns = (n_items + NTR - 1) / NTR;
-#if JF_RV_BIG_IFFT_WQ_REGS
-    // the untangling twiddles W^q of this thread's bins: the same for every item
-    float2 wq[8];
+    static_assert(B1 / 8 == kBigThreads || B1 / 8 == kBigThreads / 2, "q = tid + r B1 / 8 of the threads tid < B1 / 8");
+    // the untangling twiddles W^q of this thread's bins and the response's bin-0 pairs of wave 0's partitions: the same for
+    // every item
+    float2 wq[8], h0[2];
 #pragma unroll
     for (int r = 0; r < 8; r++) wq[r] = P.tw1[(tid0 < B1 / 8 ? tid0 : 0) + r * (B1 / 8)];
-#endif
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int q = (tid0 & 63) + 64 * c;
+        h0[c] = q < P.n_part ? P.hspec1[(size_t)P.NP * B1 + P.h_first + q] : make_float2(0.f, 0.f);
+    }
 #pragma unroll 1
-    for (int turn = blockIdx.x; turn < n_turns; turn += gridDim.x) {
+    for (int turn = blockIdx.x; turn < n_items; turn += gridDim.x) {
         // (opaque per turn: the compiler otherwise hoists every LDS and global address of the four passes out of the loop and
         // keeps them in ~60 registers)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        float2 v[NTR][8];
+        const int g = turn;
+        const int s = g / P.n_prod, i = g - s * P.n_prod;
+        BigIfftInput<B1> in;
+        in.fetch(P, g, tid);
+        // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
+        // over the partitions (thread 0, which owns bin 0 below, is one of them)
+        float2 y0 = make_float2(0.f, 0.f);
+        if (tid < 64) {
 #pragma unroll
-        for (int t = 0; t < NTR; t++) {
-            const int g = min(turn * NTR + t, n_items - 1);  // (an odd last item is done twice)
-            const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
-            const float2 *y = P.ybig + ((size_t)s * P.n_prod + i) * B1;
-            // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
-            // over the partitions (thread 0, which owns bin 0 below, is one of them)
-            float2 y0 = make_float2(0.f, 0.f);
-            if (tid < 64) {
-                const float2 *x0 = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
-                const float2 *h0 = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
-                for (int q = tid; q < P.n_part; q += 64) {
+            for (int c = 0; c < 2; c++) {
+                y0.x += in.x0[c].x * h0[c].x;
+                y0.y += in.x0[c].y * h0[c].y;
+            }
+            if (P.n_part > 128) {  // (responses beyond 128 big partitions: 6 s at B1 = 2048)
+                const float2 *xc = P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1;
+                const float2 *hc = P.hspec1 + (size_t)P.NP * B1 + P.h_first;
+                for (int q = tid + 128; q < P.n_part; q += 64) {
                     int slot = (P.anchor_slot_first + i - q) % P.R1;
                     if (slot < 0) slot += P.R1;
-                    const float2 x = x0[slot], h = h0[q];
+                    const float2 x = xc[slot], h = hc[q];
                     y0.x += x.x * h.x;
                     y0.y += x.y * h.y;
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    y0.x += __shfl_xor(y0.x, m);
-                    y0.y += __shfl_xor(y0.y, m);
-                }
             }
-            // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2, straight from global
-            // memory into the first pass's registers: q = tid + r B1 / 8
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int q = (tid < B1 / 8 ? tid : 0) + r * (B1 / 8);
-#if JF_RV_BIG_NT_Y
-                const c2 yk_ = __builtin_nontemporal_load(reinterpret_cast<const c2 *>(y + q));
-                const c2 ym_ = __builtin_nontemporal_load(reinterpret_cast<const c2 *>(y + ((B1 - q) & (B1 - 1))));
-                const float2 yk = make_float2(yk_.x, yk_.y), ym = make_float2(ym_.x, ym_.y);
-#else
-                const float2 yk = y[q];
-                const float2 ym = y[(B1 - q) & (B1 - 1)];
-#endif
-                if (q == 0) {
-                    v[t][r] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
-                } else {
-                    const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-                    const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-#if JF_RV_BIG_IFFT_WQ_REGS
-                    const float2 o = rv_mul(d, wq[r]);
-#else
-                    const float2 o = rv_mul(d, P.tw1[q]);
-#endif
-                    v[t][r] = make_float2(e.x - o.y, e.y + o.x);
-                }
+            for (int m = 32; m >= 1; m >>= 1) {
+                y0.x += __shfl_xor(y0.x, m);
+                y0.y += __shfl_xor(y0.y, m);
             }
         }
-        cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, s_w8, tid);
+        // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2: the first pass's registers
+        float2 v[1][8];
 #pragma unroll
-        for (int t = 0; t < NTR; t++) {
-            const int g = turn * NTR + t;
-            if (g >= n_items) break;
-            const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
-            const float2 *zt = s_buf[t];
+        for (int r = 0; r < 8; r++) {
+            const float2 yk = in.yk[r], ym = in.ym[r];
+            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+            const float2 o = rv_mul(d, wq[r]);
+            v[0][r] = make_float2(e.x - o.y, e.y + o.x);
+        }
+        if (tid == 0) v[0][0] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
+        cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, s_w8, tid);
+        {
+            const float2 *zt = s_buf[0];
             // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
             if (!P.to_wet) {
                 float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
-                for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_big_at(m)];
+#pragma unroll
+                for (int u = 0; u < B1 / 2 / kBigThreads; u++) {
+                    const int m = B1 / 2 + tid + u * kBigThreads;
+                    *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_big_at(m)];
+                }
             } else {
                 // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
-                const int c0 = P.st_in[s].count;
                 float *wet = P.wet + (size_t)s * P.Wr;
                 const int lgB = 31 - __builtin_clz((unsigned)P.B);  // B is 64, 128 or 256
-                for (int m = B1 / 2 + tid; m < B1; m += kBigThreads) {
+#pragma unroll
+                for (int u = 0; u < B1 / 2 / kBigThreads; u++) {
+                    const int m = B1 / 2 + tid + u * kBigThreads;
                     const int n = 2 * m - B1;                   // sample inside the big block
                     const int kb = n >> lgB;                     // n / B (once per pair)
                     const int k = P.wet_k0 + P.M * i + kb;       // block of the call
-                    int w0 = c0 + k * P.B;                       // c0 < Wr and k B < Wr: one conditional subtraction
+                    int w0 = in.c0 + k * P.B;                    // c0 < Wr and k B < Wr: one conditional subtraction
                     w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
                     *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_big_at(m)];
                 }
             }
         }
-        __syncthreads();  // the buffers are read out before the next turn's first pass writes them
+        __syncthreads();  // the buffer is read out before the next turn writes it
     }
 }
 
@@ -1283,23 +1354,12 @@ static int big_resident_wgs(K kernel) {
     return prop.multiProcessorCount * per_cu;
 }
 
-// two transforms per workgroup (shared twiddles and barriers) once there are enough of them to fill the GPU
-#ifndef JF_RV_BIG_NTR_FFT
-#define JF_RV_BIG_NTR_FFT 1
-#endif
-#ifndef JF_RV_BIG_NTR_IFFT
-#define JF_RV_BIG_NTR_IFFT 1
-#endif
 template <int B1>
 static void launch_big_transforms_t(const ReverbBigParams &P, hipStream_t st) {
     const int n = P.n_tr * P.S;
-    if (n >= 1024 && JF_RV_BIG_NTR_FFT == 2) {
-        static const int resident = big_resident_wgs(reverb_big_fft_kernel<B1, 2>);
-        hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 2>), dim3(std::min((n + 1) / 2, resident)), dim3(kBigThreads), 0, st, P);
-    } else {
-        static const int resident = big_resident_wgs(reverb_big_fft_kernel<B1, 1>);
-        hipLaunchKernelGGL((reverb_big_fft_kernel<B1, 1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
-    }
+    // persistent grid: what the device holds at once (the surplus of a larger grid would only queue)
+    static const int resident = big_resident_wgs(reverb_big_fft_kernel<B1>);
+    hipLaunchKernelGGL((reverb_big_fft_kernel<B1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
 }
 // products of one launch (tiles of 16 when there are several, else one by one) and their inverse transforms
 template <int B1>
@@ -1328,14 +1388,9 @@ static void launch_big_products_t(const ReverbBigParams &P, hipStream_t st) {
         }
     }
     const int n = P.n_prod * P.S;
-    // persistent grids: what the device holds at once (the surplus of a larger grid would only queue)
-    if (n >= 1024 && JF_RV_BIG_NTR_IFFT == 2) {
-        static const int resident = big_resident_wgs(reverb_big_ifft_kernel<B1, 2>);
-        hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 2>), dim3(std::min((n + 1) / 2, resident)), dim3(kBigThreads), 0, st, P);
-    } else {
-        static const int resident = big_resident_wgs(reverb_big_ifft_kernel<B1, 1>);
-        hipLaunchKernelGGL((reverb_big_ifft_kernel<B1, 1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
-    }
+    // persistent grid: what the device holds at once (the surplus of a larger grid would only queue)
+    static const int resident = big_resident_wgs(reverb_big_ifft_kernel<B1>);
+    hipLaunchKernelGGL((reverb_big_ifft_kernel<B1>), dim3(std::min(n, resident)), dim3(kBigThreads), 0, st, P);
 }
 static void launch_big_transforms(const ReverbBigParams &P, hipStream_t st) {
     switch (P.B1) {
