@@ -613,9 +613,15 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
     tw.load(P.tw1, tid0);
     const int n_items = P.n_tr * P.S;
     // the split's twiddles (they depend on the thread only): once per workgroup, no global load behind the last pass
+#ifndef JF_RV_BIG_WIDE_STORE
+#define JF_RV_BIG_WIDE_STORE 1  // the transforms' results as 16-byte stores (two adjacent values per lane); 0: 8-byte stores
+#endif
+    // bin q of the thread's u-th store: WIDE: q = 2 tid + (B1 / 4) u' + e with u = 2 u' + e (two adjacent bins, one 16-byte store);
+    // else q = tid + 256 u
+    auto split_bin = [](int tid, int u) { return JF_RV_BIG_WIDE_STORE ? 2 * tid + (u >> 1) * (2 * kBigThreads) + (u & 1) : tid + u * kBigThreads; };
     float2 wsplit[B1 / kBigThreads];
 #pragma unroll
-    for (int u = 0; u < B1 / kBigThreads; u++) wsplit[u] = P.tw1[tid0 + u * kBigThreads];
+    for (int u = 0; u < B1 / kBigThreads; u++) wsplit[u] = P.tw1[split_bin(tid0, u)];
     // (i, s) of a turn, stepped without a division per turn
     const int step_i = (int)gridDim.x / P.S, step_s = (int)gridDim.x - step_i * P.S;
     int ni = (int)blockIdx.x / P.S, ns = (int)blockIdx.x - ni * P.S;
@@ -671,9 +677,10 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
             float2 *out = P.fdl1 + ((size_t)s * P.R1 + slot) * B1;
             // Z[q] at rd0 + 288 u, Z[B1 - q] at the mirror thread's places counted down (rv_big_at(i) = i + (i >> 3); thread 0's
             // partner for u = 0 is itself)
+            float2 xo[B1 / kBigThreads];
 #pragma unroll
             for (int u = 0; u < B1 / kBigThreads; u++) {
-                const int q = tid + u * kBigThreads;
+                const int q = split_bin(tid, u);
                 const float2 zk = Z[rv_big_at(q)];
                 const float2 zm = Z[rv_big_at((B1 - q) & (B1 - 1))];
                 const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
@@ -684,8 +691,16 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_fft_kernel(const Rever
                     x = make_float2(zk.x + zk.y, zk.x - zk.y);  // (X[0], X[B1]), both real
                     P.fdl1[(size_t)P.S * P.R1 * B1 + (size_t)s * P.R1 + slot] = x;  // compact copy of the packed pair
                 }
-                out[q] = x;
+                xo[u] = x;
             }
+#if JF_RV_BIG_WIDE_STORE
+#pragma unroll
+            for (int u = 0; u < B1 / kBigThreads; u += 2)
+                *reinterpret_cast<float4 *>(out + split_bin(tid, u)) = make_float4(xo[u].x, xo[u].y, xo[u + 1].x, xo[u + 1].y);
+#else
+#pragma unroll
+            for (int u = 0; u < B1 / kBigThreads; u++) out[split_bin(tid, u)] = xo[u];
+#endif
         }
         __syncthreads();  // the buffer is read out before the next turn's first pass writes it
     }
@@ -1136,15 +1151,37 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
             // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
             if (!P.to_wet) {
                 float *fut = P.fut + (size_t)s * P.Fn * B1 + (size_t)((P.fut_first + i) % P.Fn) * B1;
+#if JF_RV_BIG_WIDE_STORE
+#pragma unroll
+                for (int u = 0; u < B1 / 4 / kBigThreads; u++) {  // z[m], z[m + 1]: four consecutive samples, one 16-byte store
+                    const int m = B1 / 2 + 2 * tid + u * (2 * kBigThreads);
+                    const float2 a = zt[rv_big_at(m)], b = zt[rv_big_at(m + 1)];
+                    *reinterpret_cast<float4 *>(fut + (2 * m - B1)) = make_float4(a.x, a.y, b.x, b.y);
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < B1 / 2 / kBigThreads; u++) {
                     const int m = B1 / 2 + tid + u * kBigThreads;
                     *reinterpret_cast<float2 *>(fut + (2 * m - B1)) = zt[rv_big_at(m)];
                 }
+#endif
             } else {
                 // the wet ring is a multiple of B long and is addressed block by block (mac_finish): a big block may wrap inside
                 float *wet = P.wet + (size_t)s * P.Wr;
                 const int lgB = 31 - __builtin_clz((unsigned)P.B);  // B is 64, 128 or 256
+#if JF_RV_BIG_WIDE_STORE
+#pragma unroll
+                for (int u = 0; u < B1 / 4 / kBigThreads; u++) {  // four consecutive samples (never across a block: B >= 64)
+                    const int m = B1 / 2 + 2 * tid + u * (2 * kBigThreads);
+                    const int n = 2 * m - B1;                   // sample inside the big block (a multiple of 4)
+                    const int kb = n >> lgB;                     // n / B
+                    const int k = P.wet_k0 + P.M * i + kb;       // block of the call
+                    int w0 = in.c0 + k * P.B;                    // c0 < Wr and k B < Wr: one conditional subtraction
+                    w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
+                    const float2 a = zt[rv_big_at(m)], b = zt[rv_big_at(m + 1)];
+                    *reinterpret_cast<float4 *>(wet + w0 + (n - kb * P.B)) = make_float4(a.x, a.y, b.x, b.y);
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < B1 / 2 / kBigThreads; u++) {
                     const int m = B1 / 2 + tid + u * kBigThreads;
@@ -1155,6 +1192,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
                     w0 = w0 >= P.Wr ? w0 - P.Wr : w0;
                     *reinterpret_cast<float2 *>(wet + w0 + (n - kb * P.B)) = zt[rv_big_at(m)];
                 }
+#endif
             }
         }
         __syncthreads();  // the buffer is read out before the next turn writes it
