@@ -235,8 +235,12 @@ struct jf_engine {
     bool last_catchup = false;   // the last call began with the catch-up (jf_debug_last_kernels)
     bool last_small_fft = true;  // ... and launched the small transforms' kernel
     int rv_lazy_small = 1;       // jf_debug_set_reverb_lazy_state
-    int rv_side_wgs = 256;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
-                                 // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md)
+    int rv_side_wgs = 192;       // workgroups of its product kernel (it runs beside later blocks' kernels: launched narrow;
+                                 // 64 / 128 / 256 / all measure 34.5 / 34.1 / 34.1 / 35.0 us per block: profiles/r04/rt_async.md).
+                                 // Set to THREE QUARTERS of the device's compute units at creation (round 6): with one
+                                 // workgroup on every compute unit the block's own kernels find none to themselves; 192 of 256
+                                 // measure mean 23.8-24.0 / p99 32.3-33.4 us per block against 24.4 / 35.2-35.9 with 256, 160
+                                 // and fewer stretch the product over more blocks (profiles/r06/reverb_realtime.md)
 };
 
 namespace {
@@ -911,6 +915,13 @@ int create_engine(const jf_config *cfg, const RingTable *grid, const float *hrir
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_main, hipEventDisableTiming));
         JF_HIP(e, hipEventCreateWithFlags(&e->rv_ev_side, hipEventDisableTiming));
         for (int kind = 0; kind < 3; kind++) JF_HIP(e, fused_resident_workgroups(B / 64, kind, &e->resident_wgs[kind]));
+        {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus >= 16)
+                e->rv_side_wgs = 3 * cus / 4;
+            else
+                (void)hipGetLastError();
+        }
         // (nothing of the engine's behaviour is read from the environment: jefferson_debug.h's setters are the overrides)
         e->interp_avail = !(cfg->flags & JF_FLAG_NO_INTERP_TABLE);
         e->interp_use = e->interp_avail ? 2 : 0;

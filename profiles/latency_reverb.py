@@ -1,5 +1,8 @@
 """Real-time (one block per call) cost of configs[4]: 256 sources, B = 128, 2 s IR, reverb + spatialiser, per block of the
-16-block cycle of the non-uniformly partitioned stage (and, with JF_RV_UNIFORM=1, of uniform partitioning: round 3's form)."""
+16-block cycle of the non-uniformly partitioned stage (and, with JF_RV_UNIFORM=1, of uniform partitioning: round 3's form).
+JF_RV_CALLS=n: n timed calls (default 1600; a multiple of 16).  JF_RV_PACED_US=2902: the calls at the audio callback's own
+cadence -- one per block period, the thread spinning in between -- instead of back to back (round 6): what a PortAudio host sees;
+the side stream's work of a big-block boundary then has the whole period to itself."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +25,8 @@ for uniform in ((False,) if os.environ.get("JF_RV_ONLY_NONUNIFORM") else (False,
         e.set_reverb_ahead(0)
     if os.environ.get("JF_RV_HEAD_OWN"):      # round 4's form: the head as a kernel of its own in front of the real-time kernel
         e.set_reverb_head_fused(0)
+    if os.environ.get("JF_RV_SIDE_WGS"):      # workgroups of the side stream's product kernel (jefferson_debug.h)
+        e.set_reverb_side_workgroups(int(os.environ["JF_RV_SIDE_WGS"]))
     e.set_reverb(ir, 0.5)
     out = np.zeros(2 * B, np.float32)
     fp = out.ctypes.data_as(jf._f)
@@ -29,7 +34,14 @@ for uniform in ((False,) if os.environ.get("JF_RV_ONLY_NONUNIFORM") else (False,
     for k in range(64):
         L.jf_process_block(e.h, fp)
     ts = []
-    for k in range(64, 64 + 1600):
+    n_calls = int(os.environ.get("JF_RV_CALLS", "1600")) // 16 * 16
+    paced = float(os.environ.get("JF_RV_PACED_US", "0")) * 1e-6
+    t_next = time.perf_counter()
+    for k in range(64, 64 + n_calls):
+        if paced:
+            t_next += paced
+            while time.perf_counter() < t_next:
+                pass
         if k % 7 == 0:      # sources move now and then, as they would
             for s in range(0, S, 5):
                 e.set_spherical(s, -40 + (s * 7) % 121, (s * 37 + k) % 360, 1.0)
@@ -38,7 +50,7 @@ for uniform in ((False,) if os.environ.get("JF_RV_ONLY_NONUNIFORM") else (False,
     n, head, big, taps = e.reverb_partitions()
     print(f"configs[4] real-time, {S} sources, B = 128, {n} partitions of 128 as {head} x 128" + (f" + {big} x {taps}" if big else "")
           + f": jf_process_block mean {ts.mean():.1f} us, median {np.median(ts):.1f}, p99 {np.percentile(ts, 99):.1f}, max {ts.max():.1f}"
-          f" (block period 2902 us)")
+          f" ({len(ts)} calls " + (f"at one per {paced * 1e6:.0f} us" if paced else "back to back") + "; block period 2902 us)")
     if big:
         cyc = ts.reshape(-1, 16)      # block j of the cycle: j = 15 forms X_m behind its head, j = 0 forms TAIL(m) in front of it
         print("   by place in the 16-block cycle (median us):", " ".join(f"{v:.0f}" for v in np.median(cyc, axis=0)))
