@@ -24,7 +24,7 @@ timeout -k 10 300 python3 profiles/render_config1.py > $OUT/render_config1.txt 2
 timeout -k 10 120 python3 profiles/latency.py > $OUT/latency.txt 2>> $OUT/bench.err; echo "latency rc=$?"
 timeout -k 10 120 python3 profiles/latency_reverb.py > $OUT/latency_reverb.txt 2>> $OUT/bench.err; echo "latency reverb rc=$?"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 64 --warmup 200 --no-cpu-baseline --no-pmc > $OUT/trace.log 2>&1; echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 64 --warmup 200 --no-cpu-baseline --no-pmc --no-also > $OUT/trace.log 2>&1; echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reverb -- python3 $REPO/bench.py --reverb --steps 64 --warmup 128 --no-pmc > $OUT/trace_reverb.log 2>&1; echo "trace reverb rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reverb_rt -- python3 $REPO/bench.py --reverb --realtime --steps 500 --warmup 300 --no-pmc > $OUT/trace_reverb_rt.log 2>&1; echo "trace reverb rt rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reverb_rt512 -- python3 $REPO/bench.py --reverb --realtime --rv-sources 512 --steps 500 --warmup 300 --no-pmc > $OUT/trace_reverb_rt512.log 2>&1; echo "trace reverb rt 512 rc=$?"
