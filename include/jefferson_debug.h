@@ -110,7 +110,7 @@ int jf_debug_set_reverb_partitioning(jf_engine *e, int how);
 /* One-block calls with the non-uniformly partitioned reverb (the real-time shape) run the big partitions' kernels on a second
  * stream, off the block's critical path: when a block completes a big block, the spectrum of that big block, the products of
  * the big block after the next and their inverse transform are launched there behind the block's spatialiser, sixteen blocks
- * before their result is first read (jf_engine.cpp: run_reverb_stage).
+ * before their result is first read (jf_engine_reverb.cpp: run_reverb_stage).
  * on = 0: everything in line on the engine's stream, as batch calls, calls with a pinned form and profiled calls do anyway
  * (the last block of a big block then costs ~9 us more than the others at configs[4], the first ~40 us).  Default 1.  Same
  * kernels, same order of every sum: bit-identical results. */
@@ -178,8 +178,9 @@ int jf_debug_interp_device(jf_engine *e, int n, const float *ele, const float *a
 /* Forward real FFT of n windows of PAD_LEN samples with the kernel's LDS FFT
  * (unnormalised, Nc complex bins each). */
 int jf_debug_rfft_device(jf_engine *e, int n, const float *windows, float *spectra);
-/* Workgroups of the product kernel on the reverb's side stream (jf_engine.cpp: submit_side; default 256: 8 of a compute
- * unit's 32 wave slots at most, so that the kernels of the blocks it runs beside find room at once).  8 .. 65536; tuning runs
+/* Workgroups of the product kernel on the reverb's side stream (jf_engine_reverb.cpp: submit_side; default: three quarters of the
+ * device's compute units, one workgroup of 8 waves each, so that the kernels of the blocks it runs beside keep a quarter of them to
+ * themselves: profiles/r06/reverb_realtime.md).  8 .. 65536; tuning runs
  * only (profiles/rt_ab.sh; was the environment variable JF_RV_SIDE_WGS until round 6). */
 int jf_debug_set_reverb_side_workgroups(jf_engine *e, int workgroups);
 

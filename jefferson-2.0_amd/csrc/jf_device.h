@@ -214,7 +214,7 @@ struct ReverbParams {
 // B1 samples the partitions behind the head contribute to big block m (Gardner's zero-latency scheme with two sizes): per block
 // (P1 - 1) / 16 + 32 multiply-accumulates per bin instead of P = 16 (P1 + 1).  TAIL(m) needs nothing newer than X_{m-1}, which
 // exists a whole big block before big block m begins: that slack is what lets one-block calls form it on a second stream
-// (jf_engine.cpp: run_reverb_stage).  A big block that lies
+// (jf_engine_reverb.cpp: run_reverb_stage).  A big block that lies
 // INSIDE a batch call needs no head at all:  FULL(m) = sum_{q <= P1} X_{m+1-q} H'_q  is its whole wet signal (uniform
 // partitioning at the big size; its input is all there), one transform pair per 16 blocks instead of 16 pairs.
 // blocks per big block: B1 = rv_big_blocks(B) * B is 1024 or 2048 taps (a transform of 2 B1 points by one workgroup in LDS)

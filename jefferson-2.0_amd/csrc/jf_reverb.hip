@@ -329,7 +329,7 @@ struct BigTwiddles {
     // The values are entries of the circle T2, but a wave that fetches them there gathers 64 cache lines per load (strides of
     // 8 r .. 64 r entries between neighbouring lanes) -- 17 to 21 such loads per thread were a third of a transform kernel's
     // time.  The engine lays the same values out per pass and r, neighbouring lanes side by side, BEHIND the circle
-    // (big_twiddle_pack_*, jf_engine.cpp): a load touches 1 to 8 lines.  Same bits, same results: forward 41.4 -> 35.2 us,
+    // (big_twiddle_pack_*, jf_engine_reverb.cpp): a load touches 1 to 8 lines.  Same bits, same results: forward 41.4 -> 35.2 us,
     // inverse 43.5 -> 38.7 us per launch at config 5's batch shape (rocprofv3, 320 launches, twice).
     JF_DEV void load(const float2 *__restrict__ T2, int tid) {
         const float2 *__restrict__ pk = T2 + 2 * NPT;
@@ -998,7 +998,7 @@ JF_DEV void big_mac_single_shared(const ReverbBigParams &P, int item, rv_v2 (*s_
 
 // One workgroup per item (64 bins per wave of one tile of one source) -- or, for single products on the side stream
 // (mac_wgs > 0), that many workgroups taking the items in turn: a launch that does not fill the GPU's wave slots, so that the
-// kernels of the blocks it runs beside find room at once (jf_engine.cpp: run_reverb_stage).
+// kernels of the blocks it runs beside find room at once (jf_engine_reverb.cpp: run_reverb_stage).
 template <int B1, int KB>
 __global__ __launch_bounds__(64 * (KB == 1 ? kBigMacWaves : kBigMacWavesTiled)) void reverb_big_mac_kernel(const ReverbBigParams P) {
     if constexpr (KB == 1) {
@@ -1445,7 +1445,7 @@ static void launch_big_products(const ReverbBigParams &P, hipStream_t st) {
     }
 }
 
-// The big partitions' work of one-block calls on the engine's side stream (jf_engine.cpp: run_reverb_stage): X_m of the big
+// The big partitions' work of one-block calls on the engine's side stream (jf_engine_reverb.cpp: run_reverb_stage): X_m of the big
 // block just completed, then the products of a TAIL with their inverse transform.
 hipError_t launch_reverb_big_side(const ReverbBigParams *transforms, const ReverbBigParams *products, hipStream_t st) {
     if (transforms && transforms->n_tr > 0) launch_big_transforms(*transforms, st);

@@ -564,7 +564,7 @@ def test_nonuniform_state_changes_midstream(jf, hrir, castanets):
 
 
 def test_one_block_calls_with_the_big_partitions_on_the_side_stream(jf, hrir, castanets):
-    """One-block calls put the big partitions' kernels on a second stream (jf_engine.cpp: run_reverb_stage): when a block
+    """One-block calls put the big partitions' kernels on a second stream (jf_engine_reverb.cpp: run_reverb_stage): when a block
     completes a big block, its spectrum and the TAIL of the big block after the next, a whole big block early.  Against the
     same calls with everything in line (jf_debug_set_reverb_async 0: the same kernels and sums, bit for bit) and against the
     float64 model; then a run in which batch calls of ragged sizes, a reset, a new signal and a change of the switch itself

@@ -9,7 +9,7 @@ no GPU): runs of calls of random sizes are replayed against a MODEL of the engin
 * X_m is formed exactly once, from 2 M blocks of input that are in the dry ring (earlier calls) or in the running call;
 * a product reads spectra X_{m-q} that exist (or lie before the start) and whose ring slots still hold THEM;
 * a block reads TAIL of ITS big block from the fut ring (four places): the collision this test was written after;
-* one-block calls may hand X_m and TAIL(m + 1) to a side stream when they complete big block m - 1 (jf_engine.cpp:
+* one-block calls may hand X_m and TAIL(m + 1) to a side stream when they complete big block m - 1 (jf_engine_reverb.cpp:
   run_reverb_stage): replayed as "formed at once" -- the engine's stream waits for that stream before the next call that is
   not such a one-block call and before the next hand-over, so nothing of it is read earlier than that.
 """
