@@ -1029,13 +1029,22 @@ __global__ __launch_bounds__(64 * kBigMacWaves) void reverb_big_mac1_kernel(cons
 // spectrum Y[q], q = tid + r B1 / 8, and Y[B1 - q] (the second set of loads hits the lines the first one fetches); wave 0: the
 // compact bin-0 pairs X0[anchor + i - q] of up to 128 partitions (more are fetched when they are used); the source's wet-ring
 // position (a scalar load).
+// The spectrum requested and untangled four values at a time (1): the second half's loads go into the registers the first half
+// has freed -- 75 registers instead of 92, SIX workgroups per compute unit instead of five, one more memory round trip per
+// turn: 24.5-24.7 -> 23.7-23.8 us per launch at config 5's batch shape (one box, A B A B; profiles/r06/reverb_transforms.md)
+#ifndef JF_RV_BIG_IFFT_HALVES
+#define JF_RV_BIG_IFFT_HALVES 1
+#endif
+#ifndef JF_RV_BIG_IFFT_WGS
+#define JF_RV_BIG_IFFT_WGS 6
+#endif
 template <int B1>
 struct BigIfftInput {
     float2 yk[8], ym[8];
     float2 x0[2];  // wave 0: lane's partitions q = lane, lane + 64
     int c0;        // SrcState::count of the source (to_wet)
-    JF_DEV void fetch(const ReverbBigParams &P, int g, int tid) {
-        const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
+    // the spectrum's values r0 .. r1 - 1 of the eight (JF_RV_BIG_IFFT_HALVES: requested and untangled four at a time)
+    JF_DEV void fetch_y(const ReverbBigParams &P, int g, int tid, int r0, int r1) {
         const c2 JF_RV_GLOBAL *y = (const c2 JF_RV_GLOBAL *)(P.ybig + (size_t)g * B1);
         auto ld = [](const c2 JF_RV_GLOBAL *p) {
             const c2 t = *p;
@@ -1044,6 +1053,7 @@ struct BigIfftInput {
         const int q0 = tid < B1 / 8 ? tid : 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+            if (r < r0 || r >= r1) continue;
 #if JF_RV_BIG_NT_Y
             const c2 t = __builtin_nontemporal_load(y + q0 + r * (B1 / 8));
             yk[r] = make_float2(t.x, t.y);
@@ -1052,7 +1062,16 @@ struct BigIfftInput {
 #endif
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) ym[r] = ld(y + ((B1 - (q0 + r * (B1 / 8))) & (B1 - 1)));
+        for (int r = 0; r < 8; r++)
+            if (r >= r0 && r < r1) ym[r] = ld(y + ((B1 - (q0 + r * (B1 / 8))) & (B1 - 1)));
+    }
+    JF_DEV void fetch(const ReverbBigParams &P, int g, int tid, int r1 = 8) {
+        const int s = g / P.n_prod, i = g - s * P.n_prod;  // items in memory order: a source's products one after the other
+        auto ld = [](const c2 JF_RV_GLOBAL *p) {
+            const c2 t = *p;
+            return make_float2(t.x, t.y);
+        };
+        fetch_y(P, g, tid, 0, r1);
         if (tid < 64) {
             const c2 JF_RV_GLOBAL *xc = (const c2 JF_RV_GLOBAL *)(P.fdl1 + (size_t)P.S * P.R1 * B1 + (size_t)s * P.R1);
 #pragma unroll
@@ -1079,7 +1098,7 @@ struct BigIfftInput {
 // ahead (126 registers, four workgroups per compute unit: 27.7 us), Y[B1 - q] from the mirror thread through LDS (28.2), W^q
 // fetched per turn (27.3), the register count forced down to six workgroups per compute unit (spills: 25.8).
 template <int B1>
-__global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const ReverbBigParams P) {
+__global__ __launch_bounds__(kBigThreads, JF_RV_BIG_IFFT_HALVES ? JF_RV_BIG_IFFT_WGS : 0) void reverb_big_ifft_kernel(const ReverbBigParams P) {
     __shared__ float2 s_buf[1][rv_big_len(B1)];
     const int tid0 = threadIdx.x;
     BigTwiddles<B1, kBigThreads> tw;
@@ -1107,7 +1126,7 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
         const int g = turn;
         const int s = g / P.n_prod, i = g - s * P.n_prod;
         BigIfftInput<B1> in;
-        in.fetch(P, g, tid);
+        in.fetch(P, g, tid, JF_RV_BIG_IFFT_HALVES ? 4 : 8);
         // the true packed pair of bin 0: sum_q X0[anchor + i - q] .* H0[h_first + q] from the compact copies, wave 0's lanes
         // over the partitions (thread 0, which owns bin 0 below, is one of them)
         float2 y0 = make_float2(0.f, 0.f);
@@ -1136,14 +1155,25 @@ __global__ __launch_bounds__(kBigThreads) void reverb_big_ifft_kernel(const Reve
         }
         // Z[q] = E + j O with E = (Y[q] + conj Y[B1-q]) / 2, O = conj(W^q) (Y[q] - conj Y[B1-q]) / 2: the first pass's registers
         float2 v[1][8];
+        auto untangle = [&](int r0, int r1) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float2 yk = in.yk[r], ym = in.ym[r];
-            const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
-            const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
-            const float2 o = rv_mul(d, wq[r]);
-            v[0][r] = make_float2(e.x - o.y, e.y + o.x);
-        }
+            for (int r = 0; r < 8; r++) {
+                if (r < r0 || r >= r1) continue;
+                const float2 yk = in.yk[r], ym = in.ym[r];
+                const float2 e = make_float2(0.5f * (yk.x + ym.x), 0.5f * (yk.y - ym.y));
+                const float2 d = make_float2(0.5f * (yk.x - ym.x), 0.5f * (yk.y + ym.y));
+                const float2 o = rv_mul(d, wq[r]);
+                v[0][r] = make_float2(e.x - o.y, e.y + o.x);
+            }
+        };
+#if JF_RV_BIG_IFFT_HALVES
+        untangle(0, 4);
+        __builtin_amdgcn_sched_barrier(0);  // (the second half's loads go into the registers the first half has freed)
+        in.fetch_y(P, g, tid, 4, 8);
+        untangle(4, 8);
+#else
+        untangle(0, 8);
+#endif
         if (tid == 0) v[0][0] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
         cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, s_w8, tid);
         {
