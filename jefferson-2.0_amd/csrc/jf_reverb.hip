@@ -867,9 +867,17 @@ JF_DEV void big_mac_item_shared(const ReverbBigParams &P, int item) {
     rv_v2 acc[KB], xr[KB];
 #pragma unroll
     for (int i = 0; i < KB; i++) acc[i] = rv_v2{0.f, 0.f};
-#pragma unroll
-    for (int i = 1; i < KB; i++) xr[i] = i0 + i < P.n_prod ? load_x(fdl0 + (size_t)slot_of(i) * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
+    // (one division for the tile's first slot, the others by stepping round the ring: the fifteen modulo sequences of the
+    // window's slots were ~500 scalar instructions in front of every tile's first load)
     int xslot = slot_of(0);
+    {
+        int sl = xslot;
+#pragma unroll
+        for (int i = 1; i < KB; i++) {
+            sl = sl + 1 == P.R1 ? 0 : sl + 1;
+            xr[i] = i0 + i < P.n_prod ? load_x(fdl0 + (size_t)(unsigned)sl * ((size_t)B1 * 8)) : rv_v2{0.f, 0.f};
+        }
+    }
     constexpr int D = JF_RV_BIG_PREFETCH < KB ? JF_RV_BIG_PREFETCH : KB;
     static_assert(KB % D == 0, "the queue index of a step is a constant after unrolling");
     rv_v2 xq[D];
