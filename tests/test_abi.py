@@ -372,6 +372,37 @@ def test_bench_starts_its_own_ranks():
     assert "needs a GPU" in err          # printed by the ranks, i.e. they were started
 
 
+def test_bench_also_legs_and_their_briefs():
+    """bench.py's secondary legs (round 6: config 5 in batch form and in real time, the stationary variant, under "also" of the
+    default line): configured from the headline's arguments without touching them; the record keeps what the brief names."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("jf_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = argparse.Namespace(steps=20, warmup=5, reverb=False, stationary=False, realtime=False, move_every=1, rv_sources=256,
+                           rv_ir_seconds=2.0, pmc_child=False, no_pmc=False)
+    legs = b.also_configurations(a)
+    assert list(legs) == ["reverb", "reverb_realtime_us", "stationary"]
+    assert legs["reverb"].reverb and legs["reverb"].steps >= 32 and legs["reverb"].warmup >= 8 and legs["reverb"].also_leg
+    assert legs["stationary"].stationary and legs["stationary"].steps >= 20 and not legs["stationary"].reverb
+    assert not a.reverb and not a.stationary and a.steps == 20 and not hasattr(a, "also_leg")   # the headline's own arguments
+    assert b.leg_pmc_kernels(legs["reverb"]) == ("reverb_big_mac_kernel", "reverb_mac_tiled_kernel")
+    assert b.precollect_pmc(a, 2)[0] is None and "N = 1" in b.precollect_pmc(a, 2)[1]
+    line = {"metric": "m", "value": 1.0, "unit": "u", "steps": 32, "warmup": 8, "prewarm_steps": 248, "ms_per_step": 0.3,
+            "real_time_factor": 2.0, "verified": True, "step_split_ms": {"reverb_stage": 0.1},
+            "config": {"workload": "w", "sources_per_gpu": 256, "block": 128, "blocks_per_step": 256, "source_group": 16,
+                       "kernels": ["k"], "interp_table": {}, "parallelism": "1 GPU"},
+            "roofline": {"kernel": "k", "bound": "hbm", "avg_stage_ms": 0.11, "algorithmic_bytes_per_step": 5e8, "achieved": 4.6e3,
+                         "peak": 8e3, "unit": "GB/s", "frac": 0.58, "traffic": 3.5e8, "flops_per_step": 1.0},
+            "cpu_baseline": {"value": 3e7, "unit": "u", "cores": 16, "kind": "port", "sample": "s", "gpu_over_cpu": 1e3},
+            "verification": {"max_abs_err_mix": 1e-7, "mix_peak": 1.0, "bound_mix": 1e-5, "against": "oracle"}}
+    br = b.brief(line, ("kernel", "bound", "avg_stage_ms", "algorithmic_bytes_per_step", "frac", "traffic"))
+    assert br["verified"] is True and br["roofline"] == {"kernel": "k", "bound": "hbm", "avg_stage_ms": 0.11,
+                                                         "algorithmic_bytes_per_step": 5e8, "frac": 0.58, "traffic": 3.5e8}
+    assert "parallelism" not in br["config"] and br["cpu_baseline"]["cores"] == 16 and b.brief(None, ()) is None
+
+
 # ---------------------------------------------------------------- jefferson_group.h (one job over a node's GPUs) --
 def _group(jf):
     import importlib
