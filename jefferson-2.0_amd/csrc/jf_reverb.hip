@@ -375,8 +375,11 @@ constexpr int rv_big_len(int n) { return JF_RV_BIG_XOR ? n : rv_buf_len<true>(n)
 // since every thread has read its butterflies' inputs before any thread writes (a barrier between), one buffer per transform
 // is enough.  The input comes in REGISTERS: v[t][r] = x_t[tid + r NPT / 8] of threads tid < NPT / 8 (the first pass needs no
 // twiddles and reads nothing from LDS: the caller loads straight from global memory).  The results lie in buf[t] in natural order.
-template <int NPT, int DIR, int NT, int NTR, int LEN>
+// UPPER_HALF: only elements NPT / 2 .. NPT - 1 of the result are formed and stored (the inverse kernel's overlap-save keeps the
+// second half of its 2 B1 samples = the upper half of the complex result: the last pass's other outputs are never read).
+template <int NPT, int DIR, int NT, bool UPPER_HALF = false, int NTR, int LEN>
 JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwiddles<NPT, NT> &tw, const float2 *s_w8, int tid) {
+    static_assert(!(UPPER_HALF && JF_RV_BIG_XOR), "written for the padded layout");
     constexpr int N8 = NPT / 8;  // radix-8 butterflies per pass, one per thread
     const bool on = tid < N8;
 #if !JF_RV_BIG_XOR
@@ -456,7 +459,7 @@ JF_DEV void cfft_wg(float2 (&v)[NTR][8], float2 (&buf)[NTR][LEN], const BigTwidd
 #pragma unroll
         for (int u = 0; u < NL; u++)
 #pragma unroll
-            for (int r = 0; r < RL; r++) io[288 * u + r * 576] = v[t][u * RL + r];
+            for (int r = UPPER_HALF ? RL / 2 : 0; r < RL; r++) io[288 * u + r * 576] = v[t][u * RL + r];
     }
     __syncthreads();
 #else
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(kBigThreads, JF_RV_BIG_IFFT_HALVES ? JF_RV_BIG_IFFT
         untangle(0, 8);
 #endif
         if (tid == 0) v[0][0] = make_float2(0.5f * (y0.x + y0.y), 0.5f * (y0.x - y0.y));
-        cfft_wg<B1, +1, kBigThreads>(v, s_buf, tw, s_w8, tid);
+        cfft_wg<B1, +1, kBigThreads, true>(v, s_buf, tw, s_w8, tid);  // (only z[m], m >= B1 / 2, is read below)
         {
             const float2 *zt = s_buf[0];
             // overlap-save: time samples B1 .. 2 B1 - 1 = z[m], m >= B1 / 2
