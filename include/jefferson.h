@@ -366,6 +366,7 @@ int jf_synchronize(jf_engine *e);
 /*
  * The mix of the last jf_batch_run into host memory: waits for the engine's stream, then copies blocks 0 .. n_blocks - 1 of
  * the engine's own mix buffer (the one jf_batch_run fills when d_out_mix == NULL) to out_mix[n_blocks][2 * frames_per_buffer].
+ * JF_ERR_STATE if the last jf_batch_run was given a device pointer of the caller's, failed, or left fewer than n_blocks there.
  * With jf_batch_upload_positions / jf_batch_run / jf_synchronize this completes the device-resident form of callback_func's
  * loop (Audio.cu:104-117 over many callbacks) without a device pointer in the host's hands; hosts that keep the mix on the
  * device (a reduce over several GPUs: jf_group.c) use the accessors of jefferson_debug.h.

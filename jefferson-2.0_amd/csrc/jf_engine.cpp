@@ -951,8 +951,10 @@ int jf_batch_run(jf_engine *e, int first_block, int n_blocks, float *d_out_mix) 
     if (first_block < 0 || first_block + n_blocks > e->traj_blocks)
         return fail(e, JF_ERR_ARG, "window outside the uploaded trajectory");
     if (e->in_flight) return fail(e, JF_ERR_STATE, "a per-block call is in flight");
-    return run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix,
-                      first_block);
+    const int rc = run_blocks(e, e->d_traj + (size_t)first_block * e->S * 5, n_blocks, d_out_mix ? d_out_mix : e->d_mix,
+                              first_block);
+    e->own_mix_blocks = rc == JF_OK && !d_out_mix ? n_blocks : 0;  // what jf_batch_fetch may hand out
+    return rc;
     });
 }
 
@@ -1065,6 +1067,9 @@ int jf_batch_fetch(jf_engine *e, int n_blocks, float *out_mix) {
     return jf_guard([&]() -> int {
     DeviceGuard bind(e);
     if (!e || !out_mix || n_blocks <= 0 || n_blocks > e->maxK) return fail(e, JF_ERR_ARG, "bad fetch arguments");
+    if (n_blocks > e->own_mix_blocks)
+        return fail(e, JF_ERR_STATE, "jf_batch_fetch: the last jf_batch_run did not leave that many blocks in the engine's own buffer "
+                                     "(it was given a device pointer, failed, or has not run)");
     JF_HIP(e, hipMemcpyAsync(out_mix, e->d_mix, sizeof(float) * 2 * e->B * (size_t)n_blocks, hipMemcpyDeviceToHost, e->stream));
     JF_HIP(e, hipStreamSynchronize(e->stream));
     if (device_fault(e)) return fail(e, JF_ERR_DEVICE, kHandOffMsg);

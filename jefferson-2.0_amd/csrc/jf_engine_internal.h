@@ -80,6 +80,7 @@ constexpr int kRtMaxWgs = 128;  // workgroups (8 or 16 waves, a source per wave 
 
 struct jf_engine {
     jf_config cfg{};
+    int own_mix_blocks = 0;  // blocks the last jf_batch_run left in d_mix (0: it wrote to the caller's buffer, failed or has not run)
     int B = 0, S = 0, maxK = 0;
     hipStream_t stream = nullptr;
     std::string err;

@@ -186,6 +186,41 @@ def test_wrap_short_and_empty_signals(jf, hrir):
             assert not y.any()
 
 
+def test_batch_fetch_completes_the_device_resident_form(jf, hrir, castanets):
+    """jf_batch_upload_positions + jf_batch_run(NULL) + jf_batch_fetch (round 6: the device-resident form of callback_func's loop,
+    Audio.cu:104-117, without a device pointer in the host's hands) hands out what jf_process_batch hands out, bit for bit;
+    JF_ERR_STATE before any run, for more blocks than the run left, and after a run into a buffer of the caller's."""
+    B, K = 256, 6
+    pos = np.stack([np.stack([jf.position_from_spherical(5 * (b % 3), 10 * b + 3 * s, 0.5 + 0.1 * s) for s in range(3)])
+                    for b in range(2 * K)]).astype(np.float32)
+    a = jf.Engine(B, 512, 3, hrir=hrir, max_batch_blocks=K)
+    b = jf.Engine(B, 512, 3, hrir=hrir, max_batch_blocks=K)
+    for e in (a, b):
+        for s in range(3):
+            e.set_signal(s, castanets[1000 * s: 1000 * s + 30000])
+    with pytest.raises(jf.JfError) as ex:
+        a.batch_fetch(1)
+    assert ex.value.code == jf.JF_ERR_STATE
+    want = b.process_batch(pos)
+    a.upload_positions(pos)
+    got = []
+    for k0 in (0, K):
+        a.batch_run(k0, K)
+        got.append(a.batch_fetch(K))
+    assert np.array_equal(np.concatenate(got), want)
+    a.batch_run(0, 2)
+    assert a.batch_fetch(2).shape == (2, 2 * B)
+    with pytest.raises(jf.JfError) as ex:
+        a.batch_fetch(3)                      # the run left two blocks
+    assert ex.value.code == jf.JF_ERR_STATE
+    a.batch_run(2, 2, a.mix_device_ptr())     # a device pointer of the caller's (here: the engine's own, but the engine cannot know)
+    with pytest.raises(jf.JfError) as ex:
+        a.batch_fetch(2)
+    assert ex.value.code == jf.JF_ERR_STATE
+    a.close()
+    b.close()
+
+
 def test_invalid_batch_positions_are_silence_not_faults(jf, hrir, castanets):
     """Records a caller could hand to the batch call without going through the setters."""
     e = jf.Engine(256, 512, 3, hrir=hrir, max_batch_blocks=4)
